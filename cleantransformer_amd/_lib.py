@@ -1,0 +1,95 @@
+"""ctypes binding of libctmi355.so — the C-ABI boundary declared in include/ctmi355.h.
+
+The product path has no CPU fallback: if the HIP library is missing or an entry point fails,
+an exception is raised (``CtmiError``)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from ._build import LIB_PATH
+
+F32, BF16 = 0, 1
+EPI_NONE, EPI_GELU, EPI_DGELU, EPI_RELU, EPI_DRELU = 0, 1, 2, 3, 4
+MT_MAX = 24
+ABI_VERSION = 1
+
+vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
+
+
+class CtmiError(RuntimeError):
+    pass
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [(n, i64) for n in ("B", "nh", "Sq", "Sk", "hd",
+                                   "q_bs", "q_hs", "q_rs", "k_bs", "k_hs", "k_rs",
+                                   "v_bs", "v_hs", "v_rs", "o_bs", "o_hs", "o_rs",
+                                   "am_b", "am_h", "am_q", "am_k")] + [("scale", f32), ("causal", i32)]
+
+
+# name -> (restype, argtypes); must mirror include/ctmi355.h exactly (checked by tests/test_abi.py)
+PROTOTYPES = {
+    "ctmi_abi_version": (i32, []),
+    "ctmi_last_error": (C.c_char_p, []),
+    "ctmi_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, f32, i32, vp]),
+    "ctmi_layernorm_bwd_ws": (i64, [i64, i64]),
+    "ctmi_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i64, i64, i32, vp]),
+    "ctmi_gemm": (i32, [vp, i64, i32, vp, i64, i32, vp, i64, i64, i64, i64, f32, i32, vp, vp, i32, vp, vp, i32, i32, vp]),
+    "ctmi_colsum": (i32, [vp, i64, vp, i32, vp, i64, i64, i32, vp]),
+    "ctmi_colsum_ws": (i64, [i64, i64]),
+    "ctmi_attn_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(AttnDesc), i32, vp]),
+    "ctmi_attn_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(AttnDesc), i32, vp]),
+    "ctmi_mask_prep": (i32, [vp, vp, vp, vp, i64, i64, vp]),
+    "ctmi_embed_fwd": (i32, [vp, vp, vp, i64, i64, i64, i32, vp, vp]),
+    "ctmi_embed_bwd": (i32, [vp, vp, vp, i64, i64, i64, i32, vp]),
+    "ctmi_ce_fwd": (i32, [vp, i64, vp, vp, vp, vp, i64, i64, i64, i64, i64, i32, i64, i32, vp]),
+    "ctmi_ce_bwd": (i32, [vp, i64, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i32, vp]),
+    "ctmi_adamw_step": (i32, [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64),
+                              i32, f32, f32, f32, f32, f32, i32, i32, i32, f32, vp]),
+    "ctmi_sgd_step": (i32, [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64),
+                            i32, f32, f32, f32, f32, i32, vp]),
+    "ctmi_cast": (i32, [vp, i32, vp, i32, i64, vp]),
+    "ctmi_sumsq": (i32, [vp, i64, vp, i32, vp]),
+    "ctmi_scale": (i32, [vp, i64, f32, vp, vp]),
+    "ctmi_argmax": (i32, [vp, i64, vp, i64, i64, i32, vp]),
+    "ctmi_probe": (i32, [i32, vp, vp, vp]),
+}
+
+_lib = None
+
+
+def lib_path() -> str:
+    return LIB_PATH
+
+
+def load():
+    """Load (once) and type the shared library.  Raises CtmiError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CtmiError(
+            f"{LIB_PATH} is missing: the MI355X kernels are not built. Run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (needs hipcc). There is no CPU fallback for the product path.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:                                       # pragma: no cover
+        raise CtmiError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise CtmiError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ctmi_abi_version() != ABI_VERSION:
+        raise CtmiError(f"ABI mismatch: library {lib.ctmi_abi_version()} vs binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().ctmi_last_error()
+        raise CtmiError(f"{what} failed (status {rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,583 @@
+// Fused (flash-style) attention for gfx950: ALiBi + causal + key-padding mask (+ optional additive mask),
+// forward and backward, never materialising the [S,S] score matrix.
+//   reference: modeling_bloom.py:84-116 (BloomAttentionLayer core), transformer.py:40-57 (AttentionLayer core)
+//
+// Layout idea (all three kernels): a 256-thread workgroup handles 64 "own" rows (queries in fwd/dq, keys in
+// dk/dv), 16 per wavefront, and streams the other sequence dimension through LDS in tiles of 64.  Every MFMA is
+// issued so that the wave's own row index sits in the accumulator COLUMN (lane & 15): each lane then owns exactly
+// one query (or key) row, the softmax statistics are per-lane scalars (2 shuffles per tile instead of 16), and the
+// probabilities / dS values come out of the first MFMA already in operand layout for the second one — no LDS
+// round trip for P.  The operand that must be contracted over the streamed dimension (V, K, Q, dO) is staged
+// transposed in LDS ([d][64]) so its fragments are two 8-byte reads.
+// Masked scores take finfo(float).min like the reference's masked_fill, so all-masked rows become uniform.
+#include "common.h"
+#include "mma.h"
+
+struct AttnP {
+    const void *q, *k, *v, *o, *d_o;
+    void *out, *dq, *dk, *dv;
+    float *stat_m, *stat_l, *delta;
+    const float *slopes, *kpos, *add_mask;
+    const int32_t *kvalid, *first_valid;
+    int64_t B, nh, Sq, Sk, hd;
+    int64_t q_bs, q_hs, q_rs, k_bs, k_hs, k_rs, v_bs, v_hs, v_rs, o_bs, o_hs, o_rs;
+    int64_t am_b, am_h, am_q, am_k;
+    float scale;
+    int causal, off, vec_ok;
+};
+
+// 64 x HDP tile staging helpers (256 threads).  Thread -> (row = id & 63, 16-byte chunk = id >> 6): lane == row,
+// so the transposed scatter into [d][64] writes 64 consecutive elements per instruction (conflict-free) and the
+// row-major b128 writes hit 8 different bank groups.
+template <typename T, int HDP>
+struct AT {
+    static constexpr int VEC = 16 / sizeof(T);
+    static constexpr int CPR = HDP / VEC;
+    static constexpr int NCH = (64 * CPR) / 256;
+    static constexpr int PRM = HDP + VEC;                                   // row-major pitch
+    static constexpr int PTR = 64 + (sizeof(T) == 2 ? 8 : 4);               // transposed pitch
+    static constexpr int RM_ELEMS = 64 * PRM;
+    static constexpr int TR_ELEMS = HDP * PTR;
+    static_assert((64 * CPR) % 256 == 0, "tile must split over 256 threads");
+
+    static __device__ __forceinline__ void load(uint4 (&regs)[NCH], const T* __restrict__ base, int64_t rs, int64_t row0,
+                                                int64_t nrows, int hd, bool vec_ok, int tid) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int id = tid + 256 * i;
+            const int row = id & 63, c = (id >> 6) * VEC;
+            const int64_t grow = row0 + row;
+            const T* p = base + grow * rs + c;
+            if (grow < nrows && c + VEC <= hd && vec_ok) {
+                regs[i] = *reinterpret_cast<const uint4*>(p);
+            } else {
+                T tmp[VEC];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) tmp[j] = (grow < nrows && c + j < hd) ? p[j] : (T)0;
+                regs[i] = *reinterpret_cast<const uint4*>(tmp);
+            }
+        }
+    }
+    static __device__ __forceinline__ void store_rm(const uint4 (&regs)[NCH], T* __restrict__ tile, int tid) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int id = tid + 256 * i;
+            *reinterpret_cast<uint4*>(tile + (id & 63) * PRM + (id >> 6) * VEC) = regs[i];
+        }
+    }
+    static __device__ __forceinline__ void store_tr(const uint4 (&regs)[NCH], T* __restrict__ tile, int tid) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int id = tid + 256 * i;
+            const int row = id & 63, c = (id >> 6) * VEC;
+            const T* e = reinterpret_cast<const T*>(&regs[i]);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) tile[(c + j) * PTR + row] = e[j];
+        }
+    }
+};
+
+// fragment of a row-major [64][HDP] LDS tile: KL consecutive head-dim elements of `row`
+template <typename T, int HDP> __device__ __forceinline__ typename Mma<T>::Frag frag_rm(const T* __restrict__ tile, int row, int kofs);
+template <> __device__ __forceinline__ short8 frag_rm<bf16_t, 32>(const bf16_t* __restrict__ t, int row, int kofs) { return *reinterpret_cast<const short8*>(t + row * AT<bf16_t, 32>::PRM + kofs); }
+template <> __device__ __forceinline__ short8 frag_rm<bf16_t, 64>(const bf16_t* __restrict__ t, int row, int kofs) { return *reinterpret_cast<const short8*>(t + row * AT<bf16_t, 64>::PRM + kofs); }
+template <> __device__ __forceinline__ short8 frag_rm<bf16_t, 128>(const bf16_t* __restrict__ t, int row, int kofs) { return *reinterpret_cast<const short8*>(t + row * AT<bf16_t, 128>::PRM + kofs); }
+template <> __device__ __forceinline__ float frag_rm<float, 32>(const float* __restrict__ t, int row, int kofs) { return t[row * AT<float, 32>::PRM + kofs]; }
+template <> __device__ __forceinline__ float frag_rm<float, 64>(const float* __restrict__ t, int row, int kofs) { return t[row * AT<float, 64>::PRM + kofs]; }
+template <> __device__ __forceinline__ float frag_rm<float, 128>(const float* __restrict__ t, int row, int kofs) { return t[row * AT<float, 128>::PRM + kofs]; }
+
+// fragment straight from HBM: KL consecutive elements of one row (row == nullptr -> zeros)
+template <typename T> __device__ __forceinline__ typename Mma<T>::Frag frag_global(const T* row, int kofs, int hd, bool vec_ok);
+template <> __device__ __forceinline__ short8 frag_global<bf16_t>(const bf16_t* row, int kofs, int hd, bool vec_ok) {
+    short8 f = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (row == nullptr) return f;
+    if (kofs + 8 <= hd && vec_ok) return *reinterpret_cast<const short8*>(row + kofs);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (kofs + j < hd) ? (short)row[kofs + j] : (short)0;
+    return f;
+}
+template <> __device__ __forceinline__ float frag_global<float>(const float* row, int kofs, int hd, bool) {
+    return (row != nullptr && kofs < hd) ? row[kofs] : 0.f;
+}
+
+// x[nt][r] = sum_d tile[nt*16 + (g*4+r)][d] * own[d]   (tile rows stream, lane's own row from registers)
+template <typename T, int HDP>
+__device__ __forceinline__ void dot_tile(f32x4 (&x)[4], const T* __restrict__ rm_tile,
+                                         const typename Mma<T>::Frag (&own)[HDP / Mma<T>::K], int lane) {
+    constexpr int MK = Mma<T>::K, KL = Mma<T>::KL;
+    const int g = lane >> 4, li = lane & 15;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        x[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < HDP / MK; ++kk)
+            x[nt] = Mma<T>::mma(frag_rm<T, HDP>(rm_tile, nt * 16 + li, kk * MK + g * KL), own[kk], x[nt]);
+    }
+}
+
+// acc[dt][r] += sum_{j in tile} tr_tile[dt*16 + g*4 + r][j] * x(j)      with x in accumulator layout:
+// x[nt][r] belongs to streamed index j = nt*16 + g*4 + r of the lane's own column.
+template <typename T, int HDP>
+__device__ __forceinline__ void contract64(f32x4 (&acc)[HDP / 16], const T* __restrict__ tr_tile, const f32x4 (&x)[4], int lane) {
+    constexpr int PTR = AT<T, HDP>::PTR;
+    const int g = lane >> 4, li = lane & 15;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const f32x4 lo = x[2 * ks], hi = x[2 * ks + 1];
+            uint4 pk = make_uint4(pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3]), pack_bf2(hi[0], hi[1]), pack_bf2(hi[2], hi[3]));
+            const short8 b = __builtin_bit_cast(short8, pk);
+#pragma unroll
+            for (int dt = 0; dt < HDP / 16; ++dt) {
+                const bf16_t* rowp = tr_tile + (dt * 16 + li) * PTR + ks * 32 + g * 4;
+                const uint2 a0 = *reinterpret_cast<const uint2*>(rowp);
+                const uint2 a1 = *reinterpret_cast<const uint2*>(rowp + 16);
+                const short8 a = __builtin_bit_cast(short8, make_uint4(a0.x, a0.y, a1.x, a1.y));
+                acc[dt] = Mma<bf16_t>::mma(a, b, acc[dt]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float b = x[nt][r];
+#pragma unroll
+                for (int dt = 0; dt < HDP / 16; ++dt)
+                    acc[dt] = Mma<float>::mma(tr_tile[(dt * 16 + li) * PTR + nt * 16 + g * 4 + r], b, acc[dt]);
+            }
+    }
+}
+
+// score of (q, key) given the raw dot product; masked -> FINFO_MIN (modeling_bloom.py:99-109)
+__device__ __forceinline__ float score_of(const AttnP& p, float dot, int64_t b, int64_t h, int64_t q, int64_t key, float slope, bool& masked) {
+    masked = (p.causal && key > q + p.off) || (p.kvalid != nullptr && p.kvalid[b * p.Sk + key] == 0);
+    if (masked) return FINFO_MIN;
+    float s = dot * p.scale;
+    if (p.slopes != nullptr) s += slope * p.kpos[b * p.Sk + key];
+    if (p.add_mask != nullptr) s += p.add_mask[b * p.am_b + h * p.am_h + q * p.am_q + key * p.am_k];
+    return s;
+}
+
+template <typename T, int HDP>
+__device__ __forceinline__ void store_own_row(T* rowp, const f32x4 (&acc)[HDP / 16], float mul, int hd, int g, bool vec_ok) {
+#pragma unroll
+    for (int dt = 0; dt < HDP / 16; ++dt) {
+        const int d = dt * 16 + g * 4;
+        if (d >= hd) continue;
+        float v[4] = {acc[dt][0] * mul, acc[dt][1] * mul, acc[dt][2] * mul, acc[dt][3] * mul};
+        if (d + 4 <= hd && vec_ok) {
+            if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2*>(rowp + d) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            else *reinterpret_cast<float4*>(rowp + d) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            for (int r = 0; r < 4; ++r) if (d + r < hd) rowp[d + r] = Cvt<T>::from_f(v[r]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <typename T, int HDP>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
+    using A = AT<T, HDP>;
+    constexpr int MK = Mma<T>::K, KL = Mma<T>::KL, NKK = HDP / MK, NDT = HDP / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* Ks = reinterpret_cast<T*>(smem_raw);
+    T* Vt = Ks + A::RM_ELEMS;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, li = lane & 15;
+    const int nqb = (int)((p.Sq + 63) / 64);
+    const int qb = nqb - 1 - (int)(blockIdx.x % nqb);                       // longest (latest) query blocks first
+    const int64_t bh = blockIdx.x / nqb, h = bh % p.nh, b = bh / p.nh;
+    const int64_t q0 = (int64_t)qb * 64, my_q = q0 + wid * 16 + li;
+    const T* qp = reinterpret_cast<const T*>(p.q) + b * p.q_bs + h * p.q_hs;
+    const T* kp = reinterpret_cast<const T*>(p.k) + b * p.k_bs + h * p.k_hs;
+    const T* vp = reinterpret_cast<const T*>(p.v) + b * p.v_bs + h * p.v_hs;
+    const float slope = p.slopes ? p.slopes[h] : 0.f;
+
+    typename Mma<T>::Frag qf[NKK];
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk)
+        qf[kk] = frag_global<T>(my_q < p.Sq ? qp + my_q * p.q_rs : nullptr, kk * MK + g * KL, (int)p.hd, p.vec_ok);
+
+    int64_t kv_end = p.Sk;
+    if (p.causal) {
+        kv_end = min(p.Sk, q0 + 63 + p.off + 1);
+        if (kv_end < 1) kv_end = 1;
+        // a query row whose whole causal window is padding sees only masked keys -> uniform over ALL keys
+        if (p.kvalid != nullptr && p.first_valid[b] > q0 + p.off) kv_end = p.Sk;
+    }
+    const int ntiles = (int)((kv_end + 63) / 64);
+
+    float m = -INFINITY, lsum = 0.f;
+    f32x4 acc[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    uint4 rk[A::NCH], rv[A::NCH];
+    A::load(rk, kp, p.k_rs, 0, p.Sk, (int)p.hd, p.vec_ok, tid);
+    A::load(rv, vp, p.v_rs, 0, p.Sk, (int)p.hd, p.vec_ok, tid);
+    A::store_rm(rk, Ks, tid);
+    A::store_tr(rv, Vt, tid);
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) {
+            A::load(rk, kp, p.k_rs, (int64_t)(t + 1) * 64, p.Sk, (int)p.hd, p.vec_ok, tid);
+            A::load(rv, vp, p.v_rs, (int64_t)(t + 1) * 64, p.Sk, (int)p.hd, p.vec_ok, tid);
+        }
+        f32x4 x[4];
+        dot_tile<T, HDP>(x, Ks, qf, lane);                                   // x[nt][r] = q . k[key]
+        const int64_t kv0 = (int64_t)t * 64;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t key = kv0 + nt * 16 + g * 4 + r;
+                float s = -INFINITY;                                        // keys beyond Sk do not exist
+                if (key < p.Sk) { bool msk; s = score_of(p, x[nt][r], b, h, my_q < p.Sq ? my_q : 0, key, slope, msk); }
+                x[nt][r] = s;
+                mx = fmaxf(mx, s);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m, mx);                                   // finite: every tile holds >= 1 real key
+        const float alpha = __expf(m - m_new);
+        float rs = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = __expf(x[nt][r] - m_new);
+                x[nt][r] = pv;
+                rs += pv;
+            }
+        lsum = lsum * alpha + rs;
+        m = m_new;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) acc[dt] *= alpha;
+        contract64<T, HDP>(acc, Vt, x, lane);                               // acc[dt][r] = O^T[d][my_q]
+        __syncthreads();
+        if (t + 1 < ntiles) {
+            A::store_rm(rk, Ks, tid);
+            A::store_tr(rv, Vt, tid);
+            __syncthreads();
+        }
+    }
+    lsum += __shfl_xor(lsum, 16, 64);
+    lsum += __shfl_xor(lsum, 32, 64);
+    if (my_q < p.Sq) {
+        T* op = reinterpret_cast<T*>(p.out) + b * p.o_bs + h * p.o_hs + my_q * p.o_rs;
+        store_own_row<T, HDP>(op, acc, 1.0f / lsum, (int)p.hd, g, p.vec_ok);
+        if (g == 0) {
+            p.stat_m[(b * p.nh + h) * p.Sq + my_q] = m;
+            p.stat_l[(b * p.nh + h) * p.Sq + my_q] = lsum;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ delta = rowsum(dO * O)
+template <typename T>
+__global__ __launch_bounds__(256) void attn_delta_kernel(AttnP p) {
+    const int lane = threadIdx.x & 63;
+    const int64_t rows = p.B * p.nh * p.Sq;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+        const int64_t q = row % p.Sq, bh = row / p.Sq, h = bh % p.nh, b = bh / p.nh;
+        const int64_t base = b * p.o_bs + h * p.o_hs + q * p.o_rs;
+        const T* o = reinterpret_cast<const T*>(p.o) + base;
+        const T* go = reinterpret_cast<const T*>(p.d_o) + base;
+        float s = 0.f;
+        for (int d = lane; d < p.hd; d += 64) s += Cvt<T>::to_f(o[d]) * Cvt<T>::to_f(go[d]);
+        s = wave_sum(s);
+        if (lane == 0) p.delta[row] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dK, dV
+// own rows = keys.  Per query tile: S = Q K^T and dP = dO V^T (own key in the accumulator column), P = exp(S-m)/l,
+// dS = P (dP - delta); dV^T += dO^T P, dK^T += Q^T dS  (Q, dO staged both row-major and transposed).
+template <typename T, int HDP>
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnP p) {
+    using A = AT<T, HDP>;
+    constexpr int MK = Mma<T>::K, KL = Mma<T>::KL, NKK = HDP / MK, NDT = HDP / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* Qs = reinterpret_cast<T*>(smem_raw);
+    T* Qt = Qs + A::RM_ELEMS;
+    T* Gs = Qt + A::TR_ELEMS;
+    T* Gt = Gs + A::RM_ELEMS;
+    float* st = reinterpret_cast<float*>(Gt + A::TR_ELEMS);                  // [3][64]: m, 1/l, delta
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, li = lane & 15;
+    const int nkb = (int)((p.Sk + 63) / 64);
+    const int kb = (int)(blockIdx.x % nkb);                                  // early key blocks (most work) first
+    const int64_t bh = blockIdx.x / nkb, h = bh % p.nh, b = bh / p.nh;
+    const int64_t k0 = (int64_t)kb * 64, my_k = k0 + wid * 16 + li;
+    const T* qp = reinterpret_cast<const T*>(p.q) + b * p.q_bs + h * p.q_hs;
+    const T* kp = reinterpret_cast<const T*>(p.k) + b * p.k_bs + h * p.k_hs;
+    const T* vp = reinterpret_cast<const T*>(p.v) + b * p.v_bs + h * p.v_hs;
+    const T* gp = reinterpret_cast<const T*>(p.d_o) + b * p.o_bs + h * p.o_hs;
+    const float slope = p.slopes ? p.slopes[h] : 0.f;
+
+    typename Mma<T>::Frag kf[NKK], vf[NKK];
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+        kf[kk] = frag_global<T>(my_k < p.Sk ? kp + my_k * p.k_rs : nullptr, kk * MK + g * KL, (int)p.hd, p.vec_ok);
+        vf[kk] = frag_global<T>(my_k < p.Sk ? vp + my_k * p.v_rs : nullptr, kk * MK + g * KL, (int)p.hd, p.vec_ok);
+    }
+    f32x4 dk[NDT], dv[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    int qt_begin = 0;
+    if (p.causal) {
+        const int64_t first_q = k0 - p.off;                                  // rows q >= first_q can see key k0
+        qt_begin = first_q > 0 ? (int)(first_q / 64) : 0;
+        // all-masked query rows (q + off < first_valid) are uniform over ALL keys -> they reach every key block
+        if (p.kvalid != nullptr && p.first_valid[b] - p.off > 0) qt_begin = 0;
+    }
+    const int qt_end = (int)((p.Sq + 63) / 64);
+    const float* sm = p.stat_m + (b * p.nh + h) * p.Sq;
+    const float* sl = p.stat_l + (b * p.nh + h) * p.Sq;
+    const float* sd = p.delta + (b * p.nh + h) * p.Sq;
+
+    uint4 rq[A::NCH], rg[A::NCH];
+    float rstat = 0.f;
+    auto load_stats = [&](int t) {
+        const int64_t q = (int64_t)t * 64 + (tid & 63);
+        const int which = tid >> 6;
+        if (which == 0) rstat = q < p.Sq ? sm[q] : 0.f;
+        else if (which == 1) rstat = q < p.Sq ? 1.0f / sl[q] : 0.f;
+        else if (which == 2) rstat = q < p.Sq ? sd[q] : 0.f;
+    };
+    if (qt_begin < qt_end) {
+        A::load(rq, qp, p.q_rs, (int64_t)qt_begin * 64, p.Sq, (int)p.hd, p.vec_ok, tid);
+        A::load(rg, gp, p.o_rs, (int64_t)qt_begin * 64, p.Sq, (int)p.hd, p.vec_ok, tid);
+        load_stats(qt_begin);
+        A::store_rm(rq, Qs, tid); A::store_tr(rq, Qt, tid);
+        A::store_rm(rg, Gs, tid); A::store_tr(rg, Gt, tid);
+        if (tid < 192) st[tid] = rstat;
+    }
+    __syncthreads();
+
+    for (int t = qt_begin; t < qt_end; ++t) {
+        if (t + 1 < qt_end) {
+            A::load(rq, qp, p.q_rs, (int64_t)(t + 1) * 64, p.Sq, (int)p.hd, p.vec_ok, tid);
+            A::load(rg, gp, p.o_rs, (int64_t)(t + 1) * 64, p.Sq, (int)p.hd, p.vec_ok, tid);
+            load_stats(t + 1);
+        }
+        f32x4 x[4], y[4];
+        dot_tile<T, HDP>(x, Qs, kf, lane);                                   // x[nt][r] = q[qi] . k[my_k]
+        dot_tile<T, HDP>(y, Gs, vf, lane);                                   // y[nt][r] = dO[qi] . v[my_k]
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const f32x4 mm = *reinterpret_cast<const f32x4*>(st + nt * 16 + g * 4);
+            const f32x4 il = *reinterpret_cast<const f32x4*>(st + 64 + nt * 16 + g * 4);
+            const f32x4 dl = *reinterpret_cast<const f32x4*>(st + 128 + nt * 16 + g * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t q = (int64_t)t * 64 + nt * 16 + g * 4 + r;
+                float pr = 0.f, ds = 0.f;
+                if (q < p.Sq && my_k < p.Sk) {
+                    bool msk;
+                    const float s = score_of(p, x[nt][r], b, h, q, my_k, slope, msk);
+                    pr = __expf(s - mm[r]) * il[r];
+                    ds = msk ? 0.f : pr * (y[nt][r] - dl[r]);
+                }
+                x[nt][r] = pr;
+                y[nt][r] = ds;
+            }
+        }
+        contract64<T, HDP>(dv, Gt, x, lane);                                 // dV^T[d][my_k] += sum_q dO[q][d] P[q][my_k]
+        contract64<T, HDP>(dk, Qt, y, lane);                                 // dK^T[d][my_k] += sum_q Q[q][d] dS[q][my_k]
+        __syncthreads();
+        if (t + 1 < qt_end) {
+            A::store_rm(rq, Qs, tid); A::store_tr(rq, Qt, tid);
+            A::store_rm(rg, Gs, tid); A::store_tr(rg, Gt, tid);
+            if (tid < 192) st[tid] = rstat;
+            __syncthreads();
+        }
+    }
+    if (my_k < p.Sk) {
+        T* dkp = reinterpret_cast<T*>(p.dk) + b * p.k_bs + h * p.k_hs + my_k * p.k_rs;
+        T* dvp = reinterpret_cast<T*>(p.dv) + b * p.v_bs + h * p.v_hs + my_k * p.v_rs;
+        store_own_row<T, HDP>(dkp, dk, p.scale, (int)p.hd, g, p.vec_ok);
+        store_own_row<T, HDP>(dvp, dv, 1.0f, (int)p.hd, g, p.vec_ok);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dQ
+// own rows = queries.  Per key tile: S^T = K Q^T, dP^T = V dO^T, dS^T = P^T (dP^T - delta); dQ^T += K^T dS^T.
+template <typename T, int HDP>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
+    using A = AT<T, HDP>;
+    constexpr int MK = Mma<T>::K, KL = Mma<T>::KL, NKK = HDP / MK, NDT = HDP / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* Ks = reinterpret_cast<T*>(smem_raw);
+    T* Kt = Ks + A::RM_ELEMS;
+    T* Vs = Kt + A::TR_ELEMS;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, li = lane & 15;
+    const int nqb = (int)((p.Sq + 63) / 64);
+    const int qb = nqb - 1 - (int)(blockIdx.x % nqb);
+    const int64_t bh = blockIdx.x / nqb, h = bh % p.nh, b = bh / p.nh;
+    const int64_t q0 = (int64_t)qb * 64, my_q = q0 + wid * 16 + li;
+    const bool live = my_q < p.Sq;
+    const T* qp = reinterpret_cast<const T*>(p.q) + b * p.q_bs + h * p.q_hs;
+    const T* kp = reinterpret_cast<const T*>(p.k) + b * p.k_bs + h * p.k_hs;
+    const T* vp = reinterpret_cast<const T*>(p.v) + b * p.v_bs + h * p.v_hs;
+    const T* gp = reinterpret_cast<const T*>(p.d_o) + b * p.o_bs + h * p.o_hs;
+    const float slope = p.slopes ? p.slopes[h] : 0.f;
+
+    typename Mma<T>::Frag qf[NKK], gf[NKK];
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+        qf[kk] = frag_global<T>(live ? qp + my_q * p.q_rs : nullptr, kk * MK + g * KL, (int)p.hd, p.vec_ok);
+        gf[kk] = frag_global<T>(live ? gp + my_q * p.o_rs : nullptr, kk * MK + g * KL, (int)p.hd, p.vec_ok);
+    }
+    const int64_t srow = (b * p.nh + h) * p.Sq + my_q;
+    const float m = live ? p.stat_m[srow] : 0.f;
+    const float il = live ? 1.0f / p.stat_l[srow] : 0.f;
+    const float dl = live ? p.delta[srow] : 0.f;
+
+    int64_t kv_end = p.Sk;
+    if (p.causal) { kv_end = min(p.Sk, q0 + 63 + p.off + 1); if (kv_end < 1) kv_end = 1; }   // masked entries have dS = 0
+    const int ntiles = (int)((kv_end + 63) / 64);
+
+    f32x4 dq[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    uint4 rk[A::NCH], rv[A::NCH];
+    A::load(rk, kp, p.k_rs, 0, p.Sk, (int)p.hd, p.vec_ok, tid);
+    A::load(rv, vp, p.v_rs, 0, p.Sk, (int)p.hd, p.vec_ok, tid);
+    A::store_rm(rk, Ks, tid); A::store_tr(rk, Kt, tid);
+    A::store_rm(rv, Vs, tid);
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) {
+            A::load(rk, kp, p.k_rs, (int64_t)(t + 1) * 64, p.Sk, (int)p.hd, p.vec_ok, tid);
+            A::load(rv, vp, p.v_rs, (int64_t)(t + 1) * 64, p.Sk, (int)p.hd, p.vec_ok, tid);
+        }
+        f32x4 x[4], y[4];
+        dot_tile<T, HDP>(x, Ks, qf, lane);
+        dot_tile<T, HDP>(y, Vs, gf, lane);
+        const int64_t kv0 = (int64_t)t * 64;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t key = kv0 + nt * 16 + g * 4 + r;
+                float ds = 0.f;
+                if (live && key < p.Sk) {
+                    bool msk;
+                    const float s = score_of(p, x[nt][r], b, h, my_q, key, slope, msk);
+                    ds = msk ? 0.f : __expf(s - m) * il * (y[nt][r] - dl);
+                }
+                y[nt][r] = ds;
+            }
+        contract64<T, HDP>(dq, Kt, y, lane);                                 // dQ^T[d][my_q] += sum_key K[key][d] dS[my_q][key]
+        __syncthreads();
+        if (t + 1 < ntiles) {
+            A::store_rm(rk, Ks, tid); A::store_tr(rk, Kt, tid);
+            A::store_rm(rv, Vs, tid);
+            __syncthreads();
+        }
+    }
+    if (live) {
+        T* dqp = reinterpret_cast<T*>(p.dq) + b * p.q_bs + h * p.q_hs + my_q * p.q_rs;
+        store_own_row<T, HDP>(dqp, dq, p.scale, (int)p.hd, g, p.vec_ok);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static int fill_params(AttnP& p, const ctmi_attn_desc* d, int dtype, const char* who) {
+    CTMI_REQUIRE(d != nullptr, "%s: null desc", who);
+    CTMI_REQUIRE(d->B > 0 && d->nh > 0 && d->Sq > 0 && d->Sk > 0 && d->hd > 0 && d->hd <= 128, "%s: bad shape (hd must be <= 128)", who);
+    CTMI_REQUIRE(dtype == CTMI_F32 || dtype == CTMI_BF16, "%s: unsupported dtype %d", who, dtype);
+    p.B = d->B; p.nh = d->nh; p.Sq = d->Sq; p.Sk = d->Sk; p.hd = d->hd;
+    p.q_bs = d->q_bs; p.q_hs = d->q_hs; p.q_rs = d->q_rs; p.k_bs = d->k_bs; p.k_hs = d->k_hs; p.k_rs = d->k_rs;
+    p.v_bs = d->v_bs; p.v_hs = d->v_hs; p.v_rs = d->v_rs; p.o_bs = d->o_bs; p.o_hs = d->o_hs; p.o_rs = d->o_rs;
+    p.am_b = d->am_b; p.am_h = d->am_h; p.am_q = d->am_q; p.am_k = d->am_k;
+    p.scale = d->scale; p.causal = d->causal; p.off = (int)(d->Sk - d->Sq);
+    const int vec = dtype == CTMI_F32 ? 4 : 8;
+    auto ok = [&](const void* ptr, int64_t a, int64_t b2, int64_t c) {
+        return ptr == nullptr || (((((uintptr_t)ptr) & 15) == 0) && a % vec == 0 && b2 % vec == 0 && c % vec == 0);
+    };
+    p.vec_ok = ok(p.q, p.q_bs, p.q_hs, p.q_rs) && ok(p.k, p.k_bs, p.k_hs, p.k_rs) && ok(p.v, p.v_bs, p.v_hs, p.v_rs) &&
+               ok(p.out, p.o_bs, p.o_hs, p.o_rs) && ok(p.o, p.o_bs, p.o_hs, p.o_rs) && ok(p.d_o, p.o_bs, p.o_hs, p.o_rs) &&
+               ok(p.dq, p.q_bs, p.q_hs, p.q_rs) && ok(p.dk, p.k_bs, p.k_hs, p.k_rs) && ok(p.dv, p.v_bs, p.v_hs, p.v_rs);
+    return CTMI_OK;
+}
+
+template <typename T, int HDP>
+static int fwd_launch(AttnP& p, hipStream_t st) {
+    using A = AT<T, HDP>;
+    const size_t lds = (size_t)(A::RM_ELEMS + A::TR_ELEMS) * sizeof(T);
+    auto kern = &attn_fwd_kernel<T, HDP>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int64_t grid = ((p.Sq + 63) / 64) * p.B * p.nh;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, p);
+    CTMI_CHECK_LAUNCH("attn_fwd");
+    return CTMI_OK;
+}
+template <typename T, int HDP>
+static int bwd_launch(AttnP& p, hipStream_t st) {
+    using A = AT<T, HDP>;
+    {
+        const int64_t rows = p.B * p.nh * p.Sq;
+        hipLaunchKernelGGL((attn_delta_kernel<T>), dim3((unsigned)std::min<int64_t>(cdiv64(rows, 4), 8192)), dim3(256), 0, st, p);
+        CTMI_CHECK_LAUNCH("attn_delta");
+    }
+    {
+        const size_t lds = (size_t)(2 * A::RM_ELEMS + 2 * A::TR_ELEMS) * sizeof(T) + 192 * sizeof(float);
+        auto kern = &attn_bwd_dkdv_kernel<T, HDP>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const int64_t grid = ((p.Sk + 63) / 64) * p.B * p.nh;
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, p);
+        CTMI_CHECK_LAUNCH("attn_bwd_dkdv");
+    }
+    {
+        const size_t lds = (size_t)(2 * A::RM_ELEMS + A::TR_ELEMS) * sizeof(T);
+        auto kern = &attn_bwd_dq_kernel<T, HDP>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const int64_t grid = ((p.Sq + 63) / 64) * p.B * p.nh;
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, p);
+        CTMI_CHECK_LAUNCH("attn_bwd_dq");
+    }
+    return CTMI_OK;
+}
+
+#define HDP_DISPATCH(FN, T) \
+    (p.hd <= 32 ? FN<T, 32>(p, st) : (p.hd <= 64 ? FN<T, 64>(p, st) : FN<T, 128>(p, st)))
+
+extern "C" int ctmi_attn_fwd(const void* q, const void* k, const void* v, void* o, float* stat_m, float* stat_l,
+                             const float* slopes, const float* kpos, const int32_t* kvalid, const int32_t* first_valid,
+                             const float* add_mask, const ctmi_attn_desc* desc, int dtype, void* stream) {
+    CTMI_REQUIRE(q && k && v && o && stat_m && stat_l, "attn_fwd: null pointer");
+    CTMI_REQUIRE((slopes == nullptr) == (kpos == nullptr), "attn_fwd: slopes and kpos go together");
+    CTMI_REQUIRE(kvalid == nullptr || first_valid != nullptr, "attn_fwd: kvalid needs first_valid");
+    AttnP p = {};
+    p.q = q; p.k = k; p.v = v; p.out = o; p.stat_m = stat_m; p.stat_l = stat_l;
+    p.slopes = slopes; p.kpos = kpos; p.kvalid = kvalid; p.first_valid = first_valid; p.add_mask = add_mask;
+    int rc = fill_params(p, desc, dtype, "attn_fwd");
+    if (rc != CTMI_OK) return rc;
+    hipStream_t st = as_stream(stream);
+    if (dtype == CTMI_F32) return HDP_DISPATCH(fwd_launch, float);
+    return HDP_DISPATCH(fwd_launch, bf16_t);
+}
+
+extern "C" int ctmi_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                             const float* stat_m, const float* stat_l, void* dq, void* dk, void* dv, float* delta,
+                             const float* slopes, const float* kpos, const int32_t* kvalid, const int32_t* first_valid,
+                             const float* add_mask, const ctmi_attn_desc* desc, int dtype, void* stream) {
+    CTMI_REQUIRE(q && k && v && o && d_o && stat_m && stat_l && dq && dk && dv && delta, "attn_bwd: null pointer");
+    CTMI_REQUIRE((slopes == nullptr) == (kpos == nullptr), "attn_bwd: slopes and kpos go together");
+    CTMI_REQUIRE(kvalid == nullptr || first_valid != nullptr, "attn_bwd: kvalid needs first_valid");
+    AttnP p = {};
+    p.q = q; p.k = k; p.v = v; p.o = o; p.d_o = d_o; p.dq = dq; p.dk = dk; p.dv = dv;
+    p.stat_m = const_cast<float*>(stat_m); p.stat_l = const_cast<float*>(stat_l); p.delta = delta;
+    p.slopes = slopes; p.kpos = kpos; p.kvalid = kvalid; p.first_valid = first_valid; p.add_mask = add_mask;
+    int rc = fill_params(p, desc, dtype, "attn_bwd");
+    if (rc != CTMI_OK) return rc;
+    hipStream_t st = as_stream(stream);
+    if (dtype == CTMI_F32) return HDP_DISPATCH(bwd_launch, float);
+    return HDP_DISPATCH(bwd_launch, bf16_t);
+}

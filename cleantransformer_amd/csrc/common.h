@@ -1,0 +1,82 @@
+// Shared device/host helpers for the ctmi355 kernels (gfx950 / CDNA4 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/ctmi355.h"
+
+typedef uint16_t bf16_t;                                   // raw bfloat16 bits
+typedef short  short8 __attribute__((ext_vector_type(8)));   // 8 x bf16 MFMA operand (4 VGPRs)
+typedef short  short4v __attribute__((ext_vector_type(4)));
+typedef float  f32x4 __attribute__((ext_vector_type(4)));    // 16x16 MFMA accumulator
+
+#define WAVE 64
+#define FINFO_MIN (-3.4028234663852886e+38f)                // torch.finfo(torch.float32).min
+
+// ---------------------------------------------------------------- error plumbing (host)
+void ctmi_set_error(const char* fmt, ...);
+#define CTMI_REQUIRE(cond, ...) do { if (!(cond)) { ctmi_set_error(__VA_ARGS__); return CTMI_ERR_ARG; } } while (0)
+#define CTMI_CHECK_LAUNCH(name) do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) { \
+    ctmi_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); return CTMI_ERR_LAUNCH; } } while (0)
+
+// ---------------------------------------------------------------- scalar conversions
+__device__ __forceinline__ float bf2f(bf16_t x) { return __uint_as_float(((uint32_t)x) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {           // round-to-nearest-even, NaN-preserving
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+template <typename T> struct Cvt;
+template <> struct Cvt<float>  { static __device__ __forceinline__ float to_f(float x) { return x; }
+                                 static __device__ __forceinline__ float from_f(float x) { return x; } };
+template <> struct Cvt<bf16_t> { static __device__ __forceinline__ float to_f(bf16_t x) { return bf2f(x); }
+                                 static __device__ __forceinline__ bf16_t from_f(float x) { return f2bf(x); } };
+
+// 16-byte vector of T: VEC = 16/sizeof(T) elements
+template <typename T> struct Vec16 { static constexpr int N = 16 / sizeof(T); uint4 raw; };
+
+template <typename T> __device__ __forceinline__ void unpack16(const uint4& r, float* out);
+template <> __device__ __forceinline__ void unpack16<float>(const uint4& r, float* o) {
+    o[0] = __uint_as_float(r.x); o[1] = __uint_as_float(r.y); o[2] = __uint_as_float(r.z); o[3] = __uint_as_float(r.w);
+}
+template <> __device__ __forceinline__ void unpack16<bf16_t>(const uint4& r, float* o) {
+    o[0] = __uint_as_float(r.x << 16); o[1] = __uint_as_float(r.x & 0xffff0000u);
+    o[2] = __uint_as_float(r.y << 16); o[3] = __uint_as_float(r.y & 0xffff0000u);
+    o[4] = __uint_as_float(r.z << 16); o[5] = __uint_as_float(r.z & 0xffff0000u);
+    o[6] = __uint_as_float(r.w << 16); o[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ uint4 pack16(const float* in);
+template <> __device__ __forceinline__ uint4 pack16<float>(const float* i) {
+    return make_uint4(__float_as_uint(i[0]), __float_as_uint(i[1]), __float_as_uint(i[2]), __float_as_uint(i[3]));
+}
+template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* i) {
+    return make_uint4(pack_bf2(i[0], i[1]), pack_bf2(i[2], i[3]), pack_bf2(i[4], i[5]), pack_bf2(i[6], i[7]));
+}
+
+// ---------------------------------------------------------------- wave / block reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------- math
+__device__ __forceinline__ float gelu_tanh_f(float x) {            // modeling_bloom.py:344
+    return x * 0.5f * (1.0f + tanhf(0.79788456f * x * (1.0f + 0.044715f * x * x)));
+}
+__device__ __forceinline__ float gelu_tanh_grad_f(float x) {       // modeling_bloom.py:360-362
+    float t = tanhf(0.79788456f * x * (1.0f + 0.044715f * x * x));
+    return 0.5f * x * ((1.0f - t * t) * (0.79788456f + 0.1070322243f * x * x)) + 0.5f * (1.0f + t);
+}
+
+static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,868 @@
+// HBM-bound kernels of the SFT hot path: LayerNorm, cross entropy, embedding, optimizers, small utilities.
+// gfx950: one wave (64 lanes) per row for LayerNorm, one 256-thread block per vocabulary row for CE,
+// 16-byte loads everywhere, fp32 statistics, wavefront shuffles for the reductions.
+#include "common.h"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void ctmi_set_error(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+extern "C" const char* ctmi_last_error(void) { return g_err; }
+extern "C" int ctmi_abi_version(void) { return CTMI_ABI_VERSION; }
+
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm  (transformer.py:71-89)
+// ------------------------------------------------------------------------------------------------
+// Fast path: one wave per row, the row cached in registers (MAXV 16-byte vectors per lane).
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void ln_fwd_vec(const T* __restrict__ x, const float* __restrict__ w,
+                                                  const float* __restrict__ b, T* __restrict__ y,
+                                                  float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                  int64_t rows, int cols, float eps) {
+    constexpr int VEC = 16 / sizeof(T);
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const float inv_n = 1.0f / (float)cols;
+    for (int64_t row = wave0; row < rows; row += nwaves) {
+        const T* xr = x + row * cols;
+        float vals[MAXV][VEC];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = (i * 64 + lane) * VEC;
+            if (c < cols) {
+                uint4 r = *reinterpret_cast<const uint4*>(xr + c);
+                unpack16<T>(r, vals[i]);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) s += vals[i][j];
+            }
+        }
+        const float mean = wave_sum(s) * inv_n;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = (i * 64 + lane) * VEC;
+            if (c < cols) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) { float d = vals[i][j] - mean; q += d * d; }
+            }
+        }
+        const float var = wave_sum(q) * inv_n;
+        const float rstd = 1.0f / sqrtf(var + eps);
+        if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+        T* yr = y + row * cols;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = (i * 64 + lane) * VEC;
+            if (c < cols) {
+                float o[VEC];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) o[j] = w[c + j] * ((vals[i][j] - mean) * rstd) + b[c + j];
+                *reinterpret_cast<uint4*>(yr + c) = pack16<T>(o);
+            }
+        }
+    }
+}
+
+// Generic path (any cols / alignment): scalar loads, the row is re-read (L1/L2 hits).
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_gen(const T* __restrict__ x, const float* __restrict__ w,
+                                                  const float* __restrict__ b, T* __restrict__ y,
+                                                  float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                  int64_t rows, int64_t cols, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const float inv_n = 1.0f / (float)cols;
+    for (int64_t row = wave0; row < rows; row += nwaves) {
+        const T* xr = x + row * cols;
+        float s = 0.f;
+        for (int64_t c = lane; c < cols; c += 64) s += Cvt<T>::to_f(xr[c]);
+        const float mean = wave_sum(s) * inv_n;
+        float q = 0.f;
+        for (int64_t c = lane; c < cols; c += 64) { float d = Cvt<T>::to_f(xr[c]) - mean; q += d * d; }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_n + eps);
+        if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+        T* yr = y + row * cols;
+        for (int64_t c = lane; c < cols; c += 64)
+            yr[c] = Cvt<T>::from_f(w[c] * ((Cvt<T>::to_f(xr[c]) - mean) * rstd) + b[c]);
+    }
+}
+
+template <typename T>
+static int ln_fwd_launch(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd,
+                         int64_t rows, int64_t cols, float eps, hipStream_t st) {
+    constexpr int VEC = 16 / sizeof(T);
+    const bool vec_ok = (cols % VEC == 0) && aligned16(x) && aligned16(y);
+    int grid = (int)std::min<int64_t>(cdiv64(rows, 4), 2048);
+    if (grid < 1) grid = 1;
+    const T* xp = (const T*)x; T* yp = (T*)y;
+#define LN_FWD_CASE(MV) if (vec_ok && cols <= (int64_t)MV * 64 * VEC) { \
+        hipLaunchKernelGGL((ln_fwd_vec<T, MV>), dim3(grid), dim3(256), 0, st, xp, w, b, yp, mean, rstd, rows, (int)cols, eps); \
+        CTMI_CHECK_LAUNCH("layernorm_fwd"); return CTMI_OK; }
+    LN_FWD_CASE(1) LN_FWD_CASE(2) LN_FWD_CASE(4) LN_FWD_CASE(8)
+#undef LN_FWD_CASE
+    hipLaunchKernelGGL((ln_fwd_gen<T>), dim3(grid), dim3(256), 0, st, xp, w, b, yp, mean, rstd, rows, cols, eps);
+    CTMI_CHECK_LAUNCH("layernorm_fwd");
+    return CTMI_OK;
+}
+
+extern "C" int ctmi_layernorm_fwd(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd,
+                                  int64_t rows, int64_t cols, float eps, int dtype, void* stream) {
+    CTMI_REQUIRE(x && w && b && y && mean && rstd, "layernorm_fwd: null pointer");
+    CTMI_REQUIRE(rows >= 0 && cols > 0, "layernorm_fwd: bad shape rows=%lld cols=%lld", (long long)rows, (long long)cols);
+    if (rows == 0) return CTMI_OK;
+    if (dtype == CTMI_F32) return ln_fwd_launch<float>(x, w, b, y, mean, rstd, rows, cols, eps, as_stream(stream));
+    if (dtype == CTMI_BF16) return ln_fwd_launch<bf16_t>(x, w, b, y, mean, rstd, rows, cols, eps, as_stream(stream));
+    ctmi_set_error("layernorm_fwd: unsupported dtype %d", dtype);
+    return CTMI_ERR_UNSUPPORTED;
+}
+
+// Backward.  dx = rstd * (g - mean(g) - xhat*mean(g*xhat)),  g = dy*w, xhat = (x-mean)*rstd.
+// Each wave keeps per-lane partial sums of dw = sum dy*xhat and db = sum dy for its rows; a block combines its
+// 4 waves through LDS and writes one partial row to ws[blockIdx][2][cols]; ln_bwd_reduce sums the partial rows.
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void ln_bwd_vec(const T* __restrict__ dy, const T* __restrict__ x,
+                                                  const float* __restrict__ w, const float* __restrict__ mean_i,
+                                                  const float* __restrict__ rstd_i, const T* __restrict__ dres,
+                                                  T* __restrict__ dx, float* __restrict__ ws, int64_t rows, int cols) {
+    constexpr int VEC = 16 / sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // [4][2][cols]
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + wid;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const float inv_n = 1.0f / (float)cols;
+    float aw[MAXV][VEC], ab[MAXV][VEC], wv[MAXV][VEC];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * VEC;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { aw[i][j] = 0.f; ab[i][j] = 0.f; wv[i][j] = (c < cols) ? w[c + j] : 0.f; }
+    }
+    for (int64_t row = wave0; row < rows; row += nwaves) {
+        const float mean = mean_i[row], rstd = rstd_i[row];
+        const T* xr = x + row * cols;
+        const T* gr = dy + row * cols;
+        float xh[MAXV][VEC], g[MAXV][VEC];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = (i * 64 + lane) * VEC;
+            if (c < cols) {
+                float xv[VEC], dv[VEC];
+                unpack16<T>(*reinterpret_cast<const uint4*>(xr + c), xv);
+                unpack16<T>(*reinterpret_cast<const uint4*>(gr + c), dv);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    xh[i][j] = (xv[j] - mean) * rstd;
+                    g[i][j] = dv[j] * wv[i][j];
+                    s1 += g[i][j];
+                    s2 += g[i][j] * xh[i][j];
+                    aw[i][j] += dv[j] * xh[i][j];
+                    ab[i][j] += dv[j];
+                }
+            }
+        }
+        s1 = wave_sum(s1) * inv_n;
+        s2 = wave_sum(s2) * inv_n;
+        T* dxr = dx + row * cols;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = (i * 64 + lane) * VEC;
+            if (c < cols) {
+                float o[VEC];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) o[j] = rstd * (g[i][j] - s1 - xh[i][j] * s2);
+                if (dres != nullptr) {
+                    float r[VEC];
+                    unpack16<T>(*reinterpret_cast<const uint4*>(dres + row * cols + c), r);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) o[j] += r[j];
+                }
+                *reinterpret_cast<uint4*>(dxr + c) = pack16<T>(o);
+            }
+        }
+    }
+    // block combine
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * VEC;
+        if (c < cols) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                lds[(wid * 2 + 0) * cols + c + j] = aw[i][j];
+                lds[(wid * 2 + 1) * cols + c + j] = ab[i][j];
+            }
+        }
+    }
+    __syncthreads();
+    float* out = ws + (int64_t)blockIdx.x * 2 * cols;
+    for (int c = threadIdx.x; c < 2 * cols; c += 256) {
+        const int which = c / cols, cc = c - which * cols;
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t += lds[(k * 2 + which) * cols + cc];
+        out[c] = t;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_gen(const T* __restrict__ dy, const T* __restrict__ x,
+                                                  const float* __restrict__ w, const float* __restrict__ mean_i,
+                                                  const float* __restrict__ rstd_i, const T* __restrict__ dres,
+                                                  T* __restrict__ dx, int64_t rows, int64_t cols) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const float inv_n = 1.0f / (float)cols;
+    for (int64_t row = wave0; row < rows; row += nwaves) {
+        const float mean = mean_i[row], rstd = rstd_i[row];
+        const T* xr = x + row * cols;
+        const T* gr = dy + row * cols;
+        float s1 = 0.f, s2 = 0.f;
+        for (int64_t c = lane; c < cols; c += 64) {
+            float g = Cvt<T>::to_f(gr[c]) * w[c];
+            s1 += g; s2 += g * ((Cvt<T>::to_f(xr[c]) - mean) * rstd);
+        }
+        s1 = wave_sum(s1) * inv_n; s2 = wave_sum(s2) * inv_n;
+        for (int64_t c = lane; c < cols; c += 64) {
+            float xh = (Cvt<T>::to_f(xr[c]) - mean) * rstd;
+            float o = rstd * (Cvt<T>::to_f(gr[c]) * w[c] - s1 - xh * s2);
+            if (dres != nullptr) o += Cvt<T>::to_f(dres[row * cols + c]);
+            dx[row * cols + c] = Cvt<T>::from_f(o);
+        }
+    }
+}
+
+// generic dw/db partials: block b handles rows [b*chunk, (b+1)*chunk); thread per column.
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_wb_gen(const T* __restrict__ dy, const T* __restrict__ x,
+                                                     const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                                     float* __restrict__ ws, int64_t rows, int64_t cols, int64_t chunk) {
+    const int64_t r0 = (int64_t)blockIdx.x * chunk, r1 = min(rows, r0 + chunk);
+    float* out = ws + (int64_t)blockIdx.x * 2 * cols;
+    for (int64_t c = threadIdx.x; c < cols; c += 256) {
+        float aw = 0.f, ab = 0.f;
+        for (int64_t r = r0; r < r1; ++r) {
+            float d = Cvt<T>::to_f(dy[r * cols + c]);
+            aw += d * ((Cvt<T>::to_f(x[r * cols + c]) - mean_i[r]) * rstd_i[r]);
+            ab += d;
+        }
+        out[c] = aw; out[cols + c] = ab;
+    }
+}
+
+__global__ __launch_bounds__(256) void ln_bwd_reduce(const float* __restrict__ ws, float* __restrict__ dw,
+                                                     float* __restrict__ db, int nparts, int64_t cols, int accumulate) {
+    // 64 columns x 4 row-slices per block; blockIdx.y selects dw / db
+    __shared__ float sm[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t c = (int64_t)blockIdx.x * 64 + tx;
+    const int which = blockIdx.y;
+    float t = 0.f;
+    if (c < cols)
+        for (int p = ty; p < nparts; p += 4) t += ws[((int64_t)p * 2 + which) * cols + c];
+    sm[ty][tx] = t;
+    __syncthreads();
+    if (ty == 0 && c < cols) {
+        float r = sm[0][tx] + sm[1][tx] + sm[2][tx] + sm[3][tx];
+        float* o = which ? db : dw;
+        o[c] = accumulate ? o[c] + r : r;
+    }
+}
+
+static const int LN_BWD_MAX_BLOCKS = 256;
+extern "C" int64_t ctmi_layernorm_bwd_ws(int64_t rows, int64_t cols) {
+    (void)rows;
+    return (int64_t)LN_BWD_MAX_BLOCKS * 2 * cols;
+}
+
+template <typename T>
+static int ln_bwd_launch(const void* dy, const void* x, const float* w, const float* mean, const float* rstd,
+                         const void* dres, void* dx, float* dw, float* db, int accumulate, float* ws,
+                         int64_t rows, int64_t cols, hipStream_t st) {
+    constexpr int VEC = 16 / sizeof(T);
+    const bool vec_ok = (cols % VEC == 0) && aligned16(x) && aligned16(dy) && aligned16(dx) &&
+                        (dres == nullptr || aligned16(dres)) && cols <= 8LL * 64 * VEC && cols * 32 <= 160 * 1024;
+    int nparts;
+    if (vec_ok) {
+        int grid = (int)std::min<int64_t>(cdiv64(rows, 4), LN_BWD_MAX_BLOCKS);
+        nparts = grid;
+        size_t lds = (size_t)cols * 8 * sizeof(float);
+#define LN_BWD_CASE(MV) if (cols <= (int64_t)MV * 64 * VEC) { \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_vec<T, MV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((ln_bwd_vec<T, MV>), dim3(grid), dim3(256), lds, st, (const T*)dy, (const T*)x, w, mean, rstd, \
+                               (const T*)dres, (T*)dx, ws, rows, (int)cols); }
+        LN_BWD_CASE(1) else LN_BWD_CASE(2) else LN_BWD_CASE(4) else LN_BWD_CASE(8)
+#undef LN_BWD_CASE
+        CTMI_CHECK_LAUNCH("layernorm_bwd");
+    } else {
+        int grid = (int)std::min<int64_t>(cdiv64(rows, 4), 2048);
+        hipLaunchKernelGGL((ln_bwd_gen<T>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, w, mean, rstd,
+                           (const T*)dres, (T*)dx, rows, cols);
+        CTMI_CHECK_LAUNCH("layernorm_bwd");
+        nparts = (int)std::min<int64_t>(rows, LN_BWD_MAX_BLOCKS);
+        int64_t chunk = cdiv64(rows, nparts);
+        nparts = (int)cdiv64(rows, chunk);
+        hipLaunchKernelGGL((ln_bwd_wb_gen<T>), dim3(nparts), dim3(256), 0, st, (const T*)dy, (const T*)x, mean, rstd, ws, rows, cols, chunk);
+        CTMI_CHECK_LAUNCH("layernorm_bwd_wb");
+    }
+    hipLaunchKernelGGL(ln_bwd_reduce, dim3((unsigned)cdiv64(cols, 64), 2), dim3(256), 0, st, ws, dw, db, nparts, cols, accumulate);
+    CTMI_CHECK_LAUNCH("layernorm_bwd_reduce");
+    return CTMI_OK;
+}
+
+extern "C" int ctmi_layernorm_bwd(const void* dy, const void* x, const float* w, const float* mean, const float* rstd,
+                                  const void* dres, void* dx, float* dw, float* db, int accumulate, float* ws,
+                                  int64_t rows, int64_t cols, int dtype, void* stream) {
+    CTMI_REQUIRE(dy && x && w && mean && rstd && dx && dw && db && ws, "layernorm_bwd: null pointer");
+    CTMI_REQUIRE(rows > 0 && cols > 0, "layernorm_bwd: bad shape");
+    if (dtype == CTMI_F32) return ln_bwd_launch<float>(dy, x, w, mean, rstd, dres, dx, dw, db, accumulate, ws, rows, cols, as_stream(stream));
+    if (dtype == CTMI_BF16) return ln_bwd_launch<bf16_t>(dy, x, w, mean, rstd, dres, dx, dw, db, accumulate, ws, rows, cols, as_stream(stream));
+    ctmi_set_error("layernorm_bwd: unsupported dtype %d", dtype);
+    return CTMI_ERR_UNSUPPORTED;
+}
+
+// ------------------------------------------------------------------------------------------------
+// column sum (bias gradients)
+// ------------------------------------------------------------------------------------------------
+static const int COLSUM_PARTS = 128;
+extern "C" int64_t ctmi_colsum_ws(int64_t M, int64_t N) { (void)M; return (int64_t)COLSUM_PARTS * N; }
+
+// grid (ceil(N/ (64*VEC)), parts): each block sums a slab of rows for 64*VEC columns, 4 waves over rows.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_part(const T* __restrict__ x, int64_t ld, float* __restrict__ ws,
+                                                   int64_t M, int64_t N, int64_t rows_per_part, int vec_ok) {
+    constexpr int VEC = 16 / sizeof(T);
+    __shared__ float sm[4][64 * VEC];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t c0 = ((int64_t)blockIdx.x * 64 + lane) * VEC;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_part, r1 = min(M, r0 + rows_per_part);
+    float acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+    if (vec_ok) {
+        if (c0 < N)
+            for (int64_t r = r0 + wid; r < r1; r += 4) {
+                float v[VEC];
+                unpack16<T>(*reinterpret_cast<const uint4*>(x + r * ld + c0), v);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) acc[j] += v[j];
+            }
+    } else {
+        for (int64_t r = r0 + wid; r < r1; r += 4)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) if (c0 + j < N) acc[j] += Cvt<T>::to_f(x[r * ld + c0 + j]);
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) sm[wid][lane * VEC + j] = acc[j];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * VEC; i += 256) {
+        const int64_t c = (int64_t)blockIdx.x * 64 * VEC + i;
+        if (c < N) ws[(int64_t)blockIdx.y * N + c] = sm[0][i] + sm[1][i] + sm[2][i] + sm[3][i];
+    }
+}
+__global__ __launch_bounds__(256) void colsum_final(const float* __restrict__ ws, float* __restrict__ out, int parts,
+                                                    int64_t N, int accumulate) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    float t = 0.f;
+    for (int p = 0; p < parts; ++p) t += ws[(int64_t)p * N + c];
+    out[c] = accumulate ? out[c] + t : t;
+}
+
+extern "C" int ctmi_colsum(const void* x, int64_t ld, float* out, int accumulate, float* ws, int64_t M, int64_t N, int dtype, void* stream) {
+    CTMI_REQUIRE(x && out && ws && M > 0 && N > 0, "colsum: bad args");
+    hipStream_t st = as_stream(stream);
+    int parts = (int)std::min<int64_t>(COLSUM_PARTS, cdiv64(M, 16));
+    int64_t rpp = cdiv64(M, parts);
+    parts = (int)cdiv64(M, rpp);
+    if (dtype == CTMI_F32) {
+        int vec_ok = (N % 4 == 0) && (ld % 4 == 0) && aligned16(x);
+        hipLaunchKernelGGL((colsum_part<float>), dim3((unsigned)cdiv64(N, 64 * 4), parts), dim3(256), 0, st, (const float*)x, ld, ws, M, N, rpp, vec_ok);
+    } else if (dtype == CTMI_BF16) {
+        int vec_ok = (N % 8 == 0) && (ld % 8 == 0) && aligned16(x);
+        hipLaunchKernelGGL((colsum_part<bf16_t>), dim3((unsigned)cdiv64(N, 64 * 8), parts), dim3(256), 0, st, (const bf16_t*)x, ld, ws, M, N, rpp, vec_ok);
+    } else { ctmi_set_error("colsum: unsupported dtype %d", dtype); return CTMI_ERR_UNSUPPORTED; }
+    CTMI_CHECK_LAUNCH("colsum_part");
+    hipLaunchKernelGGL(colsum_final, dim3((unsigned)cdiv64(N, 256)), dim3(256), 0, st, ws, out, parts, N, accumulate);
+    CTMI_CHECK_LAUNCH("colsum_final");
+    return CTMI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// embedding gather / scatter-add   (modeling_bloom.py:190)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void embed_fwd_k(const T* __restrict__ table, const int64_t* __restrict__ ids,
+                                                   T* __restrict__ out, int64_t n, int64_t H, int64_t V, int vec_ok,
+                                                   int32_t* err_flag) {
+    constexpr int VEC = 16 / sizeof(T);
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (int64_t t = wave0; t < n; t += (int64_t)gridDim.x * 4) {
+        int64_t id = ids[t];
+        if (id < 0 || id >= V) { if (lane == 0 && err_flag) atomicExch(err_flag, 1); id = 0; }
+        const T* src = table + id * H;
+        T* dst = out + t * H;
+        if (vec_ok) {
+            for (int64_t c = (int64_t)lane * VEC; c < H; c += 64 * VEC)
+                *reinterpret_cast<uint4*>(dst + c) = *reinterpret_cast<const uint4*>(src + c);
+        } else {
+            for (int64_t c = lane; c < H; c += 64) dst[c] = src[c];
+        }
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_k(const T* __restrict__ dout, const int64_t* __restrict__ ids,
+                                                   float* __restrict__ dtable, int64_t n, int64_t H, int64_t V) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (int64_t t = wave0; t < n; t += (int64_t)gridDim.x * 4) {
+        const int64_t id = ids[t];
+        if (id < 0 || id >= V) continue;
+        float* dst = dtable + id * H;
+        const T* src = dout + t * H;
+        for (int64_t c = lane; c < H; c += 64) unsafeAtomicAdd(dst + c, Cvt<T>::to_f(src[c]));
+    }
+}
+
+extern "C" int ctmi_embed_fwd(const void* table, const int64_t* ids, void* out, int64_t n, int64_t H, int64_t V,
+                              int dtype, int32_t* err_flag, void* stream) {
+    CTMI_REQUIRE(table && ids && out && n >= 0 && H > 0 && V > 0, "embed_fwd: bad args");
+    if (n == 0) return CTMI_OK;
+    int grid = (int)std::min<int64_t>(cdiv64(n, 4), 4096);
+    if (dtype == CTMI_F32) {
+        int vec_ok = (H % 4 == 0) && aligned16(table) && aligned16(out);
+        hipLaunchKernelGGL((embed_fwd_k<float>), dim3(grid), dim3(256), 0, as_stream(stream), (const float*)table, ids, (float*)out, n, H, V, vec_ok, err_flag);
+    } else if (dtype == CTMI_BF16) {
+        int vec_ok = (H % 8 == 0) && aligned16(table) && aligned16(out);
+        hipLaunchKernelGGL((embed_fwd_k<bf16_t>), dim3(grid), dim3(256), 0, as_stream(stream), (const bf16_t*)table, ids, (bf16_t*)out, n, H, V, vec_ok, err_flag);
+    } else { ctmi_set_error("embed_fwd: unsupported dtype %d", dtype); return CTMI_ERR_UNSUPPORTED; }
+    CTMI_CHECK_LAUNCH("embed_fwd");
+    return CTMI_OK;
+}
+extern "C" int ctmi_embed_bwd(const void* dout, const int64_t* ids, float* dtable, int64_t n, int64_t H, int64_t V,
+                              int dtype, void* stream) {
+    CTMI_REQUIRE(dout && ids && dtable && n >= 0 && H > 0 && V > 0, "embed_bwd: bad args");
+    if (n == 0) return CTMI_OK;
+    int grid = (int)std::min<int64_t>(cdiv64(n, 4), 4096);
+    if (dtype == CTMI_F32) hipLaunchKernelGGL((embed_bwd_k<float>), dim3(grid), dim3(256), 0, as_stream(stream), (const float*)dout, ids, dtable, n, H, V);
+    else if (dtype == CTMI_BF16) hipLaunchKernelGGL((embed_bwd_k<bf16_t>), dim3(grid), dim3(256), 0, as_stream(stream), (const bf16_t*)dout, ids, dtable, n, H, V);
+    else { ctmi_set_error("embed_bwd: unsupported dtype %d", dtype); return CTMI_ERR_UNSUPPORTED; }
+    CTMI_CHECK_LAUNCH("embed_bwd");
+    return CTMI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// cross entropy  (modeling_bloom.py:224-230; loss.py:29-49 in its numerically stable form)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t ce_target(const int64_t* labels, int64_t row, int64_t seq, int64_t shift, int64_t ignore) {
+    const int64_t b = row / seq, s = row - b * seq;
+    if (s + shift >= seq) return -1;
+    const int64_t t = labels[b * seq + s + shift];
+    return (t == ignore) ? -1 : t;
+}
+
+// combine two (max, sum) online-softmax states
+__device__ __forceinline__ void lse_merge(float& m, float& s, float m2, float s2) {
+    const float mn = fmaxf(m, m2);
+    s = s * __expf(m - mn) + s2 * __expf(m2 - mn);
+    m = mn;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ce_fwd_k(const T* __restrict__ logits, int64_t ld, const int64_t* __restrict__ labels,
+                                                float* __restrict__ row_lse, float* __restrict__ row_loss,
+                                                int64_t C, int64_t seq, int64_t shift, int64_t ignore, int vec_ok) {
+    constexpr int VEC = 16 / sizeof(T);
+    const int64_t row = blockIdx.x;
+    const T* x = logits + row * ld;
+    float m = -INFINITY, s = 0.f;
+    if (vec_ok) {
+        for (int64_t c = (int64_t)threadIdx.x * VEC; c < C; c += 256 * VEC) {
+            float v[VEC];
+            unpack16<T>(*reinterpret_cast<const uint4*>(x + c), v);
+            float vm = v[0];
+#pragma unroll
+            for (int j = 1; j < VEC; ++j) vm = fmaxf(vm, v[j]);
+            const float mn = fmaxf(m, vm);
+            float add = 0.f;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) add += __expf(v[j] - mn);
+            s = s * __expf(m - mn) + add;
+            m = mn;
+        }
+    } else {
+        for (int64_t c = threadIdx.x; c < C; c += 256) {
+            const float v = Cvt<T>::to_f(x[c]);
+            const float mn = fmaxf(m, v);
+            s = s * __expf(m - mn) + __expf(v - mn);
+            m = mn;
+        }
+    }
+    // threads that saw nothing hold (m=-inf, s=0): __expf(-inf - mn) = 0 keeps them neutral as long as mn is finite
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+        const float mn = fmaxf(m, m2);
+        const float a = (m == -INFINITY) ? 0.f : s * __expf(m - mn);
+        const float b = (m2 == -INFINITY) ? 0.f : s2 * __expf(m2 - mn);
+        s = a + b; m = mn;
+    }
+    __shared__ float sm_m[4], sm_s[4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) { sm_m[wid] = m; sm_s[wid] = s; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float M = sm_m[0], S = sm_s[0];
+        for (int k = 1; k < 4; ++k) {
+            const float m2 = sm_m[k], s2 = sm_s[k];
+            const float mn = fmaxf(M, m2);
+            const float a = (M == -INFINITY) ? 0.f : S * __expf(M - mn);
+            const float b = (m2 == -INFINITY) ? 0.f : s2 * __expf(m2 - mn);
+            S = a + b; M = mn;
+        }
+        const float lse = M + logf(S);
+        row_lse[row] = lse;
+        const int64_t t = ce_target(labels, row, seq, shift, ignore);
+        row_loss[row] = (t >= 0 && t < C) ? (lse - Cvt<T>::to_f(x[t])) : -1.0f;     // -1 marks "no loss"
+    }
+}
+
+// single block: loss_out[0] = sum(valid row_loss)/denom ; loss_out[1] = 1/denom
+__global__ __launch_bounds__(1024) void ce_finalize_k(const float* __restrict__ row_loss, float* __restrict__ loss_out,
+                                                      int64_t N, int denom_mode, int64_t denom_rows) {
+    __shared__ double sm_s[16];
+    __shared__ unsigned long long sm_c[16];
+    double s = 0.0; unsigned long long cnt = 0;
+    for (int64_t r = threadIdx.x; r < N; r += 1024) {
+        const float l = row_loss[r];
+        if (l >= 0.f) { s += (double)l; cnt += 1; }
+    }
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); cnt += __shfl_xor(cnt, o, 64); }
+    if ((threadIdx.x & 63) == 0) { sm_s[threadIdx.x >> 6] = s; sm_c[threadIdx.x >> 6] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double S = 0.0; unsigned long long Cn = 0;
+        for (int k = 0; k < 16; ++k) { S += sm_s[k]; Cn += sm_c[k]; }
+        double denom = denom_mode == 0 ? (double)Cn : (denom_mode == 1 ? (double)denom_rows : 1.0);
+        loss_out[0] = (float)(S / denom);                   // 0/0 -> NaN exactly as torch's mean over zero rows
+        loss_out[1] = (float)(1.0 / denom);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ce_bwd_k(const T* __restrict__ logits, int64_t ld, const int64_t* __restrict__ labels,
+                                                const float* __restrict__ row_lse, const float* __restrict__ loss_out,
+                                                const float* __restrict__ gout, T* __restrict__ dlogits, int64_t ldd,
+                                                int64_t C, int64_t seq, int64_t shift, int64_t ignore, int vec_ok) {
+    constexpr int VEC = 16 / sizeof(T);
+    const int64_t row = blockIdx.x;
+    const T* x = logits + row * ld;
+    T* d = dlogits + row * ldd;
+    const int64_t t = ce_target(labels, row, seq, shift, ignore);
+    const bool live = (t >= 0 && t < C);
+    const float coef = live ? (gout ? gout[0] : 1.0f) * loss_out[1] : 0.f;
+    const float lse = row_lse[row];
+    if (vec_ok) {
+        for (int64_t c = (int64_t)threadIdx.x * VEC; c < C; c += 256 * VEC) {
+            float o[VEC];
+            if (live) {
+                float v[VEC];
+                unpack16<T>(*reinterpret_cast<const uint4*>(x + c), v);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) o[j] = (__expf(v[j] - lse) - ((c + j == t) ? 1.0f : 0.0f)) * coef;
+            } else {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) o[j] = 0.f;
+            }
+            *reinterpret_cast<uint4*>(d + c) = pack16<T>(o);
+        }
+    } else {
+        for (int64_t c = threadIdx.x; c < C; c += 256)
+            d[c] = Cvt<T>::from_f(live ? (__expf(Cvt<T>::to_f(x[c]) - lse) - ((c == t) ? 1.0f : 0.0f)) * coef : 0.f);
+    }
+}
+
+extern "C" int ctmi_ce_fwd(const void* logits, int64_t ld, const int64_t* labels, float* row_lse, float* row_loss,
+                           float* loss_out, int64_t N, int64_t C, int64_t seq, int64_t shift, int64_t ignore_index,
+                           int denom_mode, int64_t denom_rows, int dtype, void* stream) {
+    CTMI_REQUIRE(logits && labels && row_lse && row_loss && loss_out, "ce_fwd: null pointer");
+    CTMI_REQUIRE(N > 0 && C > 0 && seq > 0 && N % seq == 0 && shift >= 0 && ld >= C, "ce_fwd: bad shape N=%lld C=%lld seq=%lld", (long long)N, (long long)C, (long long)seq);
+    hipStream_t st = as_stream(stream);
+    if (dtype == CTMI_F32) {
+        int vec_ok = (C % 4 == 0) && (ld % 4 == 0) && aligned16(logits);
+        hipLaunchKernelGGL((ce_fwd_k<float>), dim3((unsigned)N), dim3(256), 0, st, (const float*)logits, ld, labels, row_lse, row_loss, C, seq, shift, ignore_index, vec_ok);
+    } else if (dtype == CTMI_BF16) {
+        int vec_ok = (C % 8 == 0) && (ld % 8 == 0) && aligned16(logits);
+        hipLaunchKernelGGL((ce_fwd_k<bf16_t>), dim3((unsigned)N), dim3(256), 0, st, (const bf16_t*)logits, ld, labels, row_lse, row_loss, C, seq, shift, ignore_index, vec_ok);
+    } else { ctmi_set_error("ce_fwd: unsupported dtype %d", dtype); return CTMI_ERR_UNSUPPORTED; }
+    CTMI_CHECK_LAUNCH("ce_fwd");
+    hipLaunchKernelGGL(ce_finalize_k, dim3(1), dim3(1024), 0, st, row_loss, loss_out, N, denom_mode, denom_rows);
+    CTMI_CHECK_LAUNCH("ce_finalize");
+    return CTMI_OK;
+}
+
+extern "C" int ctmi_ce_bwd(const void* logits, int64_t ld, const int64_t* labels, const float* row_lse, const float* loss_out,
+                           const float* gout, void* dlogits, int64_t ldd, int64_t N, int64_t C, int64_t seq, int64_t shift,
+                           int64_t ignore_index, int dtype, void* stream) {
+    CTMI_REQUIRE(logits && labels && row_lse && loss_out && dlogits, "ce_bwd: null pointer");
+    CTMI_REQUIRE(N > 0 && C > 0 && seq > 0 && N % seq == 0 && ld >= C && ldd >= C, "ce_bwd: bad shape");
+    hipStream_t st = as_stream(stream);
+    if (dtype == CTMI_F32) {
+        int vec_ok = (C % 4 == 0) && (ld % 4 == 0) && (ldd % 4 == 0) && aligned16(logits) && aligned16(dlogits);
+        hipLaunchKernelGGL((ce_bwd_k<float>), dim3((unsigned)N), dim3(256), 0, st, (const float*)logits, ld, labels, row_lse, loss_out, gout, (float*)dlogits, ldd, C, seq, shift, ignore_index, vec_ok);
+    } else if (dtype == CTMI_BF16) {
+        int vec_ok = (C % 8 == 0) && (ld % 8 == 0) && (ldd % 8 == 0) && aligned16(logits) && aligned16(dlogits);
+        hipLaunchKernelGGL((ce_bwd_k<bf16_t>), dim3((unsigned)N), dim3(256), 0, st, (const bf16_t*)logits, ld, labels, row_lse, loss_out, gout, (bf16_t*)dlogits, ldd, C, seq, shift, ignore_index, vec_ok);
+    } else { ctmi_set_error("ce_bwd: unsupported dtype %d", dtype); return CTMI_ERR_UNSUPPORTED; }
+    CTMI_CHECK_LAUNCH("ce_bwd");
+    return CTMI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused multi-tensor AdamW / SGD   (optimizer.py:53-97, 12-50; torch.optim.AdamW semantics at ft_bloom.py:70)
+// 28 B/param of HBM traffic (+2 B when the bf16 shadow is written, +4 B when the L2 form writes the grad back).
+// ------------------------------------------------------------------------------------------------
+struct MTPack {
+    float* p[CTMI_MT_MAX];
+    float* g[CTMI_MT_MAX];
+    float* m[CTMI_MT_MAX];
+    float* v[CTMI_MT_MAX];
+    bf16_t* shadow[CTMI_MT_MAX];
+    int64_t n[CTMI_MT_MAX];
+};
+struct AdamHyper { float lr, b1, b2, eps, wd, bc1, bc2, sqrt_bc2, gscale; int decoupled, mutate_grad; };
+
+__device__ __forceinline__ void adam_one(float& p, float& g, float& m, float& v, const AdamHyper& h) {
+    g *= h.gscale;
+    if (h.decoupled) { p *= (1.0f - h.lr * h.wd); } else { g += h.wd * p; }
+    m = h.b1 * m + (1.0f - h.b1) * g;
+    v = h.b2 * v + (1.0f - h.b2) * g * g;
+    if (h.decoupled) p -= (h.lr / h.bc1) * (m / (sqrtf(v) / h.sqrt_bc2 + h.eps));
+    else             p -= h.lr * (m / h.bc1) / (sqrtf(v / h.bc2) + h.eps);
+}
+
+__global__ __launch_bounds__(256) void adamw_mt_k(MTPack pk, AdamHyper h) {
+    const int ti = blockIdx.y;
+    const int64_t n = pk.n[ti];
+    float* __restrict__ p = pk.p[ti]; float* __restrict__ g = pk.g[ti];
+    float* __restrict__ m = pk.m[ti]; float* __restrict__ v = pk.v[ti];
+    bf16_t* __restrict__ sh = pk.shadow[ti];
+    const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0) && (sh == nullptr || (((uintptr_t)sh) & 7) == 0);
+    const int64_t n4 = vec ? (n / 4) : 0;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        float4 P = reinterpret_cast<float4*>(p)[i], G = reinterpret_cast<const float4*>(g)[i];
+        float4 M = reinterpret_cast<float4*>(m)[i], V = reinterpret_cast<float4*>(v)[i];
+        adam_one(P.x, G.x, M.x, V.x, h); adam_one(P.y, G.y, M.y, V.y, h);
+        adam_one(P.z, G.z, M.z, V.z, h); adam_one(P.w, G.w, M.w, V.w, h);
+        reinterpret_cast<float4*>(p)[i] = P; reinterpret_cast<float4*>(m)[i] = M; reinterpret_cast<float4*>(v)[i] = V;
+        if (h.mutate_grad) reinterpret_cast<float4*>(g)[i] = G;
+        if (sh) reinterpret_cast<uint2*>(sh)[i] = make_uint2(pack_bf2(P.x, P.y), pack_bf2(P.z, P.w));
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        float P = p[i], G = g[i], M = m[i], V = v[i];
+        adam_one(P, G, M, V, h);
+        p[i] = P; m[i] = M; v[i] = V;
+        if (h.mutate_grad) g[i] = G;
+        if (sh) sh[i] = f2bf(P);
+    }
+}
+
+static int mt_grid_x(const int64_t* n, int count) {
+    int64_t mx = 1;
+    for (int i = 0; i < count; ++i) mx = std::max(mx, n[i]);
+    return (int)std::min<int64_t>(cdiv64(mx, 256 * 4 * 4), 2048);
+}
+
+extern "C" int ctmi_adamw_step(float* const* p, float* const* g, float* const* m, float* const* v, void* const* shadow,
+                               const int64_t* n, int count, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, int step, int decoupled, int mutate_grad, float grad_scale, void* stream) {
+    CTMI_REQUIRE(p && g && m && v && n && count >= 0 && step >= 1, "adamw_step: bad args (step must be >= 1)");
+    AdamHyper h;
+    h.lr = lr; h.b1 = beta1; h.b2 = beta2; h.eps = eps; h.wd = weight_decay;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    h.bc1 = (float)bc1; h.bc2 = (float)bc2; h.sqrt_bc2 = (float)sqrt(bc2);
+    h.gscale = grad_scale; h.decoupled = decoupled; h.mutate_grad = (mutate_grad && !decoupled && weight_decay != 0.f) || (mutate_grad && grad_scale != 1.0f);
+    for (int base = 0; base < count; base += CTMI_MT_MAX) {
+        const int c = std::min(CTMI_MT_MAX, count - base);
+        MTPack pk;
+        for (int i = 0; i < c; ++i) {
+            CTMI_REQUIRE(p[base + i] && g[base + i] && m[base + i] && v[base + i] && n[base + i] >= 0, "adamw_step: null tensor %d", base + i);
+            pk.p[i] = p[base + i]; pk.g[i] = g[base + i]; pk.m[i] = m[base + i]; pk.v[i] = v[base + i];
+            pk.shadow[i] = shadow ? (bf16_t*)shadow[base + i] : nullptr; pk.n[i] = n[base + i];
+        }
+        hipLaunchKernelGGL(adamw_mt_k, dim3(mt_grid_x(n + base, c), c), dim3(256), 0, as_stream(stream), pk, h);
+        CTMI_CHECK_LAUNCH("adamw_step");
+    }
+    return CTMI_OK;
+}
+
+struct SgdHyper { float lr, momentum, dampening, wd; int first; };
+__global__ __launch_bounds__(256) void sgd_mt_k(MTPack pk, SgdHyper h) {
+    const int ti = blockIdx.y;
+    const int64_t n = pk.n[ti];
+    float* __restrict__ p = pk.p[ti]; float* __restrict__ g = pk.g[ti]; float* __restrict__ buf = pk.m[ti];
+    bf16_t* __restrict__ sh = pk.shadow[ti];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float P = p[i], G = g[i];
+        if (h.wd != 0.f) G += h.wd * P;                         // optimizer.py:38-39
+        if (buf != nullptr) {                                    // optimizer.py:41-48
+            float B = h.first ? G : h.momentum * buf[i] + (1.0f - h.dampening) * G;
+            buf[i] = B; G = B;
+        }
+        g[i] = G;                                                // the reference leaves param.grad = buf / decayed grad
+        P -= h.lr * G;
+        p[i] = P;
+        if (sh) sh[i] = f2bf(P);
+    }
+}
+extern "C" int ctmi_sgd_step(float* const* p, float* const* g, float* const* buf, void* const* shadow, const int64_t* n,
+                             int count, float lr, float momentum, float dampening, float weight_decay, int first_step, void* stream) {
+    CTMI_REQUIRE(p && g && n && count >= 0, "sgd_step: bad args");
+    SgdHyper h{lr, momentum, dampening, weight_decay, first_step};
+    for (int base = 0; base < count; base += CTMI_MT_MAX) {
+        const int c = std::min(CTMI_MT_MAX, count - base);
+        MTPack pk;
+        for (int i = 0; i < c; ++i) {
+            pk.p[i] = p[base + i]; pk.g[i] = g[base + i]; pk.m[i] = buf ? buf[base + i] : nullptr; pk.v[i] = nullptr;
+            pk.shadow[i] = shadow ? (bf16_t*)shadow[base + i] : nullptr; pk.n[i] = n[base + i];
+        }
+        hipLaunchKernelGGL(sgd_mt_k, dim3(mt_grid_x(n + base, c), c), dim3(256), 0, as_stream(stream), pk, h);
+        CTMI_CHECK_LAUNCH("sgd_step");
+    }
+    return CTMI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// utilities
+// ------------------------------------------------------------------------------------------------
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void cast_k(const S* __restrict__ src, D* __restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        dst[i] = Cvt<D>::from_f(Cvt<S>::to_f(src[i]));
+}
+__global__ __launch_bounds__(256) void cast_f32_bf16_v4(const float4* __restrict__ src, uint2* __restrict__ dst, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 a = src[i];
+        dst[i] = make_uint2(pack_bf2(a.x, a.y), pack_bf2(a.z, a.w));
+    }
+}
+extern "C" int ctmi_cast(const void* src, int sd, void* dst, int dd, int64_t n, void* stream) {
+    CTMI_REQUIRE(src && dst && n >= 0, "cast: bad args");
+    if (n == 0) return CTMI_OK;
+    hipStream_t st = as_stream(stream);
+    int grid = (int)std::min<int64_t>(cdiv64(n, 256 * 4), 4096);
+    if (sd == CTMI_F32 && dd == CTMI_BF16) {
+        if (aligned16(src) && ((((uintptr_t)dst) & 7) == 0) && n % 4 == 0)
+            hipLaunchKernelGGL(cast_f32_bf16_v4, dim3(grid), dim3(256), 0, st, (const float4*)src, (uint2*)dst, n / 4);
+        else hipLaunchKernelGGL((cast_k<float, bf16_t>), dim3(grid), dim3(256), 0, st, (const float*)src, (bf16_t*)dst, n);
+    } else if (sd == CTMI_BF16 && dd == CTMI_F32) hipLaunchKernelGGL((cast_k<bf16_t, float>), dim3(grid), dim3(256), 0, st, (const bf16_t*)src, (float*)dst, n);
+    else if (sd == CTMI_F32 && dd == CTMI_F32) hipLaunchKernelGGL((cast_k<float, float>), dim3(grid), dim3(256), 0, st, (const float*)src, (float*)dst, n);
+    else if (sd == CTMI_BF16 && dd == CTMI_BF16) hipLaunchKernelGGL((cast_k<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, n);
+    else { ctmi_set_error("cast: unsupported dtypes %d->%d", sd, dd); return CTMI_ERR_UNSUPPORTED; }
+    CTMI_CHECK_LAUNCH("cast");
+    return CTMI_OK;
+}
+
+__global__ __launch_bounds__(256) void sumsq_k(const float* __restrict__ x, int64_t n, double* __restrict__ out) {
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) { const double v = x[i]; s += v * v; }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    __shared__ double sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, sm[0] + sm[1] + sm[2] + sm[3]);
+}
+extern "C" int ctmi_sumsq(const float* x, int64_t n, double* out, int accumulate, void* stream) {
+    CTMI_REQUIRE(x && out && n >= 0, "sumsq: bad args");
+    hipStream_t st = as_stream(stream);
+    if (!accumulate) { if (hipMemsetAsync(out, 0, sizeof(double), st) != hipSuccess) { ctmi_set_error("sumsq: memset failed"); return CTMI_ERR_LAUNCH; } }
+    if (n == 0) return CTMI_OK;
+    int grid = (int)std::min<int64_t>(cdiv64(n, 256 * 8), 1024);
+    hipLaunchKernelGGL(sumsq_k, dim3(grid), dim3(256), 0, st, x, n, out);
+    CTMI_CHECK_LAUNCH("sumsq");
+    return CTMI_OK;
+}
+
+__global__ __launch_bounds__(256) void scale_k(float* __restrict__ x, int64_t n, float s, const float* __restrict__ sd) {
+    const float f = sd ? s * sd[0] : s;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] *= f;
+}
+extern "C" int ctmi_scale(float* x, int64_t n, float s, const float* s_dev, void* stream) {
+    CTMI_REQUIRE(x && n >= 0, "scale: bad args");
+    if (n == 0) return CTMI_OK;
+    int grid = (int)std::min<int64_t>(cdiv64(n, 256 * 4), 4096);
+    hipLaunchKernelGGL(scale_k, dim3(grid), dim3(256), 0, as_stream(stream), x, n, s, s_dev);
+    CTMI_CHECK_LAUNCH("scale");
+    return CTMI_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void argmax_k(const T* __restrict__ x, int64_t ld, int64_t* __restrict__ out, int64_t cols) {
+    const T* r = x + (int64_t)blockIdx.x * ld;
+    float best = -INFINITY; int64_t bi = INT64_MAX;
+    for (int64_t c = threadIdx.x; c < cols; c += 256) {
+        const float v = Cvt<T>::to_f(r[c]);
+        if (v > best || bi == INT64_MAX) { best = v; bi = c; }          // strictly greater keeps the first index
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float b2 = __shfl_xor(best, o, 64); const int64_t i2 = __shfl_xor(bi, o, 64);
+        if (b2 > best || (b2 == best && i2 < bi)) { best = b2; bi = i2; }
+    }
+    __shared__ float sb[4]; __shared__ int64_t si[4];
+    if ((threadIdx.x & 63) == 0) { sb[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) if (sb[k] > best || (sb[k] == best && si[k] < bi)) { best = sb[k]; bi = si[k]; }
+        out[blockIdx.x] = bi;
+    }
+}
+extern "C" int ctmi_argmax(const void* x, int64_t ld, int64_t* out, int64_t rows, int64_t cols, int dtype, void* stream) {
+    CTMI_REQUIRE(x && out && rows > 0 && cols > 0 && ld >= cols, "argmax: bad args");
+    if (dtype == CTMI_F32) hipLaunchKernelGGL((argmax_k<float>), dim3((unsigned)rows), dim3(256), 0, as_stream(stream), (const float*)x, ld, out, cols);
+    else if (dtype == CTMI_BF16) hipLaunchKernelGGL((argmax_k<bf16_t>), dim3((unsigned)rows), dim3(256), 0, as_stream(stream), (const bf16_t*)x, ld, out, cols);
+    else { ctmi_set_error("argmax: unsupported dtype %d", dtype); return CTMI_ERR_UNSUPPORTED; }
+    CTMI_CHECK_LAUNCH("argmax");
+    return CTMI_OK;
+}
+
+// attention_mask [B,S] -> ALiBi key positions (cumsum(mask)-1)*mask as fp32, validity as int32 (modeling_bloom.py:328,178)
+__global__ __launch_bounds__(64) void mask_prep_k(const int64_t* __restrict__ am, float* __restrict__ kpos,
+                                                  int32_t* __restrict__ kvalid, int32_t* __restrict__ first_valid, int64_t S) {
+    const int64_t b = blockIdx.x;
+    const int lane = threadIdx.x;
+    int64_t running = 0;
+    int64_t first = S;
+    for (int64_t base = 0; base < S; base += 64) {
+        const int64_t j = base + lane;
+        const int64_t mv = (j < S) ? am[b * S + j] : 0;
+        int64_t incl = mv;                                       // inclusive wave scan
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int64_t t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        if (j < S) {
+            kpos[b * S + j] = (float)((running + incl - 1) * mv);
+            kvalid[b * S + j] = (mv != 0) ? 1 : 0;
+            if (mv != 0 && j < first) first = j;
+        }
+        running += __shfl(incl, 63, 64);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int64_t t = __shfl_xor(first, o, 64); first = t < first ? t : first; }
+    if (lane == 0) first_valid[b] = (int32_t)first;
+}
+extern "C" int ctmi_mask_prep(const int64_t* am, float* kpos, int32_t* kvalid, int32_t* first_valid, int64_t B, int64_t S, void* stream) {
+    CTMI_REQUIRE(am && kpos && kvalid && first_valid && B > 0 && S > 0, "mask_prep: bad args");
+    hipLaunchKernelGGL(mask_prep_k, dim3((unsigned)B), dim3(64), 0, as_stream(stream), am, kpos, kvalid, first_valid, S);
+    CTMI_CHECK_LAUNCH("mask_prep");
+    return CTMI_OK;
+}

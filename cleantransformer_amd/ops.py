@@ -1,0 +1,331 @@
+"""Tensor-level wrappers over the C ABI (include/ctmi355.h).
+
+PyTorch is used here only as plumbing: it owns device memory (caching allocator) and the
+current HIP stream.  Every arithmetic operation on the hot path is a ctmi_* kernel; a missing
+library or a failing launch raises (there is no eager/CPU fallback).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import AttnDesc, BF16, F32, check
+
+Tensor = torch.Tensor
+
+
+def _p(t: Optional[Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dt_code(dtype: torch.dtype) -> int:
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.bfloat16:
+        return BF16
+    raise _lib.CtmiError(f"unsupported compute dtype {dtype}: the ctmi355 kernels run fp32 or bf16")
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.CtmiError("ctmi355 ops need tensors on an MI355X device (cuda:N); there is no CPU path in the product "
+                                 "package — the CPU oracle lives under oracle/ and is test infrastructure only")
+
+
+def _c(t: Tensor) -> Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm
+def layernorm_fwd(x2d: Tensor, w: Tensor, b: Tensor, eps: float):
+    """x2d [rows, cols] (fp32|bf16, contiguous); w,b fp32 [cols] -> y, mean, rstd."""
+    _need_cuda(x2d, w, b)
+    rows, cols = x2d.shape
+    y = torch.empty_like(x2d)
+    mean = torch.empty(rows, dtype=torch.float32, device=x2d.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x2d.device)
+    check(_lib.load().ctmi_layernorm_fwd(_p(x2d), _p(w), _p(b), _p(y), _p(mean), _p(rstd), rows, cols, float(eps),
+                                         dt_code(x2d.dtype), _stream()), "layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy: Tensor, x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, dres: Optional[Tensor] = None):
+    """-> dx (same dtype as x; + dres fused), dw fp32, db fp32."""
+    rows, cols = x.shape
+    lib = _lib.load()
+    dx = torch.empty_like(x)
+    dw = torch.empty(cols, dtype=torch.float32, device=x.device)
+    db = torch.empty(cols, dtype=torch.float32, device=x.device)
+    ws = torch.empty(lib.ctmi_layernorm_bwd_ws(rows, cols), dtype=torch.float32, device=x.device)
+    check(lib.ctmi_layernorm_bwd(_p(dy), _p(x), _p(w), _p(mean), _p(rstd), _p(dres), _p(dx), _p(dw), _p(db), 0, _p(ws),
+                                 rows, cols, dt_code(x.dtype), _stream()), "layernorm_bwd")
+    return dx, dw, db
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+class KernelTimer:
+    """Opt-in HIP-event bracket around tagged launches (bench.py's live per-kernel roofline measurement).  Events are
+    recorded on the stream the kernel is launched on (torch's current stream)."""
+
+    def __init__(self, tags):
+        self.tags = set(tags)
+        self.events = {t: [] for t in self.tags}
+
+    def ms(self, tag):
+        ev = self.events[tag]
+        return [a.elapsed_time(b) for a, b in ev]
+
+
+_timer: Optional[KernelTimer] = None
+
+
+def set_timer(t: Optional[KernelTimer]) -> None:
+    global _timer
+    _timer = t
+
+
+def gemm(A: Tensor, lda: int, a_kmajor: bool, B: Tensor, ldb: int, b_kmajor: bool, M: int, N: int, K: int, *,
+         out: Optional[Tensor] = None, out_f32: bool = False, bias: Optional[Tensor] = None,
+         residual: Optional[Tensor] = None, epilogue: int = _lib.EPI_NONE, aux_in: Optional[Tensor] = None,
+         aux_out: Optional[Tensor] = None, alpha: float = 1.0, beta: int = 0, tag: Optional[str] = None) -> Tensor:
+    dtype = A.dtype
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32 if out_f32 else dtype, device=A.device)
+    timed = _timer is not None and tag in _timer.tags
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(_lib.load().ctmi_gemm(_p(A), lda, int(a_kmajor), _p(B), ldb, int(b_kmajor), _p(out), N, M, N, K, float(alpha), int(beta),
+                                _p(bias), _p(residual), int(epilogue), _p(aux_in), _p(aux_out), int(out_f32), dt_code(dtype),
+                                _stream()), "gemm")
+    if timed:
+        e1.record()
+        _timer.events[tag].append((e0, e1))
+    return out
+
+
+def linear_fwd(x2d: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None,
+               epilogue: int = _lib.EPI_NONE, aux_out: Optional[Tensor] = None, tag: Optional[str] = None) -> Tensor:
+    """y[T,out] = epilogue(x[T,in] @ w[out,in]^T + bias) (+ residual).  w in the compute dtype."""
+    T, K = x2d.shape
+    N = w.shape[0]
+    return gemm(x2d, K, False, w, K, False, T, N, K, bias=bias, residual=residual, epilogue=epilogue, aux_out=aux_out, tag=tag)
+
+
+def linear_dgrad(dy: Tensor, w: Tensor, epilogue: int = _lib.EPI_NONE, aux_in: Optional[Tensor] = None,
+                 residual: Optional[Tensor] = None) -> Tensor:
+    """dx[T,in] = dy[T,out] @ w[out,in]  (w read K-major: no transposed copy)."""
+    T, Nout = dy.shape
+    Kin = w.shape[1]
+    return gemm(dy, Nout, False, w, Kin, True, T, Kin, Nout, epilogue=epilogue, aux_in=aux_in, residual=residual)
+
+
+def linear_wgrad(dy: Tensor, x2d: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    """dW[out,in] (fp32) = dy[T,out]^T @ x[T,in]."""
+    T, Nout = dy.shape
+    Kin = x2d.shape[1]
+    return gemm(dy, Nout, True, x2d, Kin, True, Nout, Kin, T, out=out, out_f32=True, beta=int(accumulate))
+
+
+def colsum(x2d: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    M, N = x2d.shape
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=x2d.device)
+    ws = torch.empty(lib.ctmi_colsum_ws(M, N), dtype=torch.float32, device=x2d.device)
+    check(lib.ctmi_colsum(_p(x2d), N, _p(out), int(accumulate), _p(ws), M, N, dt_code(x2d.dtype), _stream()), "colsum")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ attention
+class MaskInfo:
+    """Device-side digest of attention_mask [B,S]: ALiBi key positions, key validity, first valid key."""
+    __slots__ = ("kpos", "kvalid", "first_valid", "B", "S")
+
+    def __init__(self, attention_mask: Tensor):
+        _need_cuda(attention_mask)
+        am = _c(attention_mask.to(torch.int64))
+        B, S = am.shape
+        self.B, self.S = B, S
+        self.kpos = torch.empty((B, S), dtype=torch.float32, device=am.device)
+        self.kvalid = torch.empty((B, S), dtype=torch.int32, device=am.device)
+        self.first_valid = torch.empty((B,), dtype=torch.int32, device=am.device)
+        check(_lib.load().ctmi_mask_prep(_p(am), _p(self.kpos), _p(self.kvalid), _p(self.first_valid), B, S, _stream()),
+              "mask_prep")
+
+
+def _strided_desc(B, nh, Sq, Sk, hd, q_str, k_str, v_str, o_str, scale, causal, am_str=(0, 0, 0, 0)) -> AttnDesc:
+    d = AttnDesc()
+    d.B, d.nh, d.Sq, d.Sk, d.hd = B, nh, Sq, Sk, hd
+    d.q_bs, d.q_hs, d.q_rs = q_str
+    d.k_bs, d.k_hs, d.k_rs = k_str
+    d.v_bs, d.v_hs, d.v_rs = v_str
+    d.o_bs, d.o_hs, d.o_rs = o_str
+    d.am_b, d.am_h, d.am_q, d.am_k = am_str
+    d.scale = float(scale)
+    d.causal = int(causal)
+    return d
+
+
+def _view_ptr(t: Tensor):
+    return C.c_void_p(t.data_ptr())
+
+
+def attn_fwd(q: Tensor, k: Tensor, v: Tensor, out: Tensor, desc: AttnDesc, slopes: Optional[Tensor],
+             mask: Optional[MaskInfo], add_mask: Optional[Tensor] = None):
+    """q,k,v,out: tensors (possibly views) whose data_ptr is element (b=0,h=0,row=0,d=0); strides in `desc`."""
+    dev = q.device
+    stat_m = torch.empty((desc.B, desc.nh, desc.Sq), dtype=torch.float32, device=dev)
+    stat_l = torch.empty((desc.B, desc.nh, desc.Sq), dtype=torch.float32, device=dev)
+    check(_lib.load().ctmi_attn_fwd(_view_ptr(q), _view_ptr(k), _view_ptr(v), _view_ptr(out), _p(stat_m), _p(stat_l),
+                                    _p(slopes), _p(mask.kpos) if (mask is not None and slopes is not None) else None,
+                                    _p(mask.kvalid) if mask is not None else None,
+                                    _p(mask.first_valid) if mask is not None else None,
+                                    _p(add_mask), C.byref(desc), dt_code(q.dtype), _stream()), "attn_fwd")
+    return stat_m, stat_l
+
+
+def attn_bwd(q, k, v, o, d_o, stat_m, stat_l, dq, dk, dv, desc: AttnDesc, slopes, mask: Optional[MaskInfo],
+             add_mask: Optional[Tensor] = None):
+    delta = torch.empty((desc.B, desc.nh, desc.Sq), dtype=torch.float32, device=q.device)
+    check(_lib.load().ctmi_attn_bwd(_view_ptr(q), _view_ptr(k), _view_ptr(v), _view_ptr(o), _view_ptr(d_o), _p(stat_m), _p(stat_l),
+                                    _view_ptr(dq), _view_ptr(dk), _view_ptr(dv), _p(delta), _p(slopes),
+                                    _p(mask.kpos) if (mask is not None and slopes is not None) else None,
+                                    _p(mask.kvalid) if mask is not None else None,
+                                    _p(mask.first_valid) if mask is not None else None,
+                                    _p(add_mask), C.byref(desc), dt_code(q.dtype), _stream()), "attn_bwd")
+
+
+def fused_qkv_desc(B: int, S: int, nh: int, hd: int, causal: bool) -> AttnDesc:
+    """Strides of the head-interleaved fused QKV activation [B,S,nh,3,hd] (modeling_bloom.py:81-82) and of the
+    merged-head context [B,S,nh*hd]."""
+    H = nh * hd
+    qkv = (S * 3 * H, 3 * hd, 3 * H)
+    return _strided_desc(B, nh, S, S, hd, qkv, qkv, qkv, (S * H, hd, H), 1.0 / math.sqrt(hd), causal)
+
+
+# ------------------------------------------------------------------------------------------------ embedding / CE
+def embed_fwd(table: Tensor, ids: Tensor, err_flag: Optional[Tensor] = None) -> Tensor:
+    _need_cuda(table, ids)
+    V, H = table.shape
+    ids_c = _c(ids)
+    out = torch.empty((*ids.shape, H), dtype=table.dtype, device=table.device)
+    check(_lib.load().ctmi_embed_fwd(_p(table), _p(ids_c), _p(out), ids_c.numel(), H, V, dt_code(table.dtype), _p(err_flag),
+                                     _stream()), "embed_fwd")
+    return out
+
+
+def embed_bwd(dout: Tensor, ids: Tensor, dtable: Tensor) -> None:
+    """dtable (fp32 [V,H]) += scatter(dout rows by ids)."""
+    V, H = dtable.shape
+    ids_c = _c(ids)
+    check(_lib.load().ctmi_embed_bwd(_p(dout), _p(ids_c), _p(dtable), ids_c.numel(), H, V, dt_code(dout.dtype), _stream()),
+          "embed_bwd")
+
+
+def ce_fwd(logits2d: Tensor, labels: Tensor, seq: int, shift: int, ignore_index: int = -100, denom_mode: int = 0,
+           denom_rows: int = 0):
+    """-> loss_out fp32[2] (= [loss, 1/denom]), row_lse fp32[N]."""
+    N, Cn = logits2d.shape
+    dev = logits2d.device
+    row_lse = torch.empty(N, dtype=torch.float32, device=dev)
+    row_loss = torch.empty(N, dtype=torch.float32, device=dev)
+    loss_out = torch.empty(2, dtype=torch.float32, device=dev)
+    check(_lib.load().ctmi_ce_fwd(_p(logits2d), logits2d.stride(0), _p(labels), _p(row_lse), _p(row_loss), _p(loss_out), N, Cn,
+                                  seq, shift, ignore_index, denom_mode, denom_rows, dt_code(logits2d.dtype), _stream()), "ce_fwd")
+    return loss_out, row_lse
+
+
+def ce_bwd(logits2d: Tensor, labels: Tensor, row_lse: Tensor, loss_out: Tensor, gout: Optional[Tensor], seq: int, shift: int,
+           ignore_index: int = -100, out: Optional[Tensor] = None) -> Tensor:
+    N, Cn = logits2d.shape
+    if out is None:
+        out = torch.empty((N, Cn), dtype=logits2d.dtype, device=logits2d.device)
+    check(_lib.load().ctmi_ce_bwd(_p(logits2d), logits2d.stride(0), _p(labels), _p(row_lse), _p(loss_out), _p(gout), _p(out),
+                                  out.stride(0), N, Cn, seq, shift, ignore_index, dt_code(logits2d.dtype), _stream()), "ce_bwd")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ utilities
+def cast(src: Tensor, dtype: torch.dtype, out: Optional[Tensor] = None) -> Tensor:
+    _need_cuda(src)
+    src = _c(src)
+    if out is None:
+        out = torch.empty(src.shape, dtype=dtype, device=src.device)
+    check(_lib.load().ctmi_cast(_p(src), dt_code(src.dtype), _p(out), dt_code(dtype), src.numel(), _stream()), "cast")
+    return out
+
+
+def sumsq(x: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    if out is None:
+        out = torch.zeros(1, dtype=torch.float64, device=x.device)
+        accumulate = True
+    check(_lib.load().ctmi_sumsq(_p(x), x.numel(), _p(out), int(accumulate), _stream()), "sumsq")
+    return out
+
+
+def scale_(x: Tensor, s: float, s_dev: Optional[Tensor] = None) -> Tensor:
+    check(_lib.load().ctmi_scale(_p(x), x.numel(), float(s), _p(s_dev), _stream()), "scale")
+    return x
+
+
+def argmax_lastdim(x2d: Tensor) -> Tensor:
+    rows, cols = x2d.shape
+    out = torch.empty(rows, dtype=torch.int64, device=x2d.device)
+    check(_lib.load().ctmi_argmax(_p(x2d), x2d.stride(0), _p(out), rows, cols, dt_code(x2d.dtype), _stream()), "argmax")
+    return out
+
+
+def _ptr_array(ts):
+    arr = (C.c_void_p * len(ts))()
+    for i, t in enumerate(ts):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+def adamw_step(params, grads, exp_avg, exp_avg_sq, shadows, *, lr, beta1, beta2, eps, weight_decay, step, decoupled,
+               mutate_grad=False, grad_scale=1.0) -> None:
+    n = len(params)
+    if n == 0:
+        return
+    sizes = (C.c_int64 * n)(*[p.numel() for p in params])
+    sh = _ptr_array(shadows) if shadows is not None else None
+    check(_lib.load().ctmi_adamw_step(_ptr_array(params), _ptr_array(grads), _ptr_array(exp_avg), _ptr_array(exp_avg_sq), sh,
+                                      sizes, n, float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
+                                      int(decoupled), int(mutate_grad), float(grad_scale), _stream()), "adamw_step")
+
+
+def sgd_step(params, grads, bufs, shadows, *, lr, momentum, dampening, weight_decay, first_step) -> None:
+    n = len(params)
+    if n == 0:
+        return
+    sizes = (C.c_int64 * n)(*[p.numel() for p in params])
+    check(_lib.load().ctmi_sgd_step(_ptr_array(params), _ptr_array(grads), _ptr_array(bufs) if bufs is not None else None,
+                                    _ptr_array(shadows) if shadows is not None else None, sizes, n, float(lr), float(momentum or 0.0),
+                                    float(dampening or 0.0), float(weight_decay or 0.0), int(first_step), _stream()), "sgd_step")
+
+
+# ------------------------------------------------------------------------------------------------ bf16 shadows
+def compute_weight(p: Tensor, dtype: torch.dtype) -> Tensor:
+    """The matrix `p` (an fp32 master parameter) in the compute dtype.  fp32 -> p itself.  bf16 -> a cached shadow,
+    refreshed when p's version counter moved (torch optimizers / load_state_dict) and written directly by the fused
+    optimizer (which does not move the counter)."""
+    if dtype == torch.float32 or p.dtype == dtype:
+        return p.detach()
+    sh = getattr(p, "_ct_shadow", None)
+    if sh is None or sh.device != p.device or sh.shape != p.shape or getattr(p, "_ct_shadow_ver", -1) != p._version \
+            or getattr(p, "_ct_shadow_ptr", 0) != p.data_ptr():
+        sh = cast(p.detach(), dtype, out=sh if (sh is not None and sh.shape == p.shape and sh.device == p.device) else None)
+        p._ct_shadow = sh
+        p._ct_shadow_ver = p._version
+        p._ct_shadow_ptr = p.data_ptr()
+    return sh

@@ -1,0 +1,114 @@
+"""MI355X-native counterparts of CleanTransformer/optimizer.py: AdamW (optimizer.py:53-97) and SGD (12-50), as fused
+multi-tensor HIP kernels (one launch per <=24 tensors, 28 B/param of HBM traffic for AdamW).
+
+Reference quirks, decided once:
+  Q1  the repo's "AdamW" is Adam + L2 (``grad += wd * param`` in place, coupled decay).  ``AdamW(...)`` here defaults
+      to exactly that; ``decoupled=True`` gives torch.optim.AdamW semantics (what ft_bloom.py:70 actually runs).
+  Q2  ``AdamW(model.parameters())`` silently no-ops in the reference because the generator is exhausted in
+      ``__init__``; here the parameters are materialised with ``list(params)`` (bug not replicated).
+State is exposed under the reference's attribute names: ``params``, ``momentum_buffer``, ``rmsp_buffer``, ``steps``.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+def _flatten_param_groups(params):
+    out = []
+    for p in params:
+        if isinstance(p, dict):
+            out.extend(list(p["params"]))
+        else:
+            out.append(p)
+    return out
+
+
+class AdamW():
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoupled=False,
+                 grad_scale=1.0):
+        self.params = _flatten_param_groups(list(params))
+        self.lr = lr
+        self.beta1, self.beta2 = betas
+        self.eps = eps
+        self.momentum_buffer = [0 for _ in self.params]
+        self.rmsp_buffer = [0 for _ in self.params]
+        self.steps = [1 for _ in self.params]
+        self.weight_decay = weight_decay
+        self.decoupled = decoupled
+        self.grad_scale = grad_scale
+
+    def zero_grad(self):
+        for param in self.params:
+            if param.grad is not None:
+                param.grad = None
+
+    def _lazy_state(self, i, p):
+        if not torch.is_tensor(self.momentum_buffer[i]):
+            self.momentum_buffer[i] = torch.zeros_like(p, dtype=torch.float32)
+            self.rmsp_buffer[i] = torch.zeros_like(p, dtype=torch.float32)
+
+    @torch.no_grad()
+    def step(self):
+        by_step = {}
+        for i, p in enumerate(self.params):
+            if p.grad is None:
+                continue
+            if p.dtype != torch.float32 or p.grad.dtype != torch.float32:
+                raise TypeError("ctmi355 AdamW keeps fp32 master parameters and fp32 gradients")
+            if not p.is_contiguous() or not p.grad.is_contiguous():
+                raise ValueError("ctmi355 AdamW needs contiguous parameters and gradients")
+            self._lazy_state(i, p)
+            by_step.setdefault(self.steps[i], []).append(i)
+        for t, idx in by_step.items():
+            ps = [self.params[i] for i in idx]
+            shadows = [getattr(p, "_ct_shadow", None) for p in ps]
+            for p, sh in zip(ps, shadows):                 # a stale shadow would be overwritten anyway; keep its tag in sync
+                if sh is not None:
+                    p._ct_shadow_ver, p._ct_shadow_ptr = p._version, p.data_ptr()
+            ops.adamw_step(ps, [p.grad for p in ps], [self.momentum_buffer[i] for i in idx],
+                           [self.rmsp_buffer[i] for i in idx], shadows,
+                           lr=self.lr, beta1=self.beta1, beta2=self.beta2, eps=self.eps,
+                           weight_decay=self.weight_decay or 0.0, step=t, decoupled=self.decoupled,
+                           mutate_grad=not self.decoupled, grad_scale=self.grad_scale)
+            for i in idx:
+                self.steps[i] += 1
+
+
+class SGD():
+    def __init__(self, params, lr=0.01, momentum=None, dampening=0, weight_decay=None):
+        self.params = _flatten_param_groups(list(params))
+        self.lr = lr
+        self.momentum = momentum
+        self.dampening = dampening
+        self.momentum_buffer = [None for _ in self.params]
+        self.weight_decay = weight_decay
+
+    def zero_grad(self):
+        for param in self.params:
+            if param.grad is not None:
+                param.grad = None
+
+    @torch.no_grad()
+    def step(self):
+        first, rest = [], []
+        for i, p in enumerate(self.params):
+            if p.grad is None:
+                continue
+            if self.momentum and self.momentum_buffer[i] is None:
+                self.momentum_buffer[i] = torch.empty_like(p, dtype=torch.float32)
+                first.append(i)
+            else:
+                rest.append(i)
+        for idx, is_first in ((first, True), (rest, False)):
+            if not idx:
+                continue
+            ps = [self.params[i] for i in idx]
+            shadows = [getattr(p, "_ct_shadow", None) for p in ps]
+            for p, sh in zip(ps, shadows):
+                if sh is not None:
+                    p._ct_shadow_ver, p._ct_shadow_ptr = p._version, p.data_ptr()
+            ops.sgd_step(ps, [p.grad for p in ps], [self.momentum_buffer[i] for i in idx] if self.momentum else None, shadows,
+                         lr=self.lr, momentum=self.momentum or 0.0, dampening=self.dampening or 0.0,
+                         weight_decay=self.weight_decay or 0.0, first_step=is_first)

@@ -1,0 +1,186 @@
+"""DistributedDataParallel for one-process-per-GPU data parallelism over RCCL/xGMI.
+
+The reference wraps its model in ``torch.nn.parallel.DistributedDataParallel`` (examples/ft_bloom_DDP.py:99,
+kwargs funnel at trainer/trainer.py:1187-1207).  This class keeps that constructor / attribute surface
+(``DDP(model, device_ids=[local_rank])``, ``.module``, ``state_dict`` keys prefixed ``module.``, ``no_sync()``) and
+reproduces torch-DDP's semantics — parameters and buffers broadcast from rank 0 at construction; gradients bucketed in
+reverse parameter order (first bucket 1 MiB, then ``bucket_cap_mb`` = 25 MiB); each bucket pre-divided by the world
+size and sum-all-reduced as soon as its last gradient is produced, asynchronously, while backward keeps running — but
+is built MI355X-first:
+
+  * one flat fp32 buffer per bucket, allocated once (sized for 288 GB HBM: no per-step allocation, no re-bucketing);
+  * the all-reduce is issued from the autograd hook through ``torch.distributed`` (backend "nccl" == RCCL on ROCm):
+    RCCL runs it on its own HIP stream, fenced against the compute stream by events, so buckets overlap with the
+    remaining backward kernels; the compute stream only waits at the end of backward;
+  * on a fully connected xGMI mesh large buckets are what keeps all 7 links busy, hence the 25 MiB default stays and
+    the oversized tied embedding/LM-head gradient travels as one bucket.
+
+It is transport-agnostic (``gloo`` on CPU works and is how the semantics are tested: tests/test_ddp_gloo.py).
+"""
+from __future__ import annotations
+
+from contextlib import contextmanager
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+_MiB = 1024 * 1024
+
+
+class _Bucket:
+    __slots__ = ("params", "offsets", "numel", "flat", "pending", "work", "index")
+
+    def __init__(self, index: int, params: List[torch.nn.Parameter]):
+        self.index = index
+        self.params = params
+        self.offsets = []
+        off = 0
+        for p in params:
+            self.offsets.append(off)
+            off += p.numel()
+        self.numel = off
+        self.flat: Optional[torch.Tensor] = None
+        self.pending = 0
+        self.work = None
+
+
+def build_buckets(params: List[torch.nn.Parameter], bucket_cap_bytes: int, first_bucket_bytes: int = _MiB) -> List[List[int]]:
+    """Reverse-order, size-capped bucket assignment (indices into `params`), torch-DDP style: gradients become ready
+    roughly in reverse parameter order, so bucket 0 holds the LAST parameters.  A parameter larger than the cap gets a
+    bucket of its own."""
+    buckets, cur, cur_bytes = [], [], 0
+    cap = first_bucket_bytes
+    for i in reversed(range(len(params))):
+        nbytes = params[i].numel() * 4
+        if cur and cur_bytes + nbytes > cap:
+            buckets.append(cur)
+            cur, cur_bytes = [], 0
+            cap = bucket_cap_bytes
+        cur.append(i)
+        cur_bytes += nbytes
+    if cur:
+        buckets.append(cur)
+    return buckets
+
+
+class DistributedDataParallel(torch.nn.Module):
+    def __init__(self, module: torch.nn.Module, device_ids=None, output_device=None, dim=0, broadcast_buffers=True,
+                 process_group=None, bucket_cap_mb=None, find_unused_parameters=False, check_reduction=False,
+                 gradient_as_bucket_view=False, static_graph=False, **kwargs):
+        super().__init__()
+        if not dist.is_available() or not dist.is_initialized():
+            raise RuntimeError("DistributedDataParallel needs torch.distributed.init_process_group(...) first "
+                               "(examples/ft_bloom_DDP.py:183 does init_process_group('nccl'), i.e. RCCL on ROCm)")
+        if find_unused_parameters:
+            raise NotImplementedError("find_unused_parameters=True is not supported: every parameter of the SFT model "
+                                      "receives a gradient each step")
+        self.module = module
+        self.process_group = process_group if process_group is not None else dist.group.WORLD
+        self.world_size = dist.get_world_size(self.process_group)
+        self.device_ids = device_ids
+        self.broadcast_buffers = broadcast_buffers
+        self.bucket_cap_mb = 25 if bucket_cap_mb is None else bucket_cap_mb
+        self.require_backward_grad_sync = True
+        self._params = [p for p in module.parameters() if p.requires_grad]
+        if not self._params:
+            raise RuntimeError("DistributedDataParallel is not needed when a module doesn't have any parameter that requires a gradient.")
+        self._sync_module_states()
+        cap = int(self.bucket_cap_mb * _MiB)
+        layout = build_buckets(self._params, cap, first_bucket_bytes=min(_MiB, cap))
+        self._buckets = [_Bucket(bi, [self._params[i] for i in idxs]) for bi, idxs in enumerate(layout)]
+        self._where = {}
+        for b in self._buckets:
+            for j, p in enumerate(b.params):
+                self._where[id(p)] = (b, j)
+        self._callback_queued = False
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad_ready) for p in self._params]
+
+    # ---------------------------------------------------------------- construction-time broadcast (rank 0 wins)
+    def _sync_module_states(self):
+        tensors = [p.data for p in self.module.parameters()]
+        if self.broadcast_buffers:
+            tensors += [b.data for b in self.module.buffers()]
+        self._broadcast_coalesced(tensors)
+
+    def _broadcast_coalesced(self, tensors, chunk_bytes: int = 256 * _MiB):
+        seen, groups = set(), {}
+        for t in tensors:
+            if t.data_ptr() in seen or t.numel() == 0:
+                continue
+            seen.add(t.data_ptr())
+            groups.setdefault((t.dtype, t.device), []).append(t)
+        for (_, _), ts in groups.items():
+            batch, nbytes = [], 0
+            for t in ts + [None]:
+                if t is not None and (not batch or nbytes + t.numel() * t.element_size() <= chunk_bytes):
+                    batch.append(t)
+                    nbytes += t.numel() * t.element_size()
+                    continue
+                flat = torch.cat([x.reshape(-1) for x in batch])
+                dist.broadcast(flat, src=dist.get_global_rank(self.process_group, 0) if hasattr(dist, "get_global_rank") else 0,
+                               group=self.process_group)
+                off = 0
+                for x in batch:
+                    x.copy_(flat[off:off + x.numel()].view_as(x))
+                    off += x.numel()
+                batch, nbytes = ([t], t.numel() * t.element_size()) if t is not None else ([], 0)
+
+    # ---------------------------------------------------------------- backward-time reduction
+    def _on_grad_ready(self, p: torch.nn.Parameter):
+        if not self.require_backward_grad_sync:
+            return
+        if not self._callback_queued:
+            self._callback_queued = True
+            for b in self._buckets:
+                b.pending = len(b.params)
+                b.work = None
+            torch.autograd.Variable._execution_engine.queue_callback(self._finalize_backward)
+        b, j = self._where[id(p)]
+        if b.flat is None or b.flat.device != p.grad.device:
+            b.flat = torch.empty(b.numel, dtype=torch.float32, device=p.grad.device)
+        off = b.offsets[j]
+        b.flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
+        b.pending -= 1
+        if b.pending == 0:
+            self._launch(b)
+
+    def _launch(self, b: _Bucket):
+        _scale_(b.flat, 1.0 / self.world_size)                       # torch-DDP order: divide, then sum
+        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
+
+    def _finalize_backward(self):
+        self._callback_queued = False
+        missing = [b.index for b in self._buckets if b.pending != 0]
+        if missing:
+            raise RuntimeError(f"DistributedDataParallel: buckets {missing} did not receive all of their gradients in this "
+                               f"backward pass (unused parameters are not supported)")
+        for b in self._buckets:
+            b.work.wait()                                           # compute stream waits on the RCCL stream; host does not block
+            for p, off in zip(b.params, b.offsets):
+                p.grad.copy_(b.flat[off:off + p.numel()].view_as(p.grad))
+            b.work = None
+
+    @contextmanager
+    def no_sync(self):
+        """Gradient accumulation: skip the all-reduce inside this context (same contract as torch DDP)."""
+        old = self.require_backward_grad_sync
+        self.require_backward_grad_sync = False
+        try:
+            yield
+        finally:
+            self.require_backward_grad_sync = old
+
+    def forward(self, *inputs, **kwargs):
+        return self.module(*inputs, **kwargs)
+
+    def bucket_summary(self):
+        return [(b.index, len(b.params), b.numel * 4) for b in self._buckets]
+
+
+def _scale_(flat: torch.Tensor, s: float) -> None:
+    if flat.is_cuda:
+        from .. import ops
+        ops.scale_(flat, s)
+    else:                                                           # gloo / CPU: semantics tests only
+        flat.mul_(s)

@@ -1,0 +1,160 @@
+/*
+ * ctmi355 — C ABI of the MI355X (gfx950) kernels behind the CleanTransformer SFT hot path.
+ *
+ * The reference (firechecking/CleanTransformer @ 2024-10-16) is pure Python on stock PyTorch: it has
+ * no FFI.  Every entry point below therefore replaces the *aten call sites* of one reference
+ * function; the citation names that function (file:line relative to the reference checkout).
+ * The reference-side binding a maintainer would add is a ctypes stub — see INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers + sizes; no torch types.  All pointers are DEVICE pointers unless marked host.
+ *   - `dtype` selects the storage type of activations / matrices: CTMI_F32 or CTMI_BF16.
+ *     Statistics, biases, LayerNorm affine parameters, optimizer state and ALL parameter
+ *     gradients are fp32 in both modes.  Accumulation is always fp32.
+ *   - `stream` is a hipStream_t (NULL = default stream).  Every call is asynchronous; nothing
+ *     inside synchronises the device or allocates persistent memory.  Workspaces are passed in.
+ *   - return value: 0 on success, negative ctmi_status otherwise; ctmi_last_error() gives the text
+ *     (thread-local).  Nothing throws or exits across the ABI.
+ *   - re-entrant; safe to call from PyTorch's autograd worker threads.
+ */
+#ifndef CTMI355_H
+#define CTMI355_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTMI_ABI_VERSION 1
+
+enum ctmi_dtype { CTMI_F32 = 0, CTMI_BF16 = 1 };
+enum ctmi_status { CTMI_OK = 0, CTMI_ERR_ARG = -1, CTMI_ERR_LAUNCH = -2, CTMI_ERR_UNSUPPORTED = -3 };
+
+int ctmi_abi_version(void);
+const char* ctmi_last_error(void);
+
+/* ---- LayerNorm  (transformer.py:71-89 LayerNorm._mean/forward; used at modeling_bloom.py:143,155,191,205)
+ * y = w * (x-mean)/sqrt(var_biased+eps) + b over the last `cols` elements of each of `rows` rows.
+ * mean/rstd (fp32 [rows]) are saved for the backward. */
+int ctmi_layernorm_fwd(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd,
+                       int64_t rows, int64_t cols, float eps, int dtype, void* stream);
+/* dx = LN'(dy) (+ dres if non-NULL: the residual-branch gradient, fused);  dw/db (fp32 [cols]) are
+ * overwritten (accumulate=0) or added to (accumulate=1).  ws: fp32 workspace of ctmi_layernorm_bwd_ws(rows, cols) floats. */
+int64_t ctmi_layernorm_bwd_ws(int64_t rows, int64_t cols);
+int ctmi_layernorm_bwd(const void* dy, const void* x, const float* w, const float* mean, const float* rstd,
+                       const void* dres, void* dx, float* dw, float* db, int accumulate, float* ws,
+                       int64_t rows, int64_t cols, int dtype, void* stream);
+
+/* ---- dense GEMM family  (torch.nn.Linear call sites: modeling_bloom.py:79,121,256,267,220 and their autograd)
+ *   C[M,N] = epilogue( alpha * sum_k opA(m,k) * opB(k,n) )
+ *   a_kmajor=0: A is [M,K] row-major (lda);  a_kmajor=1: A is stored [K,M] row-major (lda)
+ *   b_kmajor=0: B is [N,K] row-major (ldb)   b_kmajor=1: B is stored [K,N] row-major (ldb)
+ *     forward  y = x W^T      : a_kmajor=0,b_kmajor=0 (A=x[T,in],  B=W[out,in])
+ *     dgrad    dx = dy W      : a_kmajor=0,b_kmajor=1 (A=dy[T,out], B=W[out,in] read as [K=out, N=in])
+ *     wgrad    dW = dy^T x    : a_kmajor=1,b_kmajor=1 (A=dy[T,out] as [K=T,M=out], B=x[T,in] as [K=T,N=in])
+ *   epilogue (applied in this order):
+ *     + bias[n] (fp32, NULL = none)
+ *     CTMI_EPI_GELU : aux_out[m,n] = v (pre-activation, storage dtype);  v = bloom tanh-GELU(v)   (modeling_bloom.py:335-344)
+ *     CTMI_EPI_DGELU: v *= gelu'(aux_in[m,n])                                                     (modeling_bloom.py:348-363)
+ *     CTMI_EPI_RELU : v = max(v,0)          CTMI_EPI_DRELU: v = aux_in[m,n] > 0 ? v : 0            (transformer.py:98-102 FFN)
+ *     + residual[m,n] (storage dtype, NULL = none; ldc stride)                                     (modeling_bloom.py:122,269)
+ *     beta=1: + C_old
+ *   out_f32=1 writes C as fp32 regardless of dtype (parameter gradients). */
+enum ctmi_epilogue { CTMI_EPI_NONE = 0, CTMI_EPI_GELU = 1, CTMI_EPI_DGELU = 2, CTMI_EPI_RELU = 3, CTMI_EPI_DRELU = 4 };
+int ctmi_gemm(const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor,
+              void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+              float alpha, int beta, const float* bias, const void* residual, int epilogue,
+              const void* aux_in, void* aux_out, int out_f32, int dtype, void* stream);
+
+/* column sum: out[n] (+)= sum_m x[m,n]  — bias gradients (autograd of the Linear biases). */
+int ctmi_colsum(const void* x, int64_t ld, float* out, int accumulate, float* ws, int64_t M, int64_t N, int dtype, void* stream);
+int64_t ctmi_colsum_ws(int64_t M, int64_t N);
+
+/* ---- attention  (modeling_bloom.py:84-116 BloomAttentionLayer core; transformer.py:40-57 AttentionLayer core)
+ * Fused  softmax( scale*q.k + slope[h]*kpos[b,k] + add_mask  ; masked -> finfo.min ) v , flash-style,
+ * never materialising [S,S].  q/k/v/o are addressed as  base + b*bs + h*hs + row*rs + d  (element strides),
+ * so the head-interleaved fused-QKV buffer (modeling_bloom.py:81-82) and a [B,nh,S,hd] KV cache are both native.
+ *   slopes   fp32 [nh] or NULL   (ALiBi, modeling_bloom.py:309-331)
+ *   kpos     fp32 [B,Sk] or NULL (ALiBi key positions (cumsum(mask)-1)*mask, modeling_bloom.py:328)
+ *   kvalid   int32 [B,Sk] or NULL(1 = attend; the ~attention_mask half of _attn_mask, modeling_bloom.py:178-179)
+ *   first_valid int32 [B] (index of the first attendable key, Sk if none; required with kvalid)
+ *   causal   1: key j visible to query i iff j <= i + (Sk-Sq)  (tril half of _attn_mask, modeling_bloom.py:180-183)
+ *   add_mask fp32 additive mask or NULL, element strides am_b, am_h, am_q, am_k (0 = broadcast) (transformer.py:43-45)
+ * Masked scores take the value finfo(float).min exactly as the reference's masked_fill does, so a query row
+ * whose visible keys are all masked gets a UNIFORM distribution over all Sk keys, not NaN.
+ * stat_m / stat_l (fp32 [B,nh,Sq]) = row max and row sum of exp(score-max); saved for the backward. */
+typedef struct ctmi_attn_desc {
+    int64_t B, nh, Sq, Sk, hd;
+    int64_t q_bs, q_hs, q_rs, k_bs, k_hs, k_rs, v_bs, v_hs, v_rs, o_bs, o_hs, o_rs;
+    int64_t am_b, am_h, am_q, am_k;
+    float scale;
+    int causal;
+} ctmi_attn_desc;
+int ctmi_attn_fwd(const void* q, const void* k, const void* v, void* o, float* stat_m, float* stat_l,
+                  const float* slopes, const float* kpos, const int32_t* kvalid, const int32_t* first_valid,
+                  const float* add_mask, const ctmi_attn_desc* desc /* host */, int dtype, void* stream);
+/* dq/dk/dv use the q/k/v strides of desc; do uses the o strides.  delta: fp32 workspace [B,nh,Sq]. */
+int ctmi_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                  const float* stat_m, const float* stat_l, void* dq, void* dk, void* dv, float* delta,
+                  const float* slopes, const float* kpos, const int32_t* kvalid, const int32_t* first_valid,
+                  const float* add_mask, const ctmi_attn_desc* desc /* host */, int dtype, void* stream);
+/* attention_mask [B,S] (int64 0/1) -> kpos fp32, kvalid int32, first_valid int32[B]  (modeling_bloom.py:328, 178-179) */
+int ctmi_mask_prep(const int64_t* attention_mask, float* kpos, int32_t* kvalid, int32_t* first_valid,
+                   int64_t B, int64_t S, void* stream);
+
+/* ---- embedding  (modeling_bloom.py:190 word_embeddings; its autograd = scatter-add into the tied [V,H] grad)
+ * ids are int64; out-of-range ids raise CTMI_ERR_ARG lazily via *err_flag (int32 device word, may be NULL). */
+int ctmi_embed_fwd(const void* table, const int64_t* ids, void* out, int64_t n_tokens, int64_t H, int64_t V,
+                   int dtype, int32_t* err_flag, void* stream);
+int ctmi_embed_bwd(const void* dout, const int64_t* ids, float* dtable /* fp32 [V,H], += */, int64_t n_tokens,
+                   int64_t H, int64_t V, int dtype, void* stream);
+
+/* ---- cross entropy  (torch.nn.CrossEntropyLoss at modeling_bloom.py:224-230; repo loss.py:29-49)
+ * logits [N, C] (ld = row stride).  Row r = (b, s) with b = r / seq, s = r % seq takes its target from
+ * labels[b*seq + s + shift]; rows with s + shift >= seq, or whose target == ignore_index, carry no loss
+ * (shift=1, seq=S reproduces shift_logits/shift_labels of modeling_bloom.py:225-226 without the
+ * .contiguous() copy; shift=0, seq=N is a plain CE).
+ * fwd: row_lse fp32 [N], row_loss fp32 [N];  loss_out[0] = sum(row_loss)/denom, loss_out[1] = 1/denom
+ *      denom_mode 0: number of loss-carrying rows (torch 'mean'); 1: N_rows_total given by `denom_rows`
+ *      (loss.py:47-48 divides by input.shape[0]); 2: 1 ('sum').
+ * bwd: dlogits[r,c] = (softmax - onehot) * gout[0] * loss_out[1]   (0 for rows without loss). */
+int ctmi_ce_fwd(const void* logits, int64_t ld, const int64_t* labels, float* row_lse, float* row_loss,
+                float* loss_out, int64_t N, int64_t C, int64_t seq, int64_t shift, int64_t ignore_index,
+                int denom_mode, int64_t denom_rows, int dtype, void* stream);
+int ctmi_ce_bwd(const void* logits, int64_t ld, const int64_t* labels, const float* row_lse, const float* loss_out,
+                const float* gout /* device scalar or NULL = 1 */, void* dlogits, int64_t ldd,
+                int64_t N, int64_t C, int64_t seq, int64_t shift, int64_t ignore_index, int dtype, void* stream);
+
+/* ---- optimizers  (optimizer.py:53-97 AdamW [L2 form]; torch.optim.AdamW as called at ft_bloom.py:70 [decoupled];
+ *                   optimizer.py:12-50 SGD)
+ * Multi-tensor: `count` tensors described by host arrays of device pointers; one launch per <=CTMI_MT_MAX tensors.
+ *   shadow[i] (may be NULL): bf16 copy of the updated parameter written in the same pass (compute-dtype weights).
+ *   decoupled=0: g += wd*p (and, if mutate_grad, written back like the reference does), Adam update with
+ *                p -= lr * (m/(1-b1^t)) / (sqrt(v/(1-b2^t)) + eps)
+ *   decoupled=1: p *= 1-lr*wd;  p -= (lr/(1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ *   grad_scale: multiplies g on read (1/world for deferred DDP averaging, or a clip coefficient). */
+#define CTMI_MT_MAX 24
+int ctmi_adamw_step(float* const* p /*host*/, float* const* g /*host*/, float* const* m /*host*/, float* const* v /*host*/,
+                    void* const* shadow /*host, entries may be NULL*/, const int64_t* n /*host*/, int count,
+                    float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                    int decoupled, int mutate_grad, float grad_scale, void* stream);
+int ctmi_sgd_step(float* const* p, float* const* g, float* const* buf /* momentum buffers or NULL */,
+                  void* const* shadow, const int64_t* n, int count, float lr, float momentum, float dampening,
+                  float weight_decay, int first_step, void* stream);
+
+/* ---- small utilities on flat buffers */
+int ctmi_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
+/* out[0] (+)= sum(x^2), fp64 accumulation (device double) — global grad-norm (trainer.py:491-498 clip_grad_norm_) */
+int ctmi_sumsq(const float* x, int64_t n, double* out, int accumulate, void* stream);
+int ctmi_scale(float* x, int64_t n, float s, const float* s_dev /* optional device scalar multiplier */, void* stream);
+/* argmax over the last dim of x[rows, cols] -> int64 (first maximal index, as torch.argmax; generation_util.py:86) */
+int ctmi_argmax(const void* x, int64_t ld, int64_t* out, int64_t rows, int64_t cols, int dtype, void* stream);
+
+/* ---- hardware probe (diagnostics: dumps MFMA / LDS-transpose lane layouts into out[]; used by tests only) */
+int ctmi_probe(int which, const float* in /* device */, float* out /* device, 256 floats */, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTMI355_H */

@@ -1,0 +1,257 @@
+"""TEST INFRASTRUCTURE: CPU emulation of the ctmi355 kernel *contracts* (include/ctmi355.h), written with plain torch
+ops.  ``install()`` monkeypatches ``cleantransformer_amd.ops`` so that the product's host logic — autograd nodes,
+the hand-derived block backward, the tied-weight gradient hand-off, optimizers, DDP — can be exercised in the build
+container (no GPU) against the golden vectors.  It is never used by the product path or on the GPU box's -m gpu tests,
+where the real HIP kernels run and are checked one by one against the oracle.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+FMIN = torch.finfo(torch.float32).min
+
+
+def _gelu(x):
+    return x * 0.5 * (1.0 + torch.tanh(0.79788456 * x * (1 + 0.044715 * x * x)))
+
+
+def _dgelu(x):
+    t = torch.tanh(0.79788456 * x * (1 + 0.044715 * x * x))
+    return 0.5 * x * ((1 - t * t) * (0.79788456 + 0.1070322243 * x * x)) + 0.5 * (1 + t)
+
+
+def layernorm_fwd(x2d, w, b, eps):
+    x = x2d.float()
+    mean = x.mean(-1)
+    var = ((x - mean[:, None]) ** 2).mean(-1)
+    rstd = 1.0 / torch.sqrt(var + eps)
+    y = w * ((x - mean[:, None]) * rstd[:, None]) + b
+    return y.to(x2d.dtype), mean, rstd
+
+
+def layernorm_bwd(dy, x, w, mean, rstd, dres=None):
+    xh = (x.float() - mean[:, None]) * rstd[:, None]
+    g = dy.float() * w
+    dx = rstd[:, None] * (g - g.mean(-1, keepdim=True) - xh * (g * xh).mean(-1, keepdim=True))
+    if dres is not None:
+        dx = dx + dres.float()
+    return dx.to(x.dtype), (dy.float() * xh).sum(0), dy.float().sum(0)
+
+
+def gemm(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, *, out=None, out_f32=False, bias=None, residual=None, epilogue=0,
+         aux_in=None, aux_out=None, alpha=1.0, beta=0, tag=None):
+    a = A.reshape(-1)[: (K if a_kmajor else M) * lda].view(-1, lda)
+    a = a[:, :M].t() if a_kmajor else a[:, :K]
+    b = B.reshape(-1)[: (K if b_kmajor else N) * ldb].view(-1, ldb)
+    b = b[:, :N] if b_kmajor else b[:, :K].t()
+    v = alpha * (a.float() @ b.float())
+    if bias is not None:
+        v = v + bias
+    cd = A.dtype
+    if epilogue == 1:
+        v = v.to(cd).float()
+        aux_out.copy_(v.to(cd))
+        v = _gelu(v)
+    elif epilogue == 2:
+        v = v * _dgelu(aux_in.float())
+    elif epilogue == 3:
+        v = torch.relu(v)
+    elif epilogue == 4:
+        v = torch.where(aux_in.float() > 0, v, torch.zeros(()))
+    if residual is not None:
+        v = v + residual.float()
+    odt = torch.float32 if out_f32 else cd
+    if out is None:
+        out = torch.empty((M, N), dtype=odt)
+        beta = 0
+    if beta:
+        v = v + out.float()
+    out.copy_(v.to(out.dtype))
+    return out
+
+
+def colsum(x2d, out=None, accumulate=False):
+    s = x2d.float().sum(0)
+    if out is None:
+        return s
+    out.copy_(out + s if accumulate else s)
+    return out
+
+
+class MaskInfo:
+    def __init__(self, attention_mask):
+        am = attention_mask.to(torch.int64)
+        self.B, self.S = am.shape
+        self.kpos = ((am.cumsum(-1) - 1) * am).float()
+        self.kvalid = (am != 0).to(torch.int32)
+        fv = torch.full((self.B,), self.S, dtype=torch.int32)
+        for b in range(self.B):
+            nz = (am[b] != 0).nonzero()
+            if len(nz):
+                fv[b] = int(nz[0])
+        self.first_valid = fv
+
+
+def _strided(t, B, nh, S, hd, bs, hs, rs):
+    return t.as_strided((B, nh, S, hd), (bs, hs, rs, 1), t.storage_offset())
+
+
+def _scores(q, k, desc, slopes, mask, add_mask):
+    B, nh, Sq, Sk = desc.B, desc.nh, desc.Sq, desc.Sk
+    s = torch.einsum("bhqd,bhkd->bhqk", q.float(), k.float()) * desc.scale
+    if slopes is not None:
+        s = s + slopes.view(1, nh, 1, 1) * mask.kpos.view(B, 1, 1, Sk)
+    if add_mask is not None:
+        s = s + add_mask.as_strided((B, nh, Sq, Sk), (desc.am_b, desc.am_h, desc.am_q, desc.am_k), add_mask.storage_offset())
+    masked = torch.zeros(B, 1, Sq, Sk, dtype=torch.bool)
+    if desc.causal:
+        qi = torch.arange(Sq).view(Sq, 1) + (Sk - Sq)
+        masked = masked | (torch.arange(Sk).view(1, Sk) > qi).view(1, 1, Sq, Sk)
+    if mask is not None:
+        masked = masked | (mask.kvalid.view(B, 1, 1, Sk) == 0)
+    masked = masked.expand(B, nh, Sq, Sk)
+    return torch.where(masked, torch.full((), FMIN), s), masked
+
+
+def attn_fwd(q, k, v, out, desc, slopes, mask, add_mask=None):
+    B, nh, Sq, Sk, hd = desc.B, desc.nh, desc.Sq, desc.Sk, desc.hd
+    qv = _strided(q, B, nh, Sq, hd, desc.q_bs, desc.q_hs, desc.q_rs)
+    kv = _strided(k, B, nh, Sk, hd, desc.k_bs, desc.k_hs, desc.k_rs)
+    vv = _strided(v, B, nh, Sk, hd, desc.v_bs, desc.v_hs, desc.v_rs)
+    s, _ = _scores(qv, kv, desc, slopes, mask, add_mask)
+    m = s.max(-1).values
+    p = torch.exp(s - m[..., None])
+    l = p.sum(-1)
+    o = torch.einsum("bhqk,bhkd->bhqd", p / l[..., None], vv.float())
+    _strided(out, B, nh, Sq, hd, desc.o_bs, desc.o_hs, desc.o_rs).copy_(o.to(out.dtype))
+    return m, l
+
+
+def attn_bwd(q, k, v, o, d_o, stat_m, stat_l, dq, dk, dv, desc, slopes, mask, add_mask=None):
+    B, nh, Sq, Sk, hd = desc.B, desc.nh, desc.Sq, desc.Sk, desc.hd
+    qv = _strided(q, B, nh, Sq, hd, desc.q_bs, desc.q_hs, desc.q_rs)
+    kv = _strided(k, B, nh, Sk, hd, desc.k_bs, desc.k_hs, desc.k_rs)
+    vv = _strided(v, B, nh, Sk, hd, desc.v_bs, desc.v_hs, desc.v_rs)
+    ov = _strided(o, B, nh, Sq, hd, desc.o_bs, desc.o_hs, desc.o_rs).float()
+    gv = _strided(d_o, B, nh, Sq, hd, desc.o_bs, desc.o_hs, desc.o_rs).float()
+    s, masked = _scores(qv, kv, desc, slopes, mask, add_mask)
+    p = torch.exp(s - stat_m[..., None]) / stat_l[..., None]
+    delta = (ov * gv).sum(-1)
+    dp = torch.einsum("bhqd,bhkd->bhqk", gv, vv.float())
+    ds = torch.where(masked, torch.zeros(()), p * (dp - delta[..., None]))
+    _strided(dv, B, nh, Sk, hd, desc.v_bs, desc.v_hs, desc.v_rs).copy_(torch.einsum("bhqk,bhqd->bhkd", p, gv).to(dv.dtype))
+    _strided(dk, B, nh, Sk, hd, desc.k_bs, desc.k_hs, desc.k_rs).copy_((desc.scale * torch.einsum("bhqk,bhqd->bhkd", ds, qv.float())).to(dk.dtype))
+    _strided(dq, B, nh, Sq, hd, desc.q_bs, desc.q_hs, desc.q_rs).copy_((desc.scale * torch.einsum("bhqk,bhkd->bhqd", ds, kv.float())).to(dq.dtype))
+
+
+def embed_fwd(table, ids, err_flag=None):
+    return table[ids]
+
+
+def embed_bwd(dout, ids, dtable):
+    dtable.index_add_(0, ids.reshape(-1), dout.float().reshape(-1, dtable.shape[1]))
+
+
+def _targets(labels, N, seq, shift, ignore):
+    lab = labels.reshape(-1)
+    tgt = torch.full((N,), -1, dtype=torch.int64)
+    for r in range(N):
+        s = r % seq
+        if s + shift < seq:
+            t = int(lab[(r // seq) * seq + s + shift])
+            tgt[r] = -1 if t == ignore else t
+    return tgt
+
+
+def ce_fwd(logits2d, labels, seq, shift, ignore_index=-100, denom_mode=0, denom_rows=0):
+    N, C = logits2d.shape
+    x = logits2d.float()
+    lse = torch.logsumexp(x, -1)
+    tgt = _targets(labels, N, seq, shift, ignore_index)
+    live = tgt >= 0
+    row = torch.where(live, lse - x.gather(1, tgt.clamp(min=0)[:, None])[:, 0], torch.zeros(()))
+    denom = float(live.sum()) if denom_mode == 0 else (float(denom_rows) if denom_mode == 1 else 1.0)
+    return torch.stack([row.double().sum().float() / denom, torch.tensor(1.0 / denom)]), lse
+
+
+def ce_bwd(logits2d, labels, row_lse, loss_out, gout, seq, shift, ignore_index=-100, out=None):
+    N, C = logits2d.shape
+    tgt = _targets(labels, N, seq, shift, ignore_index)
+    live = tgt >= 0
+    p = torch.exp(logits2d.float() - row_lse[:, None])
+    p[torch.arange(N)[live], tgt[live]] -= 1.0
+    coef = (gout[0] if gout is not None else 1.0) * loss_out[1]
+    d = torch.where(live[:, None], p * coef, torch.zeros(()))
+    return d.to(logits2d.dtype)
+
+
+def cast(src, dtype, out=None):
+    r = src.to(dtype)
+    if out is not None:
+        out.copy_(r)
+        return out
+    return r
+
+
+def sumsq(x, out=None, accumulate=False):
+    s = x.double().pow(2).sum().reshape(1)
+    if out is None:
+        return s
+    out.copy_(out + s if accumulate else s)
+    return out
+
+
+def scale_(x, s, s_dev=None):
+    x.mul_(s * (float(s_dev[0]) if s_dev is not None else 1.0))
+    return x
+
+
+def argmax_lastdim(x2d):
+    return x2d.float().argmax(-1)
+
+
+def adamw_step(params, grads, exp_avg, exp_avg_sq, shadows, *, lr, beta1, beta2, eps, weight_decay, step, decoupled,
+               mutate_grad=False, grad_scale=1.0):
+    bc1, bc2 = 1.0 - beta1 ** step, 1.0 - beta2 ** step
+    for i, (p, g, m, v) in enumerate(zip(params, grads, exp_avg, exp_avg_sq)):
+        p = p.data
+        gg = g * grad_scale
+        if decoupled:
+            p.mul_(1.0 - lr * weight_decay)
+        else:
+            gg = gg + weight_decay * p
+        m.mul_(beta1).add_(gg, alpha=1 - beta1)
+        v.mul_(beta2).addcmul_(gg, gg, value=1 - beta2)
+        if decoupled:
+            p.sub_((lr / bc1) * (m / (v.sqrt() / math.sqrt(bc2) + eps)))
+        else:
+            p.sub_(lr * (m / bc1) / ((v / bc2).sqrt() + eps))
+        if mutate_grad and not decoupled and weight_decay:
+            g.copy_(gg)
+        if shadows is not None and shadows[i] is not None:
+            shadows[i].copy_(p.to(shadows[i].dtype))
+
+
+def sgd_step(params, grads, bufs, shadows, *, lr, momentum, dampening, weight_decay, first_step):
+    for i, (p, g) in enumerate(zip(params, grads)):
+        p = p.data
+        gg = g + weight_decay * p if weight_decay else g.clone()
+        if bufs is not None:
+            if first_step:
+                bufs[i].copy_(gg)
+            else:
+                bufs[i].mul_(momentum).add_(gg, alpha=1 - dampening)
+            gg = bufs[i].clone()
+        g.copy_(gg)
+        p.sub_(lr * gg)
+
+
+def install(monkeypatch):
+    """Patch cleantransformer_amd.ops in place (pytest's monkeypatch undoes it after the test)."""
+    from cleantransformer_amd import ops
+    for name in ("layernorm_fwd", "layernorm_bwd", "gemm", "colsum", "MaskInfo", "attn_fwd", "attn_bwd", "embed_fwd", "embed_bwd",
+                 "ce_fwd", "ce_bwd", "cast", "sumsq", "scale_", "argmax_lastdim", "adamw_step", "sgd_step"):
+        monkeypatch.setattr(ops, name, globals()[name])
+    monkeypatch.setattr(ops, "_need_cuda", lambda *a: None)

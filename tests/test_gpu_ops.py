@@ -1,0 +1,478 @@
+"""GPU (-m gpu): every ctmi355 kernel against the CPU oracle on the same seeded inputs, called through the C ABI.
+
+Tolerances (written here, per the north star): fp32 kernels <= 1e-4 relative (most are ~1e-6); bf16 kernels are
+compared with the fp32 oracle evaluated on the bf16-rounded inputs, with a bf16-sized tolerance (2^-8 relative per
+rounding, a few roundings per op).  Integer results (token ids, argmax, masks) are bit-exact.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import bloom_ref as R  # noqa: E402
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda:0"
+
+
+def ops():
+    from cleantransformer_amd import ops as o
+    return o
+
+
+def lib():
+    from cleantransformer_amd import _lib
+    return _lib
+
+
+def rel_err(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def max_err(a, b):
+    return float((a.detach().double().cpu() - b.detach().double().cpu()).abs().max())
+
+
+def check(name, got, ref, rtol, atol=0.0):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f"{name}: non-finite values"
+    err = (got - ref).abs()
+    bound = atol + rtol * ref.abs()
+    bad = err > bound
+    if bad.any():
+        idx = bad.nonzero()[0].tolist()
+        raise AssertionError(f"{name}: {int(bad.sum())}/{bad.numel()} off; worst abs {float(err.max()):.3e} "
+                             f"rel-norm {rel_err(got, ref):.3e}; first bad idx {idx} got {float(got[tuple(idx)])} ref {float(ref[tuple(idx)])}")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def to_dev(t, dtype):
+    return t.to(DEV).to(dtype).contiguous()
+
+
+def bf(t):
+    """value of t after rounding to bf16 (what the bf16 kernels see)."""
+    return t.to(torch.bfloat16).float()
+
+
+DT = [(torch.float32, 1e-5, 1e-6), (torch.bfloat16, 2e-2, 2e-2)]
+
+
+# ------------------------------------------------------------------------------------------------ probes (diagnostics)
+def test_probe_mfma_layouts():
+    """The MFMA operand/accumulator lane layouts assumed in csrc/mma.h (asymmetric operands catch transposes)."""
+    o, L = ops(), lib()
+    import ctypes as C
+    for which, kdim in ((1, 32), (2, 4)):
+        A = torch.arange(16 * kdim, dtype=torch.float32).reshape(16, kdim) % 7 - 3
+        B = (torch.arange(kdim * 16, dtype=torch.float32).reshape(kdim, 16) * 3 % 5) - 2
+        inp = torch.zeros(1024)
+        if which == 1:
+            inp[:512] = A.reshape(-1)
+            inp[512:1024] = B.reshape(-1)
+        else:
+            inp[:64] = A.reshape(-1)
+            inp[64:128] = B.reshape(-1)
+        d_in, d_out = inp.to(DEV), torch.zeros(256, device=DEV)
+        L.check(L.load().ctmi_probe(which, C.c_void_p(d_in.data_ptr()), C.c_void_p(d_out.data_ptr()), None), "probe")
+        torch.cuda.synchronize()
+        got = d_out.cpu().reshape(64, 4)
+        D = A @ B
+        exp = torch.empty(64, 4)
+        for lane in range(64):
+            for r in range(4):
+                exp[lane, r] = D[(lane >> 4) * 4 + r, lane & 15]
+        assert torch.equal(got, exp), f"MFMA layout assumption broken for probe {which}:\n{got[:8]}\n{exp[:8]}"
+
+
+def test_probe_lds_transpose_read_dump():
+    """ds_read_b64_tr_b16 with lane-linear addresses: dumped to gpurun_out for kernel design (no assertion on layout)."""
+    L = lib()
+    import ctypes as C
+    outs = {}
+    for name, addr in (("linear8", [l * 8 for l in range(64)]),
+                       ("rows32", [(l & 15) * 32 + (l >> 4) * 8 for l in range(64)]),
+                       ("rows128", [(l & 15) * 128 + (l >> 4) * 8 for l in range(64)])):
+        d_in = torch.tensor(addr + [0] * (1024 - 64), dtype=torch.float32, device=DEV)
+        d_out = torch.zeros(256, device=DEV)
+        L.check(L.load().ctmi_probe(0, C.c_void_p(d_in.data_ptr()), C.c_void_p(d_out.data_ptr()), None), "probe")
+        torch.cuda.synchronize()
+        outs[name] = d_out.cpu().reshape(64, 4).to(torch.int64)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/tr_read_probe.txt", "w") as f:
+        for k, v in outs.items():
+            f.write(f"== {k} (u16 element index each lane received)\n")
+            for lane in range(64):
+                f.write(f"lane {lane:2d}: {v[lane].tolist()}\n")
+    # lane-linear 8-byte addresses: lane l reads elements 4l..4l+3 of a [16 x 4] block per 16-lane group, transposed
+    v = outs["linear8"]
+    assert v.min() >= 0 and v.max() < 4096
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("dtype,rtol,atol", DT)
+@pytest.mark.parametrize("rows,cols", [(7, 48), (33, 64), (5, 211), (300, 1024), (64, 4096), (3, 24)])
+def test_layernorm_fwd_bwd(dtype, rtol, atol, rows, cols):
+    o = ops()
+    x = rnd(rows, cols, seed=1) * 2 + 0.3
+    w = 1 + 0.1 * rnd(cols, seed=2)
+    b = 0.05 * rnd(cols, seed=3)
+    gy = rnd(rows, cols, seed=4)
+    dres = rnd(rows, cols, seed=5)
+    xs, gys, drs = (bf(x), bf(gy), bf(dres)) if dtype == torch.bfloat16 else (x, gy, dres)
+    xr = xs.clone().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y_ref = R.layernorm(xr, wr, br, 1e-5)
+    y_ref.backward(gys)
+    y, mean, rstd = o.layernorm_fwd(to_dev(x, dtype), w.to(DEV), b.to(DEV), 1e-5)
+    check("ln.y", y.float(), y_ref, rtol, atol)
+    check("ln.mean", mean, xs.mean(-1), 1e-5, 1e-6)
+    dx, dw, db = o.layernorm_bwd(to_dev(gy, dtype), to_dev(x, dtype), w.to(DEV), mean, rstd)
+    check("ln.dx", dx.float(), xr.grad, rtol * 5, atol * 3)
+    check("ln.dw", dw, wr.grad, 2e-4, 1e-4 * max(1, rows ** 0.5))
+    check("ln.db", db, br.grad, 2e-4, 1e-4 * max(1, rows ** 0.5))
+    dx2, _, _ = o.layernorm_bwd(to_dev(gy, dtype), to_dev(x, dtype), w.to(DEV), mean, rstd, dres=to_dev(dres, dtype))
+    check("ln.dx+dres", dx2.float(), xr.grad + drs, rtol * 5, atol * 4)
+
+
+def test_layernorm_module_golden_and_multidim():
+    from cleantransformer_amd.transformer import LayerNorm
+    OPS = np.load(os.path.join(G, "ops.npz"))
+    ln = LayerNorm(48).to(DEV)
+    with torch.no_grad():
+        ln.weight.copy_(torch.from_numpy(OPS["ln_w"]))
+        ln.bias.copy_(torch.from_numpy(OPS["ln_b"]))
+    x = torch.from_numpy(OPS["ln_x"]).to(DEV).requires_grad_(True)
+    y = ln(x)
+    check("golden ln_y", y, torch.from_numpy(OPS["ln_y"]), 1e-5, 1e-6)
+    y.backward(torch.from_numpy(OPS["ln_gy"]).to(DEV))
+    check("golden ln_gx", x.grad, torch.from_numpy(OPS["ln_gx"]), 1e-4, 1e-6)
+    check("golden ln_gw", ln.weight.grad, torch.from_numpy(OPS["ln_gw"]), 1e-4, 1e-5)
+    check("golden ln_gb", ln.bias.grad, torch.from_numpy(OPS["ln_gb"]), 1e-4, 1e-5)
+    ln2 = LayerNorm([4, 6]).to(DEV)                       # transformer.py:134-141 self-check shape
+    check("golden ln2", ln2(torch.from_numpy(OPS["ln2_x"]).to(DEV)), torch.from_numpy(OPS["ln2_y"]), 1e-5, 1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+GEMM_SHAPES = [(128, 128, 64), (256, 384, 128), (100, 72, 40), (64, 211, 64), (37, 19, 211), (130, 260, 1000), (512, 1024, 1024)]
+
+
+@pytest.mark.parametrize("dtype,rtol,atol", [(torch.float32, 1e-5, 1e-5), (torch.bfloat16, 1.2e-2, 1.2e-2)])
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_forward_dgrad_wgrad(dtype, rtol, atol, M, N, K):
+    o, L = ops(), lib()
+    sc = 1.0 / math.sqrt(K)
+    x, w, bias = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
+    res = rnd(M, N, seed=4)
+    xs, ws, rs = (bf(x), bf(w), bf(res)) if dtype == torch.bfloat16 else (x, w, res)
+    xd, wd, rd = to_dev(x, dtype), to_dev(w, dtype), to_dev(res, dtype)
+    # forward: y = x w^T + b (+res)
+    y = o.linear_fwd(xd, wd, bias.to(DEV))
+    check("gemm.fwd", y.float() * sc, (xs @ ws.t() + bias) * sc, rtol, atol)
+    y = o.linear_fwd(xd, wd, bias.to(DEV), residual=rd)
+    check("gemm.fwd+res", y.float() * sc, (xs @ ws.t() + bias + rs) * sc, rtol, atol)
+    y = o.linear_fwd(xd, wd, None)
+    check("gemm.fwd.nobias", y.float() * sc, (xs @ ws.t()) * sc, rtol, atol)
+    # GELU epilogue keeps the pre-activation
+    u = torch.empty((M, N), dtype=dtype, device=DEV)
+    gl = o.linear_fwd(xd, wd, (bias * 0.1).to(DEV), epilogue=L.EPI_GELU, aux_out=u)
+    pre = (xs @ ws.t()) * 1.0 + bias * 0.1
+    check("gemm.gelu.pre", u.float() * sc, pre * sc, rtol, atol)
+    pre_seen = bf(pre) if dtype == torch.bfloat16 else pre
+    check("gemm.gelu.out", gl.float() * sc, R.gelu_tanh(pre_seen) * sc, rtol * 3, atol * 3)
+    rl = o.linear_fwd(xd, wd, (bias * 0.1).to(DEV), epilogue=L.EPI_RELU)
+    check("gemm.relu", rl.float() * sc, torch.relu(pre) * sc, rtol, atol)
+    # dgrad: dx = dy w   (w read K-major)
+    dy = rnd(M, N, seed=5)
+    dys = bf(dy) if dtype == torch.bfloat16 else dy
+    dyd = to_dev(dy, dtype)
+    scn = 1.0 / math.sqrt(N)
+    dx = o.linear_dgrad(dyd, wd)
+    check("gemm.dgrad", dx.float() * scn, (dys @ ws) * scn, rtol, atol)
+    aux = rnd(M, K, seed=6)
+    auxs = bf(aux) if dtype == torch.bfloat16 else aux
+    dxg = o.linear_dgrad(dyd, wd, epilogue=L.EPI_DGELU, aux_in=to_dev(aux, dtype))
+    check("gemm.dgrad.dgelu", dxg.float() * scn, R.gelu_tanh_bwd(dys @ ws, auxs) * scn, rtol * 2, atol * 2)
+    dxr = o.linear_dgrad(dyd, wd, epilogue=L.EPI_DRELU, aux_in=to_dev(aux, dtype))
+    check("gemm.dgrad.drelu", dxr.float() * scn, torch.where(auxs > 0, dys @ ws, torch.zeros(())) * scn, rtol, atol)
+    # wgrad: dW = dy^T x  (fp32 out, both operands K-major), and accumulation
+    scm = 1.0 / math.sqrt(M)
+    dw = o.linear_wgrad(dyd, xd)
+    assert dw.dtype == torch.float32
+    check("gemm.wgrad", dw * scm, (dys.t() @ xs) * scm, rtol, atol)
+    dw2 = o.linear_wgrad(dyd, xd, out=dw.clone(), accumulate=True)
+    check("gemm.wgrad.acc", dw2 * scm, 2 * (dys.t() @ xs) * scm, rtol, atol)
+    # bias grad
+    db = o.colsum(dyd)
+    check("colsum", db * scm, dys.sum(0) * scm, 1e-5, 1e-5)
+
+
+def test_gemm_transpose_detecting_identity():
+    """A = I with an asymmetric B (guide rule: symmetric inputs hide transposed C writes)."""
+    o = ops()
+    for dtype in (torch.float32, torch.bfloat16):
+        n = 128
+        eye = torch.eye(n)
+        Bm = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 13) - 6
+        y = o.linear_fwd(to_dev(eye, dtype), to_dev(Bm, dtype), None)          # I @ B^T = B^T
+        assert torch.equal(y.float().cpu(), Bm.t()), dtype
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _attn_oracle(qkv, am, nh, causal=True):
+    B, S, _ = qkv.shape
+    alibi = R.build_alibi(am, nh)
+    masked = R.causal_key_mask(am, S) if causal else ~am[:, None, None, :].expand(B, 1, S, S).to(torch.bool)
+    return R.attention_core(qkv, alibi, masked, nh)[0]
+
+
+ATT_CASES = [  # B, S, nh, hd, mask kind
+    (2, 16, 8, 8, "ones"), (3, 10, 8, 8, "mixed"), (2, 70, 4, 16, "mixed"), (2, 128, 2, 64, "right"),
+    (1, 200, 2, 64, "left"), (2, 64, 2, 128, "ones"), (2, 130, 3, 32, "mixed")]
+
+
+def _mask(kind, B, S):
+    am = torch.ones(B, S, dtype=torch.long)
+    if kind in ("right", "mixed") and B > 1:
+        am[1, (S * 3) // 4:] = 0
+    if kind in ("left", "mixed"):
+        am[B - 1 if kind == "mixed" and B > 2 else 0, :max(1, S // 3)] = 0
+    return am
+
+
+@pytest.mark.parametrize("dtype,rtol,atol", [(torch.float32, 2e-5, 2e-6), (torch.bfloat16, 2e-2, 1e-2)])
+@pytest.mark.parametrize("B,S,nh,hd,kind", ATT_CASES)
+def test_bloom_attention_fwd_bwd(dtype, rtol, atol, B, S, nh, hd, kind):
+    o = ops()
+    from cleantransformer_amd.models.modeling_bloom import alibi_slopes
+    H = nh * hd
+    qkv = rnd(B, S, 3 * H, seed=11)
+    go = rnd(B, S, H, seed=12)
+    am = _mask(kind, B, S)
+    qs, gs = (bf(qkv), bf(go)) if dtype == torch.bfloat16 else (qkv, go)
+    qr = qs.clone().requires_grad_(True)
+    ctx_ref = _attn_oracle(qr, am, nh)
+    ctx_ref.backward(gs)
+    mask = o.MaskInfo(am.to(DEV))
+    assert torch.equal(mask.kpos.cpu(), R.alibi_positions(am).float())                       # integer-valued: bit-exact
+    assert torch.equal(mask.kvalid.cpu().long(), am)
+    slopes = alibi_slopes(nh).to(DEV)
+    qd = to_dev(qkv.reshape(B * S, 3 * H), dtype)
+    desc = o.fused_qkv_desc(B, S, nh, hd, causal=True)
+    out = torch.empty((B * S, H), dtype=dtype, device=DEV)
+    sm, sl = o.attn_fwd(qd, qd[:, hd:], qd[:, 2 * hd:], out, desc, slopes, mask)
+    check("attn.out", out.float().view(B, S, H), ctx_ref, rtol, atol)
+    dq = torch.zeros_like(qd)
+    o.attn_bwd(qd, qd[:, hd:], qd[:, 2 * hd:], out, to_dev(go.reshape(B * S, H), dtype), sm, sl,
+               dq, dq[:, hd:], dq[:, 2 * hd:], desc, slopes, mask)
+    check("attn.dqkv", dq.float().view(B, S, 3 * H), qr.grad, rtol * 5, atol * 5)
+
+
+def test_attention_layer_golden_block():
+    """One reference BloomAttentionLayer forward/backward incl. left padding (golden from the reference itself)."""
+    o = ops()
+    from cleantransformer_amd.models.modeling_bloom import alibi_slopes
+    OPS = np.load(os.path.join(G, "ops.npz"))
+    T = lambda k: torch.from_numpy(OPS[k])  # noqa: E731
+    am = T("alibi_mask")
+    hs, res, go = T("att_hs"), T("att_res"), T("att_go")
+    B, S, H = hs.shape
+    nh, hd = 8, H // 8
+    wq, bq, wd, bd = T("att_p_query_key_value.weight"), T("att_p_query_key_value.bias"), T("att_p_dense.weight"), T("att_p_dense.bias")
+    qkv = o.linear_fwd(hs.reshape(-1, H).to(DEV), wq.to(DEV), bq.to(DEV))
+    mask = o.MaskInfo(am.to(DEV))
+    slopes = alibi_slopes(nh).to(DEV)
+    desc = o.fused_qkv_desc(B, S, nh, hd, causal=True)
+    ctx = torch.empty((B * S, H), device=DEV)
+    sm, sl = o.attn_fwd(qkv, qkv[:, hd:], qkv[:, 2 * hd:], ctx, desc, slopes, mask)
+    out = o.linear_fwd(ctx, wd.to(DEV), bd.to(DEV), residual=res.reshape(-1, H).to(DEV))
+    check("golden att_out", out.view(B, S, H), T("att_out"), 2e-5, 2e-6)
+    g2 = go.reshape(-1, H).to(DEV)
+    dctx = o.linear_dgrad(g2, wd.to(DEV))
+    dqkv = torch.empty_like(qkv)
+    o.attn_bwd(qkv, qkv[:, hd:], qkv[:, 2 * hd:], ctx, dctx, sm, sl, dqkv, dqkv[:, hd:], dqkv[:, 2 * hd:], desc, slopes, mask)
+    dhs = o.linear_dgrad(dqkv, wq.to(DEV))
+    check("golden att_ghs", dhs.view(B, S, H), T("att_ghs"), 1e-4, 2e-6)
+    check("golden att_g_qkv_w", o.linear_wgrad(dqkv, hs.reshape(-1, H).to(DEV)), T("att_g_query_key_value.weight"), 1e-4, 2e-6)
+    check("golden att_g_dense_w", o.linear_wgrad(g2, ctx), T("att_g_dense.weight"), 1e-4, 2e-6)
+    check("golden att_g_dense_b", o.colsum(g2), T("att_g_dense.bias"), 1e-4, 2e-6)
+
+
+def test_generic_attention_and_post_ln_block_golden():
+    """transformer.py AttentionLayer / TransformerBlock vs goldens generated from the reference (dropout 0)."""
+    from cleantransformer_amd.transformer import TransformerBlock
+    OPS = np.load(os.path.join(G, "ops.npz"))
+
+    class C:
+        num_attention_heads = 4
+        layer_norm_epsilong = 1e-5
+        attention_probs_dropout_prob = 0.0
+        hidden_size = 32
+        hidden_dropout_prob = 0.0
+    blk = TransformerBlock(C()).to(DEV)
+    with torch.no_grad():
+        for n, p in blk.named_parameters():
+            p.copy_(torch.from_numpy(OPS["blk_p_" + n]))
+    x = torch.from_numpy(OPS["blk_x"]).to(DEV).requires_grad_(True)
+    y = blk(x)
+    check("golden blk_y", y, torch.from_numpy(OPS["blk_y"]), 2e-5, 2e-6)
+    y.backward(torch.from_numpy(OPS["blk_go"]).to(DEV))
+    check("golden blk_gx", x.grad, torch.from_numpy(OPS["blk_gx"]), 2e-4, 2e-6)
+    for n, p in blk.named_parameters():
+        check("golden blk_g_" + n, p.grad, torch.from_numpy(OPS["blk_g_" + n]), 2e-4, 4e-6)
+    check("golden mha_y", blk.attention(x.detach()), torch.from_numpy(OPS["mha_y"]), 2e-5, 2e-6)
+    check("golden mha_y_masked", blk.attention(x.detach(), attention_mask=torch.from_numpy(OPS["mha_addmask"]).to(DEV)),
+          torch.from_numpy(OPS["mha_y_masked"]), 2e-5, 2e-6)
+
+
+# ------------------------------------------------------------------------------------------------ CE / embedding
+@pytest.mark.parametrize("dtype,rtol", [(torch.float32, 2e-6), (torch.bfloat16, 1e-5)])
+@pytest.mark.parametrize("N,C,seq", [(37, 211, 37), (16, 1000, 8), (12, 250880, 6), (6, 77, 3)])
+def test_cross_entropy_shifted(dtype, rtol, N, C, seq):
+    o = ops()
+    logits = rnd(N, C, seed=3) * 2
+    ls = bf(logits) if dtype == torch.bfloat16 else logits
+    labels = torch.randint(0, C, (N,), generator=torch.Generator().manual_seed(4))
+    if seq == N:
+        shift, rows, tgt = 0, torch.arange(N), labels
+    else:
+        shift = 1
+        rows = torch.tensor([r for r in range(N) if (r % seq) + 1 < seq])
+        tgt = labels[rows + 1]
+    lr_ = ls.clone().requires_grad_(True)
+    ref = R.cross_entropy(lr_[rows], tgt)
+    ref.backward()
+    ld = to_dev(logits, dtype)
+    loss_out, row_lse = o.ce_fwd(ld, labels.to(DEV), seq=seq, shift=shift)
+    check("ce.loss", loss_out[:1], ref.reshape(1), rtol, 0)
+    check("ce.lse", row_lse, torch.logsumexp(ls.double(), -1), 2e-6, 1e-6)
+    d = o.ce_bwd(ld, labels.to(DEV), row_lse, loss_out, torch.tensor([0.5], device=DEV), seq=seq, shift=shift)
+    check("ce.dlogits", d.float(), 0.5 * lr_.grad, 1e-2 if dtype == torch.bfloat16 else 1e-5, 1e-9 if dtype == torch.float32 else 1e-6)
+    if shift:
+        dead = torch.tensor([r for r in range(N) if (r % seq) + 1 >= seq])
+        assert float(d.float().cpu()[dead].abs().max()) == 0.0                      # rows without a target carry no gradient
+
+
+def test_cross_entropy_module_golden_and_known_answers():
+    import json
+    from cleantransformer_amd.loss import CrossEntropyLoss
+    OPS = np.load(os.path.join(G, "ops.npz"))
+    lg = torch.from_numpy(OPS["ce_logits"]).to(DEV).requires_grad_(True)
+    tg = torch.from_numpy(OPS["ce_target"]).to(DEV)
+    l = CrossEntropyLoss()(lg, tg)
+    check("golden ce_repo_mean", l, torch.from_numpy(OPS["ce_repo_mean"]), 2e-6)
+    check("golden ce_torch", l, torch.from_numpy(OPS["ce_torch"]), 2e-6)
+    l.backward()
+    check("golden ce_dlogits", lg.grad, torch.from_numpy(OPS["ce_dlogits"]), 1e-5, 1e-9)
+    check("golden ce_repo_sum", CrossEntropyLoss('sum')(lg.detach(), tg), torch.from_numpy(OPS["ce_repo_sum"]), 2e-6)
+    ka = json.load(open(os.path.join(G, "known_answers.json")))
+    torch.manual_seed(999)                                                        # loss.py:76-100 self-check
+    pred, gt = torch.rand(3, 4), torch.randint(0, 4, (3,))
+    assert abs(float(CrossEntropyLoss()(pred.to(DEV), gt.to(DEV))) - ka["ce_index"]) < 2e-6
+
+
+def test_embedding_gather_scatter_exact():
+    o = ops()
+    V, H, n = 211, 64, 300
+    table = rnd(V, H, seed=5)
+    ids = torch.randint(0, V, (n,), generator=torch.Generator().manual_seed(6))
+    for dtype in (torch.float32, torch.bfloat16):
+        td = to_dev(table, dtype)
+        out = o.embed_fwd(td, ids.to(DEV))
+        assert torch.equal(out.cpu(), td.cpu()[ids])                               # gather is bit-exact
+    dout = rnd(n, H, seed=7)
+    dt = torch.zeros(V, H, device=DEV)
+    o.embed_bwd(dout.to(DEV), ids.to(DEV), dt)
+    ref = torch.zeros(V, H).index_add_(0, ids, dout)
+    check("embed.bwd", dt, ref, 1e-5, 1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ optimizers / utils
+def _run_traj(make_opt, steps=50):
+    OPS = np.load(os.path.join(G, "ops.npz"))
+    w = torch.nn.Parameter(torch.from_numpy(OPS["opt_w0"]).clone().to(DEV))
+    b = torch.nn.Parameter(torch.from_numpy(OPS["opt_b0"]).clone().to(DEV))
+    opt = make_opt([w, b])
+    gen = torch.Generator().manual_seed(13)
+    for _ in range(steps):
+        xin, tgt = torch.randn(4, 6, generator=gen), torch.randn(4, 5, generator=gen)
+        wr, br = w.detach().cpu().requires_grad_(True), b.detach().cpu().requires_grad_(True)
+        ((xin @ wr + br - tgt) ** 2).sum().backward()                             # grads from the CPU problem definition
+        opt.zero_grad()
+        w.grad, b.grad = wr.grad.to(DEV), br.grad.to(DEV)
+        opt.step()
+    return w.detach().cpu(), b.detach().cpu()
+
+
+@pytest.mark.parametrize("wd,tag", [(0.0, "wd0"), (0.01, "wd01")])
+def test_adamw_trajectories_match_reference(wd, tag):
+    from cleantransformer_amd.optimizer import AdamW
+    OPS = np.load(os.path.join(G, "ops.npz"))
+    w, b = _run_traj(lambda ps: AdamW(ps, lr=1e-2, weight_decay=wd))                           # repo AdamW == Adam + L2
+    check("adam_repo_w", w, torch.from_numpy(OPS[f"adam_repo_{tag}_w"]), 2e-5, 2e-6)
+    check("adam_repo_b", b, torch.from_numpy(OPS[f"adam_repo_{tag}_b"]), 2e-5, 2e-6)
+    w, b = _run_traj(lambda ps: AdamW(ps, lr=1e-2, weight_decay=wd, decoupled=True))           # torch.optim.AdamW
+    check("adam_torch_w", w, torch.from_numpy(OPS[f"adam_torch_{tag}_w"]), 2e-5, 2e-6)
+    check("adam_torch_b", b, torch.from_numpy(OPS[f"adam_torch_{tag}_b"]), 2e-5, 2e-6)
+
+
+def test_adamw_accepts_generator_and_many_tensors():
+    from cleantransformer_amd.optimizer import AdamW
+    ps = [torch.nn.Parameter(rnd(3 + i, 5, seed=i).to(DEV)) for i in range(60)]      # > CTMI_MT_MAX tensors, odd sizes
+    ref = [p.detach().cpu().clone() for p in ps]
+    opt = AdamW((p for p in ps), lr=1e-3, weight_decay=0.01, decoupled=True)         # a generator (reference bug Q2 not replicated)
+    st = [(torch.zeros_like(r), torch.zeros_like(r)) for r in ref]
+    for t in range(1, 4):
+        for i, p in enumerate(ps):
+            g = rnd(*p.shape, seed=100 * t + i)
+            p.grad = g.to(DEV)
+            R.adamw_update(ref[i], g.clone(), st[i][0], st[i][1], t, 1e-3, weight_decay=0.01, decoupled=True)
+        opt.step()
+    for i, p in enumerate(ps):
+        check(f"adamw.many[{i}]", p, ref[i], 1e-5, 1e-7)
+
+
+def test_adamw_refreshes_bf16_shadow():
+    o = ops()
+    from cleantransformer_amd.optimizer import AdamW
+    p = torch.nn.Parameter(rnd(300, 40, seed=3).to(DEV))
+    sh = o.compute_weight(p, torch.bfloat16)
+    assert torch.equal(sh.float().cpu(), bf(p.detach().cpu()))
+    opt = AdamW([p], lr=1e-1, decoupled=True)
+    p.grad = rnd(300, 40, seed=4).to(DEV)
+    opt.step()
+    sh2 = o.compute_weight(p, torch.bfloat16)
+    assert sh2.data_ptr() == sh.data_ptr()                                           # written in place by the fused kernel
+    assert torch.equal(sh2.float().cpu(), bf(p.detach().cpu()))
+
+
+def test_sgd_trajectory_matches_reference():
+    from cleantransformer_amd.optimizer import SGD
+    OPS = np.load(os.path.join(G, "ops.npz"))
+    w, b = _run_traj(lambda ps: SGD(ps, lr=1e-2, momentum=0.9, weight_decay=0.01))
+    check("sgd_w", w, torch.from_numpy(OPS["sgd_repo_w"]), 2e-5, 2e-6)
+    check("sgd_b", b, torch.from_numpy(OPS["sgd_repo_b"]), 2e-5, 2e-6)
+
+
+def test_utils_cast_sumsq_argmax():
+    o = ops()
+    x = rnd(1000, 37, seed=9)
+    xd = x.to(DEV)
+    assert torch.equal(o.cast(xd, torch.bfloat16).cpu(), x.to(torch.bfloat16))       # RNE conversion is bit-exact
+    check("sumsq", o.sumsq(xd.reshape(-1)), x.double().pow(2).sum().reshape(1), 1e-12)
+    for dtype in (torch.float32, torch.bfloat16):
+        big = to_dev(rnd(5, 250880, seed=2), dtype)
+        assert torch.equal(o.argmax_lastdim(big).cpu(), big.float().cpu().argmax(-1))   # token ids: bit-exact
+    tie = torch.zeros(3, 50, device=DEV)
+    tie[:, 7] = 1
+    tie[:, 30] = 1
+    assert o.argmax_lastdim(tie).tolist() == [7, 7, 7]                               # first maximal index, like torch.argmax
