@@ -7,6 +7,9 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import torch  # noqa: F401  (must come first: libctmi355.so has to bind to the HIP runtime torch already loaded — two
+#                              HIP runtimes in one process cannot both initialise the device)
+
 from ._build import LIB_PATH
 
 F32, BF16 = 0, 1
@@ -35,7 +38,7 @@ PROTOTYPES = {
     "ctmi_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, f32, i32, vp]),
     "ctmi_layernorm_bwd_ws": (i64, [i64, i64]),
     "ctmi_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i64, i64, i32, vp]),
-    "ctmi_gemm": (i32, [vp, i64, i32, vp, i64, i32, vp, i64, i64, i64, i64, f32, i32, vp, vp, i32, vp, vp, i32, i32, vp]),
+    "ctmi_gemm": (i32, [vp, i64, i32, vp, i64, i32, vp, i64, i64, i64, i64, f32, i32, vp, vp, i32, vp, vp, i32, i32, vp, i64, vp]),
     "ctmi_colsum": (i32, [vp, i64, vp, i32, vp, i64, i64, i32, vp]),
     "ctmi_colsum_ws": (i64, [i64, i64]),
     "ctmi_attn_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(AttnDesc), i32, vp]),

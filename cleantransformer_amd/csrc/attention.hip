@@ -40,22 +40,30 @@ struct AT {
     static constexpr int TR_ELEMS = HDP * PTR;
     static_assert((64 * CPR) % 256 == 0, "tile must split over 256 threads");
 
+    // `fast` (wave-uniform: 16-byte aligned strides and hd == HDP): unconditional vector loads; rows beyond the
+    // tensor are clamped to its last row — they carry finite data whose probabilities / dS are forced to zero by the
+    // callers, so no predicate (and no exec-masked load + vmcnt(0) join) is needed in the steady state.
     static __device__ __forceinline__ void load(uint4 (&regs)[NCH], const T* __restrict__ base, int64_t rs, int64_t row0,
-                                                int64_t nrows, int hd, bool vec_ok, int tid) {
+                                                int64_t nrows, int hd, bool fast, int tid) {
+        if (fast) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int id = tid + 256 * i;
+                const int64_t grow = min(row0 + (id & 63), nrows - 1);
+                regs[i] = *reinterpret_cast<const uint4*>(base + grow * rs + (id >> 6) * VEC);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int id = tid + 256 * i;
             const int row = id & 63, c = (id >> 6) * VEC;
             const int64_t grow = row0 + row;
             const T* p = base + grow * rs + c;
-            if (grow < nrows && c + VEC <= hd && vec_ok) {
-                regs[i] = *reinterpret_cast<const uint4*>(p);
-            } else {
-                T tmp[VEC];
+            T tmp[VEC];
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) tmp[j] = (grow < nrows && c + j < hd) ? p[j] : (T)0;
-                regs[i] = *reinterpret_cast<const uint4*>(tmp);
-            }
+            for (int j = 0; j < VEC; ++j) tmp[j] = (grow < nrows && c + j < hd) ? p[j] : (T)0;
+            regs[i] = *reinterpret_cast<const uint4*>(tmp);
         }
     }
     static __device__ __forceinline__ void store_rm(const uint4 (&regs)[NCH], T* __restrict__ tile, int tid) {
@@ -149,12 +157,19 @@ __device__ __forceinline__ void contract64(f32x4 (&acc)[HDP / 16], const T* __re
     }
 }
 
+// Per-key digest staged once per tile: kb = ALiBi key position (>= 0) if the key may be attended, -1 if it is
+// padding (attention_mask == 0), -2 if it lies beyond Sk.
+__device__ __forceinline__ float key_digest(const AttnP& p, int64_t b, int64_t key) {
+    if (key >= p.Sk) return -2.0f;
+    if (p.kvalid != nullptr && p.kvalid[b * p.Sk + key] == 0) return -1.0f;
+    return p.kpos != nullptr ? p.kpos[b * p.Sk + key] : 0.0f;
+}
 // score of (q, key) given the raw dot product; masked -> FINFO_MIN (modeling_bloom.py:99-109)
-__device__ __forceinline__ float score_of(const AttnP& p, float dot, int64_t b, int64_t h, int64_t q, int64_t key, float slope, bool& masked) {
-    masked = (p.causal && key > q + p.off) || (p.kvalid != nullptr && p.kvalid[b * p.Sk + key] == 0);
+__device__ __forceinline__ float score_of(const AttnP& p, float dot, float kb, int64_t b, int64_t h, int64_t q, int64_t key,
+                                          float slope, bool& masked) {
+    masked = (kb < 0.f) || (p.causal && key > q + p.off);
     if (masked) return FINFO_MIN;
-    float s = dot * p.scale;
-    if (p.slopes != nullptr) s += slope * p.kpos[b * p.Sk + key];
+    float s = dot * p.scale + slope * kb;
     if (p.add_mask != nullptr) s += p.add_mask[b * p.am_b + h * p.am_h + q * p.am_q + key * p.am_k];
     return s;
 }
@@ -183,7 +198,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* Ks = reinterpret_cast<T*>(smem_raw);
     T* Vt = Ks + A::RM_ELEMS;
+    float* kbs = reinterpret_cast<float*>(Vt + A::TR_ELEMS);                 // [64] per-key digest of the staged tile
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, li = lane & 15;
+    const bool fast = p.vec_ok && p.hd == HDP;
     const int nqb = (int)((p.Sq + 63) / 64);
     const int qb = nqb - 1 - (int)(blockIdx.x % nqb);                       // longest (latest) query blocks first
     const int64_t bh = blockIdx.x / nqb, h = bh % p.nh, b = bh / p.nh;
@@ -213,31 +230,38 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
     for (int dt = 0; dt < NDT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     uint4 rk[A::NCH], rv[A::NCH];
-    A::load(rk, kp, p.k_rs, 0, p.Sk, (int)p.hd, p.vec_ok, tid);
-    A::load(rv, vp, p.v_rs, 0, p.Sk, (int)p.hd, p.vec_ok, tid);
+    float rkb = 0.f;
+    A::load(rk, kp, p.k_rs, 0, p.Sk, (int)p.hd, fast, tid);
+    A::load(rv, vp, p.v_rs, 0, p.Sk, (int)p.hd, fast, tid);
+    if (tid < 64) rkb = key_digest(p, b, tid);
     A::store_rm(rk, Ks, tid);
     A::store_tr(rv, Vt, tid);
+    if (tid < 64) kbs[tid] = rkb;
     __syncthreads();
+    const int64_t q_eff = my_q < p.Sq ? my_q : 0;
 
     for (int t = 0; t < ntiles; ++t) {
         if (t + 1 < ntiles) {
-            A::load(rk, kp, p.k_rs, (int64_t)(t + 1) * 64, p.Sk, (int)p.hd, p.vec_ok, tid);
-            A::load(rv, vp, p.v_rs, (int64_t)(t + 1) * 64, p.Sk, (int)p.hd, p.vec_ok, tid);
+            A::load(rk, kp, p.k_rs, (int64_t)(t + 1) * 64, p.Sk, (int)p.hd, fast, tid);
+            A::load(rv, vp, p.v_rs, (int64_t)(t + 1) * 64, p.Sk, (int)p.hd, fast, tid);
+            if (tid < 64) rkb = key_digest(p, b, (int64_t)(t + 1) * 64 + tid);
         }
         f32x4 x[4];
         dot_tile<T, HDP>(x, Ks, qf, lane);                                   // x[nt][r] = q . k[key]
         const int64_t kv0 = (int64_t)t * 64;
         float mx = -INFINITY;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < 4; ++nt) {
+            const f32x4 kb4 = *reinterpret_cast<const f32x4*>(kbs + nt * 16 + g * 4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t key = kv0 + nt * 16 + g * 4 + r;
                 float s = -INFINITY;                                        // keys beyond Sk do not exist
-                if (key < p.Sk) { bool msk; s = score_of(p, x[nt][r], b, h, my_q < p.Sq ? my_q : 0, key, slope, msk); }
+                if (kb4[r] > -1.5f) { bool msk; s = score_of(p, x[nt][r], kb4[r], b, h, q_eff, key, slope, msk); }
                 x[nt][r] = s;
                 mx = fmaxf(mx, s);
             }
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m, mx);                                   // finite: every tile holds >= 1 real key
@@ -260,6 +284,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
         if (t + 1 < ntiles) {
             A::store_rm(rk, Ks, tid);
             A::store_tr(rv, Vt, tid);
+            if (tid < 64) kbs[tid] = rkb;
             __syncthreads();
         }
     }
@@ -306,6 +331,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnP p) {
     T* Gt = Gs + A::RM_ELEMS;
     float* st = reinterpret_cast<float*>(Gt + A::TR_ELEMS);                  // [3][64]: m, 1/l, delta
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, li = lane & 15;
+    const bool fast = p.vec_ok && p.hd == HDP;
     const int nkb = (int)((p.Sk + 63) / 64);
     const int kb = (int)(blockIdx.x % nkb);                                  // early key blocks (most work) first
     const int64_t bh = blockIdx.x / nkb, h = bh % p.nh, b = bh / p.nh;
@@ -325,6 +351,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnP p) {
     f32x4 dk[NDT], dv[NDT];
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const float my_kb = key_digest(p, b, my_k);                              // -2: key row does not exist
 
     int qt_begin = 0;
     if (p.causal) {
@@ -348,8 +375,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnP p) {
         else if (which == 2) rstat = q < p.Sq ? sd[q] : 0.f;
     };
     if (qt_begin < qt_end) {
-        A::load(rq, qp, p.q_rs, (int64_t)qt_begin * 64, p.Sq, (int)p.hd, p.vec_ok, tid);
-        A::load(rg, gp, p.o_rs, (int64_t)qt_begin * 64, p.Sq, (int)p.hd, p.vec_ok, tid);
+        A::load(rq, qp, p.q_rs, (int64_t)qt_begin * 64, p.Sq, (int)p.hd, fast, tid);
+        A::load(rg, gp, p.o_rs, (int64_t)qt_begin * 64, p.Sq, (int)p.hd, fast, tid);
         load_stats(qt_begin);
         A::store_rm(rq, Qs, tid); A::store_tr(rq, Qt, tid);
         A::store_rm(rg, Gs, tid); A::store_tr(rg, Gt, tid);
@@ -359,8 +386,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnP p) {
 
     for (int t = qt_begin; t < qt_end; ++t) {
         if (t + 1 < qt_end) {
-            A::load(rq, qp, p.q_rs, (int64_t)(t + 1) * 64, p.Sq, (int)p.hd, p.vec_ok, tid);
-            A::load(rg, gp, p.o_rs, (int64_t)(t + 1) * 64, p.Sq, (int)p.hd, p.vec_ok, tid);
+            A::load(rq, qp, p.q_rs, (int64_t)(t + 1) * 64, p.Sq, (int)p.hd, fast, tid);
+            A::load(rg, gp, p.o_rs, (int64_t)(t + 1) * 64, p.Sq, (int)p.hd, fast, tid);
             load_stats(t + 1);
         }
         f32x4 x[4], y[4];
@@ -375,9 +402,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnP p) {
             for (int r = 0; r < 4; ++r) {
                 const int64_t q = (int64_t)t * 64 + nt * 16 + g * 4 + r;
                 float pr = 0.f, ds = 0.f;
-                if (q < p.Sq && my_k < p.Sk) {
+                if (q < p.Sq && my_kb > -1.5f) {
                     bool msk;
-                    const float s = score_of(p, x[nt][r], b, h, q, my_k, slope, msk);
+                    const float s = score_of(p, x[nt][r], my_kb, b, h, q, my_k, slope, msk);
                     pr = __expf(s - mm[r]) * il[r];
                     ds = msk ? 0.f : pr * (y[nt][r] - dl[r]);
                 }
@@ -413,7 +440,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
     T* Ks = reinterpret_cast<T*>(smem_raw);
     T* Kt = Ks + A::RM_ELEMS;
     T* Vs = Kt + A::TR_ELEMS;
+    float* kbs = reinterpret_cast<float*>(Vs + A::RM_ELEMS);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, li = lane & 15;
+    const bool fast = p.vec_ok && p.hd == HDP;
     const int nqb = (int)((p.Sq + 63) / 64);
     const int qb = nqb - 1 - (int)(blockIdx.x % nqb);
     const int64_t bh = blockIdx.x / nqb, h = bh % p.nh, b = bh / p.nh;
@@ -445,39 +474,46 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
     for (int dt = 0; dt < NDT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     uint4 rk[A::NCH], rv[A::NCH];
-    A::load(rk, kp, p.k_rs, 0, p.Sk, (int)p.hd, p.vec_ok, tid);
-    A::load(rv, vp, p.v_rs, 0, p.Sk, (int)p.hd, p.vec_ok, tid);
+    float rkb = 0.f;
+    A::load(rk, kp, p.k_rs, 0, p.Sk, (int)p.hd, fast, tid);
+    A::load(rv, vp, p.v_rs, 0, p.Sk, (int)p.hd, fast, tid);
+    if (tid < 64) rkb = key_digest(p, b, tid);
     A::store_rm(rk, Ks, tid); A::store_tr(rk, Kt, tid);
     A::store_rm(rv, Vs, tid);
+    if (tid < 64) kbs[tid] = rkb;
     __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
         if (t + 1 < ntiles) {
-            A::load(rk, kp, p.k_rs, (int64_t)(t + 1) * 64, p.Sk, (int)p.hd, p.vec_ok, tid);
-            A::load(rv, vp, p.v_rs, (int64_t)(t + 1) * 64, p.Sk, (int)p.hd, p.vec_ok, tid);
+            A::load(rk, kp, p.k_rs, (int64_t)(t + 1) * 64, p.Sk, (int)p.hd, fast, tid);
+            A::load(rv, vp, p.v_rs, (int64_t)(t + 1) * 64, p.Sk, (int)p.hd, fast, tid);
+            if (tid < 64) rkb = key_digest(p, b, (int64_t)(t + 1) * 64 + tid);
         }
         f32x4 x[4], y[4];
         dot_tile<T, HDP>(x, Ks, qf, lane);
         dot_tile<T, HDP>(y, Vs, gf, lane);
         const int64_t kv0 = (int64_t)t * 64;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < 4; ++nt) {
+            const f32x4 kb4 = *reinterpret_cast<const f32x4*>(kbs + nt * 16 + g * 4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t key = kv0 + nt * 16 + g * 4 + r;
                 float ds = 0.f;
-                if (live && key < p.Sk) {
+                if (live && kb4[r] > -1.5f) {
                     bool msk;
-                    const float s = score_of(p, x[nt][r], b, h, my_q, key, slope, msk);
+                    const float s = score_of(p, x[nt][r], kb4[r], b, h, my_q, key, slope, msk);
                     ds = msk ? 0.f : __expf(s - m) * il * (y[nt][r] - dl);
                 }
                 y[nt][r] = ds;
             }
+        }
         contract64<T, HDP>(dq, Kt, y, lane);                                 // dQ^T[d][my_q] += sum_key K[key][d] dS[my_q][key]
         __syncthreads();
         if (t + 1 < ntiles) {
             A::store_rm(rk, Ks, tid); A::store_tr(rk, Kt, tid);
             A::store_rm(rv, Vs, tid);
+            if (tid < 64) kbs[tid] = rkb;
             __syncthreads();
         }
     }
@@ -510,7 +546,7 @@ static int fill_params(AttnP& p, const ctmi_attn_desc* d, int dtype, const char*
 template <typename T, int HDP>
 static int fwd_launch(AttnP& p, hipStream_t st) {
     using A = AT<T, HDP>;
-    const size_t lds = (size_t)(A::RM_ELEMS + A::TR_ELEMS) * sizeof(T);
+    const size_t lds = (size_t)(A::RM_ELEMS + A::TR_ELEMS) * sizeof(T) + 64 * sizeof(float);
     auto kern = &attn_fwd_kernel<T, HDP>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int64_t grid = ((p.Sq + 63) / 64) * p.B * p.nh;
@@ -535,7 +571,7 @@ static int bwd_launch(AttnP& p, hipStream_t st) {
         CTMI_CHECK_LAUNCH("attn_bwd_dkdv");
     }
     {
-        const size_t lds = (size_t)(2 * A::RM_ELEMS + A::TR_ELEMS) * sizeof(T);
+        const size_t lds = (size_t)(2 * A::RM_ELEMS + A::TR_ELEMS) * sizeof(T) + 64 * sizeof(float);
         auto kern = &attn_bwd_dq_kernel<T, HDP>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         const int64_t grid = ((p.Sq + 63) / 64) * p.B * p.nh;

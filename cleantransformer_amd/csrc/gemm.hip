@@ -4,16 +4,29 @@
 // One 256-thread workgroup (4 wavefronts, 2x2) owns a 128x128 output tile; each wave a 64x64 sub-tile held as
 // 4x4 16x16 accumulators.  Operand tiles are staged HBM -> registers (16-byte loads) -> LDS with the global
 // loads of tile t+1 in flight under the MFMAs of tile t, LDS double-buffered, one barrier per K-step.
-// An operand may be stored K-major ([K][rows]); its fragments are then gathered transposed from LDS, so the
-// same kernel serves forward (x W^T), dgrad (dy W) and wgrad (dy^T x) without any transposed copies in HBM.
+// An operand may be stored K-major ([K][rows]); its fragments are then read transposed from LDS
+// (ds_read_b64_tr_b16 for bf16), so the same kernel serves forward (x W^T), dgrad (dy W) and wgrad (dy^T x)
+// without any transposed copies in HBM.
 // The MFMA is issued with the operands swapped (D' = B A^T) so that every lane ends up with 4 *consecutive
 // output columns* of one row: bias / residual / aux loads and the C store are 8-16 byte vector accesses.
+// FAST instantiations (16-byte aligned operands, contiguous dimension a multiple of the vector width) have a
+// branch-free main loop: unconditional vector loads from clamped addresses + selects; the generic instantiation
+// handles any shape/alignment element-wise.  Small-tile-count problems (weight gradients) are split along K into
+// fp32 slabs in a caller-provided workspace and reduced deterministically by a second kernel.
 #include "common.h"
 #include "mma.h"
 
 template <typename T> struct Tile;
 template <> struct Tile<bf16_t> { static constexpr int BM = 128, BN = 128, BK = 64, PADK = 8, PADR = 8; };
 template <> struct Tile<float>  { static constexpr int BM = 128, BN = 128, BK = 16, PADK = 4, PADR = 4; };
+
+typedef short short4_t __attribute__((ext_vector_type(4)));
+// ds_read_b64_tr_b16 through the compiler builtin (hipcc then tracks its lgkmcnt itself)
+__device__ __forceinline__ uint2 lds_read_tr_b16(const bf16_t* p) {
+    typedef __attribute__((address_space(3))) short4_t lds_v4;
+    const short4_t r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(unsigned)(size_t)p);
+    return __builtin_bit_cast(uint2, r);
+}
 
 // LDS image of one operand tile.  !KMAJOR: [ROWS][BK+PADK] (k contiguous).  KMAJOR: [BK][ROWS+PADR] (rows contiguous).
 template <typename T, bool KMAJOR, int ROWS>
@@ -28,28 +41,63 @@ struct OpTile {
     static constexpr int ELEMS = LINES * PITCH;
     static_assert(LINES * CPL % 256 == 0, "tile must split evenly over 256 threads");
 
-    // HBM -> registers.  row0: first tile row (in the M or N dimension), k0: first k of the tile.
-    static __device__ __forceinline__ void load(uint4 (&regs)[NCH], const T* __restrict__ g, int64_t ld, int64_t row0,
-                                                int64_t k0, int64_t row_lim, int64_t k_lim, bool vec_ok, int tid) {
+    // ---- generic (any shape / alignment): element-wise guarded loads
+    static __device__ __forceinline__ void load_gen(uint4 (&regs)[NCH], const T* __restrict__ g, int64_t ld, int64_t row0,
+                                                    int64_t k0, int64_t row_lim, int64_t k_lim, int tid) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int id = tid + 256 * i;
             const int line = id / CPL, c = (id % CPL) * VEC;
-            const int64_t gline = (KMAJOR ? k0 : row0) + line;           // index along the strided dimension
-            const int64_t gcol = (KMAJOR ? row0 : k0) + c;               // index along the contiguous dimension
+            const int64_t gline = (KMAJOR ? k0 : row0) + line;
+            const int64_t gcol = (KMAJOR ? row0 : k0) + c;
             const int64_t line_lim = KMAJOR ? k_lim : row_lim;
             const int64_t col_lim = KMAJOR ? row_lim : k_lim;
             const T* p = g + gline * ld + gcol;
-            if (gline < line_lim && gcol + VEC <= col_lim && vec_ok) {
-                regs[i] = *reinterpret_cast<const uint4*>(p);
-            } else {
-                T tmp[VEC];
+            T tmp[VEC];
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) tmp[j] = (gline < line_lim && gcol + j < col_lim) ? p[j] : (T)0;
-                regs[i] = *reinterpret_cast<const uint4*>(tmp);
+            for (int j = 0; j < VEC; ++j) tmp[j] = (gline < line_lim && gcol + j < col_lim) ? p[j] : (T)0;
+            regs[i] = *reinterpret_cast<const uint4*>(tmp);
+        }
+    }
+
+    // ---- fast path: per-thread base pointers (clamped in-bounds) + validity bits, set up once per block
+    struct Ptrs { const T* p[NCH]; };
+    static __device__ __forceinline__ void init(Ptrs& P, const T* __restrict__ g, int64_t ld, int64_t row0, int64_t row_lim, int tid) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int id = tid + 256 * i;
+            const int line = id / CPL, c = (id % CPL) * VEC;
+            if (!KMAJOR) {
+                const int64_t row = row0 + line;
+                P.p[i] = g + (row < row_lim ? row : row_lim - 1) * ld + c;
+            } else {
+                const int64_t col = row0 + c;                            // row_lim % VEC == 0 on this path: chunk is all-in or all-out
+                P.p[i] = g + (int64_t)line * ld + (col < row_lim ? col : 0);
             }
         }
     }
+    // k0 = first k of the tile.  Rows (or K-major columns) outside the matrix were clamped to valid addresses by
+    // init(): they load real-but-irrelevant data that only reaches accumulator rows/columns the epilogue never
+    // stores, so the steady-state loads carry NO predicate (a select here makes hipcc re-introduce exec-masked
+    // loads with a vmcnt(0) at every join).  Only the TAIL tile (reaches beyond K) zero-fills, because k >= K must
+    // contribute exactly 0 to valid outputs (K % VEC == 0 for !KMAJOR on this path).
+    template <bool TAIL>
+    static __device__ __forceinline__ void load_fast(uint4 (&regs)[NCH], const Ptrs& P, int64_t ld, int64_t k0, int64_t K, int tid) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            if (!TAIL) {
+                regs[i] = *reinterpret_cast<const uint4*>(P.p[i] + (KMAJOR ? k0 * ld : k0));
+            } else {
+                const int id = tid + 256 * i;
+                const int line = id / CPL, c = (id % CPL) * VEC;
+                const bool kin = KMAJOR ? ((k0 + line) < K) : ((k0 + c) < K);
+                const int64_t kk = kin ? k0 : (KMAJOR ? (K - 1 - line) : (K - VEC - c));
+                const uint4 v = *reinterpret_cast<const uint4*>(P.p[i] + (KMAJOR ? kk * ld : kk));
+                regs[i] = kin ? v : make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+    }
+
     static __device__ __forceinline__ void store(const uint4 (&regs)[NCH], T* __restrict__ tile, int tid) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
@@ -58,24 +106,28 @@ struct OpTile {
             *reinterpret_cast<uint4*>(tile + line * PITCH + c) = regs[i];
         }
     }
-    // MFMA operand fragment for tile row r (0..ROWS) at k offset kofs (= kk*K + (lane>>4)*KL): KL consecutive k.
-    static __device__ __forceinline__ typename Mma<T>::Frag frag(const T* __restrict__ tile, int r, int kofs);
+    // MFMA operand fragment for the 16 tile rows r16..r16+15 (lane's row = r16 + (lane&15)) at k offset
+    // kofs = kk*K + (lane>>4)*KL: KL consecutive k.
+    static __device__ __forceinline__ typename Mma<T>::Frag frag(const T* __restrict__ tile, int r16, int lane, int kofs);
 };
 
-template <> __device__ __forceinline__ short8 OpTile<bf16_t, false, 128>::frag(const bf16_t* __restrict__ tile, int r, int kofs) {
-    return *reinterpret_cast<const short8*>(tile + r * PITCH + kofs);
+template <> __device__ __forceinline__ short8 OpTile<bf16_t, false, 128>::frag(const bf16_t* __restrict__ tile, int r16, int lane, int kofs) {
+    return *reinterpret_cast<const short8*>(tile + (r16 + (lane & 15)) * PITCH + kofs);
 }
-template <> __device__ __forceinline__ short8 OpTile<bf16_t, true, 128>::frag(const bf16_t* __restrict__ tile, int r, int kofs) {
-    short8 f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = (short)tile[(kofs + j) * PITCH + r];
-    return f;
+// K-major image [k][rows]: hardware transpose read.  Lane i of a 16-lane group supplies the address of k-row
+// kofs + (i>>2), columns r16 + 4*(i&3) .. +3 and receives column r16+i for k = kofs .. kofs+3 (probe-verified layout).
+template <> __device__ __forceinline__ short8 OpTile<bf16_t, true, 128>::frag(const bf16_t* __restrict__ tile, int r16, int lane, int kofs) {
+    const int i = lane & 15;
+    const bf16_t* p = tile + (kofs + (i >> 2)) * PITCH + r16 + 4 * (i & 3);
+    const uint2 lo = lds_read_tr_b16(p);
+    const uint2 hi = lds_read_tr_b16(p + 4 * PITCH);
+    return __builtin_bit_cast(short8, make_uint4(lo.x, lo.y, hi.x, hi.y));
 }
-template <> __device__ __forceinline__ float OpTile<float, false, 128>::frag(const float* __restrict__ tile, int r, int kofs) {
-    return tile[r * PITCH + kofs];
+template <> __device__ __forceinline__ float OpTile<float, false, 128>::frag(const float* __restrict__ tile, int r16, int lane, int kofs) {
+    return tile[(r16 + (lane & 15)) * PITCH + kofs];
 }
-template <> __device__ __forceinline__ float OpTile<float, true, 128>::frag(const float* __restrict__ tile, int r, int kofs) {
-    return tile[kofs * PITCH + r];
+template <> __device__ __forceinline__ float OpTile<float, true, 128>::frag(const float* __restrict__ tile, int r16, int lane, int kofs) {
+    return tile[kofs * PITCH + r16 + (lane & 15)];
 }
 
 struct GemmArgs {
@@ -83,7 +135,8 @@ struct GemmArgs {
     int64_t lda, ldb, ldc, M, N, K;
     float alpha; int beta;
     const float* bias; const void* residual; const void* aux_in; void* aux_out;
-    int tiles_m, tiles_n, vec_a, vec_b, vec_c;
+    int tiles_m, tiles_n, vec_c;
+    int splits; int64_t k_per_split; float* slabs;        // split-K: partial products go to slabs[s][M][N] (fp32)
 };
 
 template <typename TO> __device__ __forceinline__ void store4(TO* p, const float* v);
@@ -96,25 +149,33 @@ template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float
     v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u); v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
 }
 
-template <typename T, typename TO, bool AK, bool BKM, int EPI>
+template <typename T, typename TO, bool AK, bool BKM, int EPI, bool FAST>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     using TA = OpTile<T, AK, Tile<T>::BM>;
     using TB = OpTile<T, BKM, Tile<T>::BN>;
     constexpr int BM = Tile<T>::BM, BN = Tile<T>::BN, BK = Tile<T>::BK;
     constexpr int MK = Mma<T>::K, KL = Mma<T>::KL;
+    constexpr int STAGE = TA::ELEMS + TB::ELEMS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* smem = reinterpret_cast<T*>(smem_raw);
-    T* As[2] = { smem, smem + TA::ELEMS + TB::ELEMS };
-    T* Bs[2] = { smem + TA::ELEMS, smem + 2 * TA::ELEMS + TB::ELEMS };
 
-    // XCD-aware block -> tile map: the dispatcher places block b on XCD b%8; give each XCD a contiguous run of
-    // tiles (bijective for any grid size) walking down M for a fixed weight tile, so B tiles are L2-resident.
-    const int nblk = g.tiles_m * g.tiles_n;
+    // Block -> (tile, K-split).  XCD-aware: the dispatcher places block b on XCD b%8; give each XCD a contiguous run
+    // of tile ids (bijective for any grid size).  Inside the run tiles are ordered in groups of 8 M-tiles x all
+    // N-tiles, M fastest, so the ~64 blocks resident on one XCD share 8 A-panels and 8 B-panels in its 4 MiB L2.
+    const int ntile = g.tiles_m * g.tiles_n;
+    const int nblk = ntile * g.splits;
     const int bid = blockIdx.x;
     const int xcd = bid & 7, q = nblk >> 3, r8 = nblk & 7;
-    const int vid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
-    const int tm = vid % g.tiles_m, tn = vid / g.tiles_m;
+    const int vid_all = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    const int split = vid_all / ntile, vid = vid_all - split * ntile;
+    constexpr int GM = 8;
+    const int group = vid / (GM * g.tiles_n), first_m = group * GM;
+    const int gm = min(GM, g.tiles_m - first_m);
+    const int in_group = vid - group * GM * g.tiles_n;
+    const int tm = first_m + in_group % gm, tn = in_group / gm;
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+    const int64_t kbeg = (int64_t)split * g.k_per_split;
+    const int64_t kend = min(g.K, kbeg + g.k_per_split);
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
@@ -127,43 +188,74 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nt = (int)((g.K + BK - 1) / BK);
+    const int nt = (int)((kend - kbeg + BK - 1) / BK);
+    const bool ktail = ((kend - kbeg) % BK) != 0;
     uint4 ra[TA::NCH], rb[TB::NCH];
-    TA::load(ra, A, g.lda, m0, 0, g.M, g.K, g.vec_a, tid);
-    TB::load(rb, B, g.ldb, n0, 0, g.N, g.K, g.vec_b, tid);
-    TA::store(ra, As[0], tid);
-    TB::store(rb, Bs[0], tid);
+    typename TA::Ptrs pa;
+    typename TB::Ptrs pb;
+    if (FAST) {
+        TA::init(pa, A, g.lda, m0, g.M, tid);
+        TB::init(pb, B, g.ldb, n0, g.N, tid);
+    }
+    auto load_tile = [&](int t) {
+        const int64_t k0 = kbeg + (int64_t)t * BK;
+        if (FAST) {
+            if (ktail && t == nt - 1) { TA::template load_fast<true>(ra, pa, g.lda, k0, kend, tid); TB::template load_fast<true>(rb, pb, g.ldb, k0, kend, tid); }
+            else { TA::template load_fast<false>(ra, pa, g.lda, k0, kend, tid); TB::template load_fast<false>(rb, pb, g.ldb, k0, kend, tid); }
+        } else {
+            TA::load_gen(ra, A, g.lda, m0, k0, g.M, kend, tid);
+            TB::load_gen(rb, B, g.ldb, n0, k0, g.N, kend, tid);
+        }
+    };
+    load_tile(0);
+    TA::store(ra, smem, tid);
+    TB::store(rb, smem + TA::ELEMS, tid);
     __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
         const int cur = t & 1;
-        if (t + 1 < nt) {
-            TA::load(ra, A, g.lda, m0, (int64_t)(t + 1) * BK, g.M, g.K, g.vec_a, tid);
-            TB::load(rb, B, g.ldb, n0, (int64_t)(t + 1) * BK, g.N, g.K, g.vec_b, tid);
-        }
-        const T* as = As[cur];
-        const T* bs = Bs[cur];
+        if (t + 1 < nt) load_tile(t + 1);
+        const T* as = smem + cur * STAGE;
+        const T* bs = as + TA::ELEMS;
 #pragma unroll
         for (int kk = 0; kk < BK / MK; ++kk) {
             const int kofs = kk * MK + (lane >> 4) * KL;
             typename Mma<T>::Frag af[4], bf[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = TA::frag(as, wr * 64 + i * 16 + (lane & 15), kofs);
+            for (int i = 0; i < 4; ++i) af[i] = TA::frag(as, wr * 64 + i * 16, lane, kofs);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bf[j] = TB::frag(bs, wc * 64 + j * 16 + (lane & 15), kofs);
+            for (int j = 0; j < 4; ++j) bf[j] = TB::frag(bs, wc * 64 + j * 16, lane, kofs);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(bf[j], af[i], acc[i][j]);   // D'[n][m]
         }
         if (t + 1 < nt) {
-            TA::store(ra, As[cur ^ 1], tid);
-            TB::store(rb, Bs[cur ^ 1], tid);
+            T* nx = smem + (cur ^ 1) * STAGE;
+            TA::store(ra, nx, tid);
+            TB::store(rb, nx + TA::ELEMS, tid);
         }
         __syncthreads();
     }
 
     // epilogue: lane holds C[m][n..n+3], m = m0+wr*64+i*16+(lane&15), n = n0+wc*64+j*16+(lane>>4)*4
+    if (g.splits > 1) {
+        float* S = g.slabs + (int64_t)split * g.M * g.N;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t m = m0 + wr * 64 + i * 16 + (lane & 15);
+            if (m >= g.M) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t n = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+                if (n >= g.N) continue;
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if (n + 4 <= g.N && (g.N & 3) == 0) store4<float>(S + m * g.N + n, v);
+                else { for (int r = 0; r < 4; ++r) if (n + r < g.N) S[m * g.N + n + r] = v[r]; }
+            }
+        }
+        return;
+    }
     TO* C = reinterpret_cast<TO*>(g.C);
     const T* R = reinterpret_cast<const T*>(g.residual);
     const T* AUXI = reinterpret_cast<const T*>(g.aux_in);
@@ -182,8 +274,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = g.alpha * acc[i][j][r];
             if (g.bias != nullptr) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) if (n + r < g.N) v[r] += g.bias[n + r];
+                if (full) { const float4 bb = *reinterpret_cast<const float4*>(g.bias + n); v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
+                else { for (int r = 0; r < 4; ++r) if (n + r < g.N) v[r] += g.bias[n + r]; }
             }
             if (EPI == CTMI_EPI_GELU) {
 #pragma unroll
@@ -222,42 +314,70 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
 }
 
+// C[m,n] = alpha * sum_s slabs[s][m][n] (+ C_old)   — deterministic split-K reduction
+template <typename TO>
+__global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ slabs, TO* __restrict__ C, int64_t ldc,
+                                                     int64_t M, int64_t N, int splits, float alpha, int beta) {
+    const int64_t total = M * N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += slabs[(int64_t)k * total + i];
+        const int64_t m = i / N, n = i - m * N;
+        float v = alpha * s;
+        if (beta) v += Cvt<TO>::to_f(C[m * ldc + n]);
+        C[m * ldc + n] = Cvt<TO>::from_f(v);
+    }
+}
+
 template <typename T, typename TO, bool AK, bool BKM, int EPI>
-static int gemm_launch(GemmArgs& g, hipStream_t st) {
+static int gemm_launch(GemmArgs& g, bool fast, hipStream_t st) {
     using TA = OpTile<T, AK, Tile<T>::BM>;
     using TB = OpTile<T, BKM, Tile<T>::BN>;
     const size_t lds = 2 * (size_t)(TA::ELEMS + TB::ELEMS) * sizeof(T);
-    auto kern = &gemm_kernel<T, TO, AK, BKM, EPI>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(256), lds, st, g);
+    const unsigned grid = (unsigned)(g.tiles_m * g.tiles_n * g.splits);
+    if (fast) {
+        auto kern = &gemm_kernel<T, TO, AK, BKM, EPI, true>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, g);
+    } else {
+        auto kern = &gemm_kernel<T, TO, AK, BKM, EPI, false>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, g);
+    }
     CTMI_CHECK_LAUNCH("gemm");
+    if (g.splits > 1) {
+        const int64_t total = g.M * g.N;
+        const unsigned rg = (unsigned)std::min<int64_t>(cdiv64(total, 256), 4096);
+        hipLaunchKernelGGL((splitk_reduce<TO>), dim3(rg), dim3(256), 0, st, g.slabs, reinterpret_cast<TO*>(g.C), g.ldc, g.M, g.N, g.splits, g.alpha, g.beta);
+        CTMI_CHECK_LAUNCH("gemm_splitk_reduce");
+    }
     return CTMI_OK;
 }
 
 template <typename T>
-static int gemm_dispatch(GemmArgs& g, int ak, int bk, int epi, int out_f32, hipStream_t st) {
+static int gemm_dispatch(GemmArgs& g, int ak, int bk, int epi, int out_f32, bool fast, hipStream_t st) {
     const bool of = out_f32 || sizeof(T) == 4;
     if (!ak && !bk && !of) {
-        if (epi == CTMI_EPI_NONE) return gemm_launch<T, T, false, false, CTMI_EPI_NONE>(g, st);
-        if (epi == CTMI_EPI_GELU) return gemm_launch<T, T, false, false, CTMI_EPI_GELU>(g, st);
-        if (epi == CTMI_EPI_RELU) return gemm_launch<T, T, false, false, CTMI_EPI_RELU>(g, st);
+        if (epi == CTMI_EPI_NONE) return gemm_launch<T, T, false, false, CTMI_EPI_NONE>(g, fast, st);
+        if (epi == CTMI_EPI_GELU) return gemm_launch<T, T, false, false, CTMI_EPI_GELU>(g, fast, st);
+        if (epi == CTMI_EPI_RELU) return gemm_launch<T, T, false, false, CTMI_EPI_RELU>(g, fast, st);
     }
     if (!ak && bk && !of) {
-        if (epi == CTMI_EPI_NONE) return gemm_launch<T, T, false, true, CTMI_EPI_NONE>(g, st);
-        if (epi == CTMI_EPI_DGELU) return gemm_launch<T, T, false, true, CTMI_EPI_DGELU>(g, st);
-        if (epi == CTMI_EPI_DRELU) return gemm_launch<T, T, false, true, CTMI_EPI_DRELU>(g, st);
+        if (epi == CTMI_EPI_NONE) return gemm_launch<T, T, false, true, CTMI_EPI_NONE>(g, fast, st);
+        if (epi == CTMI_EPI_DGELU) return gemm_launch<T, T, false, true, CTMI_EPI_DGELU>(g, fast, st);
+        if (epi == CTMI_EPI_DRELU) return gemm_launch<T, T, false, true, CTMI_EPI_DRELU>(g, fast, st);
     }
-    if (ak && bk && of && epi == CTMI_EPI_NONE) return gemm_launch<T, float, true, true, CTMI_EPI_NONE>(g, st);
+    if (ak && bk && of && epi == CTMI_EPI_NONE) return gemm_launch<T, float, true, true, CTMI_EPI_NONE>(g, fast, st);
     if constexpr (sizeof(T) == 4) {                         // fp32 storage: output is fp32 either way
         if (!ak && !bk) {
-            if (epi == CTMI_EPI_NONE) return gemm_launch<T, float, false, false, CTMI_EPI_NONE>(g, st);
-            if (epi == CTMI_EPI_GELU) return gemm_launch<T, float, false, false, CTMI_EPI_GELU>(g, st);
-            if (epi == CTMI_EPI_RELU) return gemm_launch<T, float, false, false, CTMI_EPI_RELU>(g, st);
+            if (epi == CTMI_EPI_NONE) return gemm_launch<T, float, false, false, CTMI_EPI_NONE>(g, fast, st);
+            if (epi == CTMI_EPI_GELU) return gemm_launch<T, float, false, false, CTMI_EPI_GELU>(g, fast, st);
+            if (epi == CTMI_EPI_RELU) return gemm_launch<T, float, false, false, CTMI_EPI_RELU>(g, fast, st);
         }
         if (!ak && bk) {
-            if (epi == CTMI_EPI_NONE) return gemm_launch<T, float, false, true, CTMI_EPI_NONE>(g, st);
-            if (epi == CTMI_EPI_DGELU) return gemm_launch<T, float, false, true, CTMI_EPI_DGELU>(g, st);
-            if (epi == CTMI_EPI_DRELU) return gemm_launch<T, float, false, true, CTMI_EPI_DRELU>(g, st);
+            if (epi == CTMI_EPI_NONE) return gemm_launch<T, float, false, true, CTMI_EPI_NONE>(g, fast, st);
+            if (epi == CTMI_EPI_DGELU) return gemm_launch<T, float, false, true, CTMI_EPI_DGELU>(g, fast, st);
+            if (epi == CTMI_EPI_DRELU) return gemm_launch<T, float, false, true, CTMI_EPI_DRELU>(g, fast, st);
         }
     }
     ctmi_set_error("gemm: unsupported combination a_kmajor=%d b_kmajor=%d epilogue=%d out_f32=%d", ak, bk, epi, out_f32);
@@ -267,7 +387,8 @@ static int gemm_dispatch(GemmArgs& g, int ak, int bk, int epi, int out_f32, hipS
 extern "C" int ctmi_gemm(const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor,
                          void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                          float alpha, int beta, const float* bias, const void* residual, int epilogue,
-                         const void* aux_in, void* aux_out, int out_f32, int dtype, void* stream) {
+                         const void* aux_in, void* aux_out, int out_f32, int dtype,
+                         void* workspace, int64_t workspace_bytes, void* stream) {
     CTMI_REQUIRE(A && B && C, "gemm: null operand");
     CTMI_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
     CTMI_REQUIRE(lda >= (a_kmajor ? M : K) && ldb >= (b_kmajor ? N : K) && ldc >= N, "gemm: leading dimension too small");
@@ -276,17 +397,32 @@ extern "C" int ctmi_gemm(const void* A, int64_t lda, int a_kmajor, const void* B
     CTMI_REQUIRE(dtype == CTMI_F32 || dtype == CTMI_BF16, "gemm: unsupported dtype %d", dtype);
     const int es = dtype == CTMI_F32 ? 4 : 2;
     const int vec = 16 / es;
+    const int bkt = dtype == CTMI_F32 ? Tile<float>::BK : Tile<bf16_t>::BK;
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.alpha = alpha; g.beta = beta; g.bias = bias; g.residual = residual; g.aux_in = aux_in; g.aux_out = aux_out;
     g.tiles_m = (int)cdiv64(M, 128); g.tiles_n = (int)cdiv64(N, 128);
-    CTMI_REQUIRE((int64_t)g.tiles_m * g.tiles_n < (1LL << 31), "gemm: too many tiles");
-    g.vec_a = (lda % vec == 0) && ((((uintptr_t)A) & 15) == 0);
-    g.vec_b = (ldb % vec == 0) && ((((uintptr_t)B) & 15) == 0);
+    const int64_t ntile = (int64_t)g.tiles_m * g.tiles_n;
+    CTMI_REQUIRE(ntile < (1LL << 27), "gemm: too many tiles");
+    const bool vec_a = (lda % vec == 0) && ((((uintptr_t)A) & 15) == 0) && ((a_kmajor ? M : K) % vec == 0);
+    const bool vec_b = (ldb % vec == 0) && ((((uintptr_t)B) & 15) == 0) && ((b_kmajor ? N : K) % vec == 0);
+    const bool fast = vec_a && vec_b;
     // C-side vector accesses are 4 elements wide (8 B bf16 / 16 B fp32)
     auto al = [](const void* p, int bytes) { return p == nullptr || ((((uintptr_t)p) & (bytes - 1)) == 0); };
     const int cbytes = (out_f32 || dtype == CTMI_F32) ? 16 : 8;
-    g.vec_c = (ldc % 4 == 0) && al(C, cbytes) && al(residual, 4 * es) && al(aux_in, 4 * es) && al(aux_out, 4 * es);
-    if (dtype == CTMI_F32) return gemm_dispatch<float>(g, a_kmajor, b_kmajor, epilogue, out_f32, as_stream(stream));
-    return gemm_dispatch<bf16_t>(g, a_kmajor, b_kmajor, epilogue, out_f32, as_stream(stream));
+    g.vec_c = (ldc % 4 == 0) && al(C, cbytes) && al(residual, 4 * es) && al(aux_in, 4 * es) && al(aux_out, 4 * es) && al(bias, 16);
+    // split-K: only for plain accumulations (weight gradients) that would leave most of the 256 CUs idle
+    g.splits = 1; g.k_per_split = K; g.slabs = nullptr;
+    if (workspace != nullptr && epilogue == CTMI_EPI_NONE && bias == nullptr && residual == nullptr && ntile < 384 && K >= 8 * bkt) {
+        int64_t want = std::min<int64_t>(8, cdiv64(512, ntile));
+        want = std::min<int64_t>(want, K / (4 * bkt));
+        want = std::min<int64_t>(want, workspace_bytes / (int64_t)(M * N * sizeof(float)));
+        if (want > 1) {
+            const int64_t kps = cdiv64(cdiv64(K, want), bkt) * bkt;
+            g.splits = (int)cdiv64(K, kps); g.k_per_split = kps; g.slabs = reinterpret_cast<float*>(workspace);
+            if (g.splits <= 1) { g.splits = 1; g.k_per_split = K; g.slabs = nullptr; }
+        }
+    }
+    if (dtype == CTMI_F32) return gemm_dispatch<float>(g, a_kmajor, b_kmajor, epilogue, out_f32, fast, as_stream(stream));
+    return gemm_dispatch<bf16_t>(g, a_kmajor, b_kmajor, epilogue, out_f32, fast, as_stream(stream));
 }

@@ -93,6 +93,19 @@ def set_timer(t: Optional[KernelTimer]) -> None:
     _timer = t
 
 
+_SPLITK_WS = {}
+
+
+def _splitk_ws(device) -> Tensor:
+    """Per-device scratch for split-K weight-gradient GEMMs (fp32 slabs; 8 x [4096,1024] fits).  Kernels on one stream
+    run in order, so one buffer per device is enough."""
+    ws = _SPLITK_WS.get(device)
+    if ws is None:
+        ws = torch.empty(8 * 4096 * 1024, dtype=torch.float32, device=device)
+        _SPLITK_WS[device] = ws
+    return ws
+
+
 def gemm(A: Tensor, lda: int, a_kmajor: bool, B: Tensor, ldb: int, b_kmajor: bool, M: int, N: int, K: int, *,
          out: Optional[Tensor] = None, out_f32: bool = False, bias: Optional[Tensor] = None,
          residual: Optional[Tensor] = None, epilogue: int = _lib.EPI_NONE, aux_in: Optional[Tensor] = None,
@@ -104,9 +117,10 @@ def gemm(A: Tensor, lda: int, a_kmajor: bool, B: Tensor, ldb: int, b_kmajor: boo
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+    ws = _splitk_ws(A.device) if (a_kmajor and b_kmajor and out_f32) else None
     check(_lib.load().ctmi_gemm(_p(A), lda, int(a_kmajor), _p(B), ldb, int(b_kmajor), _p(out), N, M, N, K, float(alpha), int(beta),
                                 _p(bias), _p(residual), int(epilogue), _p(aux_in), _p(aux_out), int(out_f32), dt_code(dtype),
-                                _stream()), "gemm")
+                                _p(ws), 0 if ws is None else ws.numel() * 4, _stream()), "gemm")
     if timed:
         e1.record()
         _timer.events[tag].append((e0, e1))

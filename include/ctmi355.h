@@ -60,12 +60,15 @@ int ctmi_layernorm_bwd(const void* dy, const void* x, const float* w, const floa
  *     CTMI_EPI_RELU : v = max(v,0)          CTMI_EPI_DRELU: v = aux_in[m,n] > 0 ? v : 0            (transformer.py:98-102 FFN)
  *     + residual[m,n] (storage dtype, NULL = none; ldc stride)                                     (modeling_bloom.py:122,269)
  *     beta=1: + C_old
- *   out_f32=1 writes C as fp32 regardless of dtype (parameter gradients). */
+ *   out_f32=1 writes C as fp32 regardless of dtype (parameter gradients).
+ *   workspace (optional, may be NULL): scratch for deterministic split-K of small-tile-count problems (weight
+ *   gradients): fp32 slabs [splits][M][N]; more workspace = more splits (up to 8). */
 enum ctmi_epilogue { CTMI_EPI_NONE = 0, CTMI_EPI_GELU = 1, CTMI_EPI_DGELU = 2, CTMI_EPI_RELU = 3, CTMI_EPI_DRELU = 4 };
 int ctmi_gemm(const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor,
               void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
               float alpha, int beta, const float* bias, const void* residual, int epilogue,
-              const void* aux_in, void* aux_out, int out_f32, int dtype, void* stream);
+              const void* aux_in, void* aux_out, int out_f32, int dtype,
+              void* workspace, int64_t workspace_bytes, void* stream);
 
 /* column sum: out[n] (+)= sum_m x[m,n]  — bias gradients (autograd of the Linear biases). */
 int ctmi_colsum(const void* x, int64_t ld, float* out, int accumulate, float* ws, int64_t M, int64_t N, int dtype, void* stream);
