@@ -26,9 +26,13 @@ struct AttnP {
     int causal, off, vec_ok;
 };
 
-// 64 x HDP tile staging helpers (256 threads).  Thread -> (row = id & 63, 16-byte chunk = id >> 6): lane == row,
-// so the transposed scatter into [d][64] writes 64 consecutive elements per instruction (conflict-free) and the
-// row-major b128 writes hit 8 different bank groups.
+// 64 x HDP tile staging helpers (256 threads).  Thread -> (row = id / CPR, 16-byte chunk = id % CPR): the CPR lanes of
+// one row read one contiguous run of HBM (coalesced: a head row of hd=64 bf16 is exactly one 128-byte line).
+// The transposed image [d][64] is XOR-swizzled on the key/query index by the d-block ((d>>3)&7)<<3, which makes the
+// 2-byte scatter writes of a wave (8 rows x 8 chunks) land in distinct banks while keeping every aligned group of 4
+// (and 8) streamed indices contiguous for the 8-byte fragment reads.
+__device__ __forceinline__ int tr_swz(int d) { return ((d >> 3) & 7) << 3; }
+
 template <typename T, int HDP>
 struct AT {
     static constexpr int VEC = 16 / sizeof(T);
@@ -49,15 +53,15 @@ struct AT {
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
                 const int id = tid + 256 * i;
-                const int64_t grow = min(row0 + (id & 63), nrows - 1);
-                regs[i] = *reinterpret_cast<const uint4*>(base + grow * rs + (id >> 6) * VEC);
+                const int64_t grow = min(row0 + id / CPR, nrows - 1);
+                regs[i] = *reinterpret_cast<const uint4*>(base + grow * rs + (id % CPR) * VEC);
             }
             return;
         }
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int id = tid + 256 * i;
-            const int row = id & 63, c = (id >> 6) * VEC;
+            const int row = id / CPR, c = (id % CPR) * VEC;
             const int64_t grow = row0 + row;
             const T* p = base + grow * rs + c;
             T tmp[VEC];
@@ -70,17 +74,17 @@ struct AT {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int id = tid + 256 * i;
-            *reinterpret_cast<uint4*>(tile + (id & 63) * PRM + (id >> 6) * VEC) = regs[i];
+            *reinterpret_cast<uint4*>(tile + (id / CPR) * PRM + (id % CPR) * VEC) = regs[i];
         }
     }
     static __device__ __forceinline__ void store_tr(const uint4 (&regs)[NCH], T* __restrict__ tile, int tid) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int id = tid + 256 * i;
-            const int row = id & 63, c = (id >> 6) * VEC;
+            const int row = id / CPR, c = (id % CPR) * VEC;
             const T* e = reinterpret_cast<const T*>(&regs[i]);
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) tile[(c + j) * PTR + row] = e[j];
+            for (int j = 0; j < VEC; ++j) tile[(c + j) * PTR + (row ^ tr_swz(c + j))] = e[j];
         }
     }
 };
@@ -137,9 +141,10 @@ __device__ __forceinline__ void contract64(f32x4 (&acc)[HDP / 16], const T* __re
             const short8 b = __builtin_bit_cast(short8, pk);
 #pragma unroll
             for (int dt = 0; dt < HDP / 16; ++dt) {
-                const bf16_t* rowp = tr_tile + (dt * 16 + li) * PTR + ks * 32 + g * 4;
-                const uint2 a0 = *reinterpret_cast<const uint2*>(rowp);
-                const uint2 a1 = *reinterpret_cast<const uint2*>(rowp + 16);
+                const int d = dt * 16 + li, sw = tr_swz(d);
+                const bf16_t* rowp = tr_tile + d * PTR;
+                const uint2 a0 = *reinterpret_cast<const uint2*>(rowp + ((ks * 32 + g * 4) ^ sw));
+                const uint2 a1 = *reinterpret_cast<const uint2*>(rowp + ((ks * 32 + 16 + g * 4) ^ sw));
                 const short8 a = __builtin_bit_cast(short8, make_uint4(a0.x, a0.y, a1.x, a1.y));
                 acc[dt] = Mma<bf16_t>::mma(a, b, acc[dt]);
             }
@@ -151,8 +156,10 @@ __device__ __forceinline__ void contract64(f32x4 (&acc)[HDP / 16], const T* __re
             for (int r = 0; r < 4; ++r) {
                 const float b = x[nt][r];
 #pragma unroll
-                for (int dt = 0; dt < HDP / 16; ++dt)
-                    acc[dt] = Mma<float>::mma(tr_tile[(dt * 16 + li) * PTR + nt * 16 + g * 4 + r], b, acc[dt]);
+                for (int dt = 0; dt < HDP / 16; ++dt) {
+                    const int d = dt * 16 + li;
+                    acc[dt] = Mma<float>::mma(tr_tile[d * PTR + ((nt * 16 + g * 4 + r) ^ tr_swz(d))], b, acc[dt]);
+                }
             }
     }
 }
@@ -164,14 +171,19 @@ __device__ __forceinline__ float key_digest(const AttnP& p, int64_t b, int64_t k
     if (p.kvalid != nullptr && p.kvalid[b * p.Sk + key] == 0) return -1.0f;
     return p.kpos != nullptr ? p.kpos[b * p.Sk + key] : 0.0f;
 }
-// score of (q, key) given the raw dot product; masked -> FINFO_MIN (modeling_bloom.py:99-109)
-__device__ __forceinline__ float score_of(const AttnP& p, float dot, float kb, int64_t b, int64_t h, int64_t q, int64_t key,
-                                          float slope, bool& masked) {
-    masked = (kb < 0.f) || (p.causal && key > q + p.off);
-    if (masked) return FINFO_MIN;
-    float s = dot * p.scale + slope * kb;
-    if (p.add_mask != nullptr) s += p.add_mask[b * p.am_b + h * p.am_h + q * p.am_q + key * p.am_k];
-    return s;
+// score of (q, key) given the raw dot product; masked -> FINFO_MIN (modeling_bloom.py:99-109).  Branch-free: every
+// condition is a select (a divergent branch per score element costs more than the whole softmax).  AM (additive mask,
+// transformer.py:43-45) is a compile-time switch; am_base already points at element (b, h, 0, 0).
+template <bool AM>
+__device__ __forceinline__ float score_of(const AttnP& p, float dot, float kb, int q, int key, float slope,
+                                          const float* __restrict__ am_base, bool& masked) {
+    masked = (kb < 0.f) | ((p.causal != 0) & (key > q + p.off));
+    float s = fmaf(dot, p.scale, slope * kb);
+    if (AM) {
+        const int qc = min(q, (int)p.Sq - 1), kc = min(key, (int)p.Sk - 1);
+        s += am_base[(int64_t)qc * p.am_q + (int64_t)kc * p.am_k];
+    }
+    return masked ? FINFO_MIN : s;
 }
 
 template <typename T, int HDP>
@@ -191,7 +203,7 @@ __device__ __forceinline__ void store_own_row(T* rowp, const f32x4 (&acc)[HDP / 
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <typename T, int HDP>
+template <typename T, int HDP, bool AM>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
     using A = AT<T, HDP>;
     constexpr int MK = Mma<T>::K, KL = Mma<T>::KL, NKK = HDP / MK, NDT = HDP / 16;
@@ -238,7 +250,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
     A::store_tr(rv, Vt, tid);
     if (tid < 64) kbs[tid] = rkb;
     __syncthreads();
-    const int64_t q_eff = my_q < p.Sq ? my_q : 0;
+    const int q_eff = my_q < p.Sq ? (int)my_q : 0;
+    const float* am_base = AM ? p.add_mask + b * p.am_b + h * p.am_h : nullptr;
 
     for (int t = 0; t < ntiles; ++t) {
         if (t + 1 < ntiles) {
@@ -248,16 +261,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
         }
         f32x4 x[4];
         dot_tile<T, HDP>(x, Ks, qf, lane);                                   // x[nt][r] = q . k[key]
-        const int64_t kv0 = (int64_t)t * 64;
+        const int kv0 = t * 64;
         float mx = -INFINITY;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const f32x4 kb4 = *reinterpret_cast<const f32x4*>(kbs + nt * 16 + g * 4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int64_t key = kv0 + nt * 16 + g * 4 + r;
-                float s = -INFINITY;                                        // keys beyond Sk do not exist
-                if (kb4[r] > -1.5f) { bool msk; s = score_of(p, x[nt][r], kb4[r], b, h, q_eff, key, slope, msk); }
+                bool msk;
+                float s = score_of<AM>(p, x[nt][r], kb4[r], q_eff, kv0 + nt * 16 + g * 4 + r, slope, am_base, msk);
+                s = kb4[r] > -1.5f ? s : -INFINITY;                          // keys beyond Sk do not exist
                 x[nt][r] = s;
                 mx = fmaxf(mx, s);
             }
@@ -320,7 +333,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnP p) {
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
 // own rows = keys.  Per query tile: S = Q K^T and dP = dO V^T (own key in the accumulator column), P = exp(S-m)/l,
 // dS = P (dP - delta); dV^T += dO^T P, dK^T += Q^T dS  (Q, dO staged both row-major and transposed).
-template <typename T, int HDP>
+template <typename T, int HDP, bool AM>
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnP p) {
     using A = AT<T, HDP>;
     constexpr int MK = Mma<T>::K, KL = Mma<T>::KL, NKK = HDP / MK, NDT = HDP / 16;
@@ -352,6 +365,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnP p) {
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     const float my_kb = key_digest(p, b, my_k);                              // -2: key row does not exist
+    const bool key_live = my_kb > -1.5f;
+    const float* am_base = AM ? p.add_mask + b * p.am_b + h * p.am_h : nullptr;
 
     int qt_begin = 0;
     if (p.causal) {
@@ -400,16 +415,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnP p) {
             const f32x4 dl = *reinterpret_cast<const f32x4*>(st + 128 + nt * 16 + g * 4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int64_t q = (int64_t)t * 64 + nt * 16 + g * 4 + r;
-                float pr = 0.f, ds = 0.f;
-                if (q < p.Sq && my_kb > -1.5f) {
-                    bool msk;
-                    const float s = score_of(p, x[nt][r], my_kb, b, h, q, my_k, slope, msk);
-                    pr = __expf(s - mm[r]) * il[r];
-                    ds = msk ? 0.f : pr * (y[nt][r] - dl[r]);
-                }
+                const int q = t * 64 + nt * 16 + g * 4 + r;
+                const bool valid = key_live & (q < (int)p.Sq);
+                bool msk;
+                const float s = score_of<AM>(p, x[nt][r], my_kb, q, (int)my_k, slope, am_base, msk);
+                const float pr = valid ? __expf(s - mm[r]) * il[r] : 0.f;
                 x[nt][r] = pr;
-                y[nt][r] = ds;
+                y[nt][r] = (valid & !msk) ? pr * (y[nt][r] - dl[r]) : 0.f;
             }
         }
         contract64<T, HDP>(dv, Gt, x, lane);                                 // dV^T[d][my_k] += sum_q dO[q][d] P[q][my_k]
@@ -432,7 +444,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnP p) {
 
 // ------------------------------------------------------------------------------------------------ backward: dQ
 // own rows = queries.  Per key tile: S^T = K Q^T, dP^T = V dO^T, dS^T = P^T (dP^T - delta); dQ^T += K^T dS^T.
-template <typename T, int HDP>
+template <typename T, int HDP, bool AM>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
     using A = AT<T, HDP>;
     constexpr int MK = Mma<T>::K, KL = Mma<T>::KL, NKK = HDP / MK, NDT = HDP / 16;
@@ -464,6 +476,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
     const float m = live ? p.stat_m[srow] : 0.f;
     const float il = live ? 1.0f / p.stat_l[srow] : 0.f;
     const float dl = live ? p.delta[srow] : 0.f;
+    const float* am_base = AM ? p.add_mask + b * p.am_b + h * p.am_h : nullptr;
+    const int q_eff = live ? (int)my_q : 0;
 
     int64_t kv_end = p.Sk;
     if (p.causal) { kv_end = min(p.Sk, q0 + 63 + p.off + 1); if (kv_end < 1) kv_end = 1; }   // masked entries have dS = 0
@@ -492,20 +506,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
         f32x4 x[4], y[4];
         dot_tile<T, HDP>(x, Ks, qf, lane);
         dot_tile<T, HDP>(y, Vs, gf, lane);
-        const int64_t kv0 = (int64_t)t * 64;
+        const int kv0 = t * 64;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const f32x4 kb4 = *reinterpret_cast<const f32x4*>(kbs + nt * 16 + g * 4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int64_t key = kv0 + nt * 16 + g * 4 + r;
-                float ds = 0.f;
-                if (live && kb4[r] > -1.5f) {
-                    bool msk;
-                    const float s = score_of(p, x[nt][r], kb4[r], b, h, my_q, key, slope, msk);
-                    ds = msk ? 0.f : __expf(s - m) * il * (y[nt][r] - dl);
-                }
-                y[nt][r] = ds;
+                bool msk;
+                const float s = score_of<AM>(p, x[nt][r], kb4[r], q_eff, kv0 + nt * 16 + g * 4 + r, slope, am_base, msk);
+                const bool use = live & (kb4[r] > -1.5f) & !msk;
+                y[nt][r] = use ? __expf(s - m) * il * (y[nt][r] - dl) : 0.f;
             }
         }
         contract64<T, HDP>(dq, Kt, y, lane);                                 // dQ^T[d][my_q] += sum_key K[key][d] dS[my_q][key]
@@ -543,14 +553,19 @@ static int fill_params(AttnP& p, const ctmi_attn_desc* d, int dtype, const char*
     return CTMI_OK;
 }
 
+template <typename K>
+static void launch_k(K kern, int64_t grid, size_t lds, hipStream_t st, AttnP& p) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, p);
+}
+
 template <typename T, int HDP>
 static int fwd_launch(AttnP& p, hipStream_t st) {
     using A = AT<T, HDP>;
     const size_t lds = (size_t)(A::RM_ELEMS + A::TR_ELEMS) * sizeof(T) + 64 * sizeof(float);
-    auto kern = &attn_fwd_kernel<T, HDP>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int64_t grid = ((p.Sq + 63) / 64) * p.B * p.nh;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, p);
+    if (p.add_mask) launch_k(&attn_fwd_kernel<T, HDP, true>, grid, lds, st, p);
+    else launch_k(&attn_fwd_kernel<T, HDP, false>, grid, lds, st, p);
     CTMI_CHECK_LAUNCH("attn_fwd");
     return CTMI_OK;
 }
@@ -564,18 +579,16 @@ static int bwd_launch(AttnP& p, hipStream_t st) {
     }
     {
         const size_t lds = (size_t)(2 * A::RM_ELEMS + 2 * A::TR_ELEMS) * sizeof(T) + 192 * sizeof(float);
-        auto kern = &attn_bwd_dkdv_kernel<T, HDP>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         const int64_t grid = ((p.Sk + 63) / 64) * p.B * p.nh;
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, p);
+        if (p.add_mask) launch_k(&attn_bwd_dkdv_kernel<T, HDP, true>, grid, lds, st, p);
+        else launch_k(&attn_bwd_dkdv_kernel<T, HDP, false>, grid, lds, st, p);
         CTMI_CHECK_LAUNCH("attn_bwd_dkdv");
     }
     {
         const size_t lds = (size_t)(2 * A::RM_ELEMS + A::TR_ELEMS) * sizeof(T) + 64 * sizeof(float);
-        auto kern = &attn_bwd_dq_kernel<T, HDP>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         const int64_t grid = ((p.Sq + 63) / 64) * p.B * p.nh;
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, p);
+        if (p.add_mask) launch_k(&attn_bwd_dq_kernel<T, HDP, true>, grid, lds, st, p);
+        else launch_k(&attn_bwd_dq_kernel<T, HDP, false>, grid, lds, st, p);
         CTMI_CHECK_LAUNCH("attn_bwd_dq");
     }
     return CTMI_OK;

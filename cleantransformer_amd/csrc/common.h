@@ -22,13 +22,14 @@ void ctmi_set_error(const char* fmt, ...);
 
 // ---------------------------------------------------------------- scalar conversions
 __device__ __forceinline__ float bf2f(bf16_t x) { return __uint_as_float(((uint32_t)x) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {           // round-to-nearest-even, NaN-preserving
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// fp32 -> bf16, round-to-nearest-even: the native conversion, which hipcc lowers to gfx950's v_cvt_pk_bf16_f32
+typedef __bf16 bf16x2_native __attribute__((ext_vector_type(2)));
+typedef float f32x2_native __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    const f32x2_native v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_native));
 }
-__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
 
 template <typename T> struct Cvt;
 template <> struct Cvt<float>  { static __device__ __forceinline__ float to_f(float x) { return x; }
@@ -70,11 +71,17 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---------------------------------------------------------------- math
+// tanh via one v_exp_f32 + one reciprocal: tanh(|a|) = (1 - e) / (1 + e), e = exp(-2|a|)  (abs error ~1e-7; the libm
+// tanhf is ~40 instructions and doubled the time of the GELU-epilogue GEMMs)
+__device__ __forceinline__ float fast_tanh(float a) {
+    const float e = __expf(-2.0f * fabsf(a));
+    return copysignf(__fdividef(1.0f - e, 1.0f + e), a);
+}
 __device__ __forceinline__ float gelu_tanh_f(float x) {            // modeling_bloom.py:344
-    return x * 0.5f * (1.0f + tanhf(0.79788456f * x * (1.0f + 0.044715f * x * x)));
+    return x * 0.5f * (1.0f + fast_tanh(0.79788456f * x * (1.0f + 0.044715f * x * x)));
 }
 __device__ __forceinline__ float gelu_tanh_grad_f(float x) {       // modeling_bloom.py:360-362
-    float t = tanhf(0.79788456f * x * (1.0f + 0.044715f * x * x));
+    float t = fast_tanh(0.79788456f * x * (1.0f + 0.044715f * x * x));
     return 0.5f * x * ((1.0f - t * t) * (0.79788456f + 0.1070322243f * x * x)) + 0.5f * (1.0f + t);
 }
 
