@@ -203,14 +203,23 @@ __device__ __forceinline__ void store_own_row(T* rowp, const f32x4 (&acc)[HDP / 
 }
 
 // ------------------------------------------------------------------------------------------------ forward
+// LDS stage sizes (bytes) and buffering depth: two stages (one barrier per tile) whenever they fit in 160 KiB with room
+// for >= 2 workgroups per CU, else one stage (two barriers per tile).
+template <typename T, int HDP> struct FwdStage { static constexpr int BYTES = (AT<T, HDP>::RM_ELEMS + AT<T, HDP>::TR_ELEMS) * (int)sizeof(T) + 256; };
+template <typename T, int HDP> struct DkdvStage { static constexpr int BYTES = (2 * AT<T, HDP>::RM_ELEMS + 2 * AT<T, HDP>::TR_ELEMS) * (int)sizeof(T) + 768; };
+template <typename T, int HDP> struct DqStage { static constexpr int BYTES = (2 * AT<T, HDP>::RM_ELEMS + AT<T, HDP>::TR_ELEMS) * (int)sizeof(T) + 256; };
+constexpr int nbuf_for(int stage_bytes) { return 2 * stage_bytes <= 80 * 1024 ? 2 : 1; }
+
 template <typename T, int HDP, bool AM>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
     using A = AT<T, HDP>;
     constexpr int MK = Mma<T>::K, KL = Mma<T>::KL, NKK = HDP / MK, NDT = HDP / 16;
+    constexpr int STAGE = FwdStage<T, HDP>::BYTES, NBUF = nbuf_for(STAGE);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* Ks = reinterpret_cast<T*>(smem_raw);
-    T* Vt = Ks + A::RM_ELEMS;
-    float* kbs = reinterpret_cast<float*>(Vt + A::TR_ELEMS);                 // [64] per-key digest of the staged tile
+    int cur = 0;
+    auto KS = [&](int s_) { return reinterpret_cast<T*>(smem_raw + s_ * STAGE); };
+    auto VT = [&](int s_) { return KS(s_) + A::RM_ELEMS; };
+    auto KB = [&](int s_) { return reinterpret_cast<float*>(VT(s_) + A::TR_ELEMS); };   // [64] per-key digest of the staged tile
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, li = lane & 15;
     const bool fast = p.vec_ok && p.hd == HDP;
     const int nqb = (int)((p.Sq + 63) / 64);
@@ -246,9 +255,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
     A::load(rk, kp, p.k_rs, 0, p.Sk, (int)p.hd, fast, tid);
     A::load(rv, vp, p.v_rs, 0, p.Sk, (int)p.hd, fast, tid);
     if (tid < 64) rkb = key_digest(p, b, tid);
-    A::store_rm(rk, Ks, tid);
-    A::store_tr(rv, Vt, tid);
-    if (tid < 64) kbs[tid] = rkb;
+    A::store_rm(rk, KS(0), tid);
+    A::store_tr(rv, VT(0), tid);
+    if (tid < 64) KB(0)[tid] = rkb;
     __syncthreads();
     const int q_eff = my_q < p.Sq ? (int)my_q : 0;
     const float* am_base = AM ? p.add_mask + b * p.am_b + h * p.am_h : nullptr;
@@ -260,7 +269,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
             if (tid < 64) rkb = key_digest(p, b, (int64_t)(t + 1) * 64 + tid);
         }
         f32x4 x[4];
-        dot_tile<T, HDP>(x, Ks, qf, lane);                                   // x[nt][r] = q . k[key]
+        const float* kbs = KB(cur);
+        dot_tile<T, HDP>(x, KS(cur), qf, lane);                              // x[nt][r] = q . k[key]
         const int kv0 = t * 64;
         float mx = -INFINITY;
 #pragma unroll
@@ -292,14 +302,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
         m = m_new;
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) acc[dt] *= alpha;
-        contract64<T, HDP>(acc, Vt, x, lane);                               // acc[dt][r] = O^T[d][my_q]
-        __syncthreads();
+        contract64<T, HDP>(acc, VT(cur), x, lane);                          // acc[dt][r] = O^T[d][my_q]
+        if (NBUF == 1) __syncthreads();
         if (t + 1 < ntiles) {
-            A::store_rm(rk, Ks, tid);
-            A::store_tr(rv, Vt, tid);
-            if (tid < 64) kbs[tid] = rkb;
-            __syncthreads();
+            const int nx = NBUF == 2 ? cur ^ 1 : 0;
+            A::store_rm(rk, KS(nx), tid);
+            A::store_tr(rv, VT(nx), tid);
+            if (tid < 64) KB(nx)[tid] = rkb;
+            cur = nx;
         }
+        __syncthreads();
     }
     lsum += __shfl_xor(lsum, 16, 64);
     lsum += __shfl_xor(lsum, 32, 64);
@@ -334,15 +346,17 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnP p) {
 // own rows = keys.  Per query tile: S = Q K^T and dP = dO V^T (own key in the accumulator column), P = exp(S-m)/l,
 // dS = P (dP - delta); dV^T += dO^T P, dK^T += Q^T dS  (Q, dO staged both row-major and transposed).
 template <typename T, int HDP, bool AM>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnP p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
     using A = AT<T, HDP>;
     constexpr int MK = Mma<T>::K, KL = Mma<T>::KL, NKK = HDP / MK, NDT = HDP / 16;
+    constexpr int STAGE = DkdvStage<T, HDP>::BYTES, NBUF = nbuf_for(STAGE);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* Qs = reinterpret_cast<T*>(smem_raw);
-    T* Qt = Qs + A::RM_ELEMS;
-    T* Gs = Qt + A::TR_ELEMS;
-    T* Gt = Gs + A::RM_ELEMS;
-    float* st = reinterpret_cast<float*>(Gt + A::TR_ELEMS);                  // [3][64]: m, 1/l, delta
+    int cur = 0;
+    auto QS = [&](int s_) { return reinterpret_cast<T*>(smem_raw + s_ * STAGE); };
+    auto QT = [&](int s_) { return QS(s_) + A::RM_ELEMS; };
+    auto GS = [&](int s_) { return QT(s_) + A::TR_ELEMS; };
+    auto GT = [&](int s_) { return GS(s_) + A::RM_ELEMS; };
+    auto ST = [&](int s_) { return reinterpret_cast<float*>(GT(s_) + A::TR_ELEMS); };   // [3][64]: m, 1/l, delta
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, li = lane & 15;
     const bool fast = p.vec_ok && p.hd == HDP;
     const int nkb = (int)((p.Sk + 63) / 64);
@@ -393,9 +407,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnP p) {
         A::load(rq, qp, p.q_rs, (int64_t)qt_begin * 64, p.Sq, (int)p.hd, fast, tid);
         A::load(rg, gp, p.o_rs, (int64_t)qt_begin * 64, p.Sq, (int)p.hd, fast, tid);
         load_stats(qt_begin);
-        A::store_rm(rq, Qs, tid); A::store_tr(rq, Qt, tid);
-        A::store_rm(rg, Gs, tid); A::store_tr(rg, Gt, tid);
-        if (tid < 192) st[tid] = rstat;
+        A::store_rm(rq, QS(0), tid); A::store_tr(rq, QT(0), tid);
+        A::store_rm(rg, GS(0), tid); A::store_tr(rg, GT(0), tid);
+        if (tid < 192) ST(0)[tid] = rstat;
     }
     __syncthreads();
 
@@ -406,8 +420,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnP p) {
             load_stats(t + 1);
         }
         f32x4 x[4], y[4];
-        dot_tile<T, HDP>(x, Qs, kf, lane);                                   // x[nt][r] = q[qi] . k[my_k]
-        dot_tile<T, HDP>(y, Gs, vf, lane);                                   // y[nt][r] = dO[qi] . v[my_k]
+        const float* st = ST(cur);
+        dot_tile<T, HDP>(x, QS(cur), kf, lane);                              // x[nt][r] = q[qi] . k[my_k]
+        dot_tile<T, HDP>(y, GS(cur), vf, lane);                              // y[nt][r] = dO[qi] . v[my_k]
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const f32x4 mm = *reinterpret_cast<const f32x4*>(st + nt * 16 + g * 4);
@@ -424,15 +439,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnP p) {
                 y[nt][r] = (valid & !msk) ? pr * (y[nt][r] - dl[r]) : 0.f;
             }
         }
-        contract64<T, HDP>(dv, Gt, x, lane);                                 // dV^T[d][my_k] += sum_q dO[q][d] P[q][my_k]
-        contract64<T, HDP>(dk, Qt, y, lane);                                 // dK^T[d][my_k] += sum_q Q[q][d] dS[q][my_k]
-        __syncthreads();
+        contract64<T, HDP>(dv, GT(cur), x, lane);                            // dV^T[d][my_k] += sum_q dO[q][d] P[q][my_k]
+        contract64<T, HDP>(dk, QT(cur), y, lane);                            // dK^T[d][my_k] += sum_q Q[q][d] dS[q][my_k]
+        if (NBUF == 1) __syncthreads();
         if (t + 1 < qt_end) {
-            A::store_rm(rq, Qs, tid); A::store_tr(rq, Qt, tid);
-            A::store_rm(rg, Gs, tid); A::store_tr(rg, Gt, tid);
-            if (tid < 192) st[tid] = rstat;
-            __syncthreads();
+            const int nx = NBUF == 2 ? cur ^ 1 : 0;
+            A::store_rm(rq, QS(nx), tid); A::store_tr(rq, QT(nx), tid);
+            A::store_rm(rg, GS(nx), tid); A::store_tr(rg, GT(nx), tid);
+            if (tid < 192) ST(nx)[tid] = rstat;
+            cur = nx;
         }
+        __syncthreads();
     }
     if (my_k < p.Sk) {
         T* dkp = reinterpret_cast<T*>(p.dk) + b * p.k_bs + h * p.k_hs + my_k * p.k_rs;
@@ -445,14 +462,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnP p) {
 // ------------------------------------------------------------------------------------------------ backward: dQ
 // own rows = queries.  Per key tile: S^T = K Q^T, dP^T = V dO^T, dS^T = P^T (dP^T - delta); dQ^T += K^T dS^T.
 template <typename T, int HDP, bool AM>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
     using A = AT<T, HDP>;
     constexpr int MK = Mma<T>::K, KL = Mma<T>::KL, NKK = HDP / MK, NDT = HDP / 16;
+    constexpr int STAGE = DqStage<T, HDP>::BYTES, NBUF = nbuf_for(STAGE);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* Ks = reinterpret_cast<T*>(smem_raw);
-    T* Kt = Ks + A::RM_ELEMS;
-    T* Vs = Kt + A::TR_ELEMS;
-    float* kbs = reinterpret_cast<float*>(Vs + A::RM_ELEMS);
+    int cur = 0;
+    auto KS = [&](int s_) { return reinterpret_cast<T*>(smem_raw + s_ * STAGE); };
+    auto KT = [&](int s_) { return KS(s_) + A::RM_ELEMS; };
+    auto VS = [&](int s_) { return KT(s_) + A::TR_ELEMS; };
+    auto KB = [&](int s_) { return reinterpret_cast<float*>(VS(s_) + A::RM_ELEMS); };
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, li = lane & 15;
     const bool fast = p.vec_ok && p.hd == HDP;
     const int nqb = (int)((p.Sq + 63) / 64);
@@ -492,9 +511,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
     A::load(rk, kp, p.k_rs, 0, p.Sk, (int)p.hd, fast, tid);
     A::load(rv, vp, p.v_rs, 0, p.Sk, (int)p.hd, fast, tid);
     if (tid < 64) rkb = key_digest(p, b, tid);
-    A::store_rm(rk, Ks, tid); A::store_tr(rk, Kt, tid);
-    A::store_rm(rv, Vs, tid);
-    if (tid < 64) kbs[tid] = rkb;
+    A::store_rm(rk, KS(0), tid); A::store_tr(rk, KT(0), tid);
+    A::store_rm(rv, VS(0), tid);
+    if (tid < 64) KB(0)[tid] = rkb;
     __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
@@ -504,8 +523,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
             if (tid < 64) rkb = key_digest(p, b, (int64_t)(t + 1) * 64 + tid);
         }
         f32x4 x[4], y[4];
-        dot_tile<T, HDP>(x, Ks, qf, lane);
-        dot_tile<T, HDP>(y, Vs, gf, lane);
+        const float* kbs = KB(cur);
+        dot_tile<T, HDP>(x, KS(cur), qf, lane);
+        dot_tile<T, HDP>(y, VS(cur), gf, lane);
         const int kv0 = t * 64;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
@@ -518,14 +538,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
                 y[nt][r] = use ? __expf(s - m) * il * (y[nt][r] - dl) : 0.f;
             }
         }
-        contract64<T, HDP>(dq, Kt, y, lane);                                 // dQ^T[d][my_q] += sum_key K[key][d] dS[my_q][key]
-        __syncthreads();
+        contract64<T, HDP>(dq, KT(cur), y, lane);                            // dQ^T[d][my_q] += sum_key K[key][d] dS[my_q][key]
+        if (NBUF == 1) __syncthreads();
         if (t + 1 < ntiles) {
-            A::store_rm(rk, Ks, tid); A::store_tr(rk, Kt, tid);
-            A::store_rm(rv, Vs, tid);
-            if (tid < 64) kbs[tid] = rkb;
-            __syncthreads();
+            const int nx = NBUF == 2 ? cur ^ 1 : 0;
+            A::store_rm(rk, KS(nx), tid); A::store_tr(rk, KT(nx), tid);
+            A::store_rm(rv, VS(nx), tid);
+            if (tid < 64) KB(nx)[tid] = rkb;
+            cur = nx;
         }
+        __syncthreads();
     }
     if (live) {
         T* dqp = reinterpret_cast<T*>(p.dq) + b * p.q_bs + h * p.q_hs + my_q * p.q_rs;
@@ -562,7 +584,7 @@ static void launch_k(K kern, int64_t grid, size_t lds, hipStream_t st, AttnP& p)
 template <typename T, int HDP>
 static int fwd_launch(AttnP& p, hipStream_t st) {
     using A = AT<T, HDP>;
-    const size_t lds = (size_t)(A::RM_ELEMS + A::TR_ELEMS) * sizeof(T) + 64 * sizeof(float);
+    const size_t lds = (size_t)FwdStage<T, HDP>::BYTES * nbuf_for(FwdStage<T, HDP>::BYTES);
     const int64_t grid = ((p.Sq + 63) / 64) * p.B * p.nh;
     if (p.add_mask) launch_k(&attn_fwd_kernel<T, HDP, true>, grid, lds, st, p);
     else launch_k(&attn_fwd_kernel<T, HDP, false>, grid, lds, st, p);
@@ -578,14 +600,14 @@ static int bwd_launch(AttnP& p, hipStream_t st) {
         CTMI_CHECK_LAUNCH("attn_delta");
     }
     {
-        const size_t lds = (size_t)(2 * A::RM_ELEMS + 2 * A::TR_ELEMS) * sizeof(T) + 192 * sizeof(float);
+        const size_t lds = (size_t)DkdvStage<T, HDP>::BYTES * nbuf_for(DkdvStage<T, HDP>::BYTES);
         const int64_t grid = ((p.Sk + 63) / 64) * p.B * p.nh;
         if (p.add_mask) launch_k(&attn_bwd_dkdv_kernel<T, HDP, true>, grid, lds, st, p);
         else launch_k(&attn_bwd_dkdv_kernel<T, HDP, false>, grid, lds, st, p);
         CTMI_CHECK_LAUNCH("attn_bwd_dkdv");
     }
     {
-        const size_t lds = (size_t)(2 * A::RM_ELEMS + A::TR_ELEMS) * sizeof(T) + 64 * sizeof(float);
+        const size_t lds = (size_t)DqStage<T, HDP>::BYTES * nbuf_for(DqStage<T, HDP>::BYTES);
         const int64_t grid = ((p.Sq + 63) / 64) * p.B * p.nh;
         if (p.add_mask) launch_k(&attn_bwd_dq_kernel<T, HDP, true>, grid, lds, st, p);
         else launch_k(&attn_bwd_dq_kernel<T, HDP, false>, grid, lds, st, p);
