@@ -314,6 +314,231 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
 }
 
+// =================================================================================================================
+// bf16 fast path v2: LDS-DMA staging (global_load_lds_dwordx4), 3-stage ring, big wave tiles.
+//   * workgroup = 4 waves (2x2) on a (WM*32) x 128 output tile; each wave (WM*16) x 64 -> WM x 4 accumulators.
+//     WM = 8 (256x128) halves the LDS fragment traffic per MFMA of the 128x128 tile; WM = 4 serves small problems.
+//   * BK = 32 (one MFMA K-step per stage).  A stage is the raw tile, UNPADDED, written by the LDS-DMA engine: each
+//     wave-instruction drops 64 x 16 B = 1 KiB at a wave-uniform LDS base (M0) + lane*16, so the LDS image is linear
+//     in the order of the lanes; bank conflicts are removed by permuting which 16-byte GLOBAL chunk each lane fetches
+//     (XOR swizzle on the source address) and applying the same permutation when fragments are read.
+//   * no VGPR staging, no ds_write: the LDS write port (79 B/clk for ds_write_b128) was the v1 bottleneck.
+//   * 3 stages in flight: loads of tile t+2 are issued right after the barrier that retires tile t-1; each wave
+//     waits only for its own oldest tile with a counted s_waitcnt vmcnt(N) (never 0 in steady state) and one
+//     s_barrier per K-step orders LDS-DMA writes against the other waves' reads.  The DMA instructions are inline
+//     asm, so hipcc neither counts nor drains them.
+// Requires: bf16, 16-byte aligned operands, K % 32 == 0 (per split).  Anything else takes the v1 kernel above.
+__device__ __forceinline__ void glds16(const bf16_t* gsrc, unsigned lds_dst /* wave-uniform LDS byte address */) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ int swz4(int key) { return (0x78 >> (2 * key)) & 3; }          // {0,2,3,1}: see GTile<false>
+__device__ __forceinline__ int kkey(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+
+template <bool KMAJOR, int ROWS>
+struct GTile {
+    static constexpr int BK = 32;
+    static constexpr int BYTES = ROWS * BK * 2;
+    static constexpr int NINSTR = BYTES / 1024;             // 1-KiB wave-instructions per stage
+    static constexpr int PER_WAVE = NINSTR / 4;
+    static constexpr int CPR = ROWS / 8;                    // KMAJOR: 16-byte chunks per k-row
+    static constexpr int ROWB = ROWS * 2;                   // KMAJOR: bytes per k-row
+
+    // global source of LDS 16-byte slot P of the stage (k offset NOT included).
+    //  !KMAJOR image: [row][4 chunks of 8 k] (64 B per row).  slot (row, c') holds global chunk c' ^ swz4((row>>2)&3):
+    //   a ds_read_b128 lane group (16 rows x one k-chunk, in the hardware's 4+4+8 lane grouping) then covers all 16
+    //   16-byte slots of the 256-byte bank row exactly once.
+    //  KMAJOR image: [k][ROWS] (rows contiguous).  32-byte blocks of a k-row are XOR-ed with kkey(k) (3 bits), so the
+    //   8 k-rows touched by one half-wave of ds_read_b64_tr_b16 land in 8 different 32-byte bank groups.
+    static __device__ __forceinline__ const bf16_t* src(const bf16_t* __restrict__ g, int64_t ld, int64_t row0, int64_t row_lim, int P) {
+        if (!KMAJOR) {
+            const int row = P >> 2, cp = P & 3;
+            const int c = cp ^ swz4((row >> 2) & 3);
+            const int64_t grow = min(row0 + row, row_lim - 1);
+            return g + grow * ld + c * 8;
+        } else {
+            const int k = P / CPR, cp = P % CPR;
+            const int b32p = cp >> 1;
+            const int b32 = (b32p & ~7) | ((b32p ^ kkey(k)) & 7);
+            const int64_t col = row0 + (((b32 << 1) | (cp & 1)) * 8);
+            return g + (int64_t)k * ld + (col < row_lim ? col : 0);
+        }
+    }
+    static __device__ __forceinline__ short8 frag(const unsigned char* __restrict__ tile, int r16, int lane) {
+        const int i = lane & 15, g = lane >> 4;
+        if (!KMAJOR) {
+            const int r = r16 + i;
+            const int cpp = g ^ swz4((r >> 2) & 3);
+            return *reinterpret_cast<const short8*>(tile + r * 64 + cpp * 16);
+        } else {
+            const int k = g * 8 + (i >> 2);
+            const int b32 = r16 >> 4;
+            const int b32s = (b32 & ~7) | ((b32 ^ kkey(k)) & 7);
+            const bf16_t* p = reinterpret_cast<const bf16_t*>(tile + k * ROWB + b32s * 32 + 8 * (i & 3));
+            const uint2 lo = lds_read_tr_b16(p);
+            const uint2 hi = lds_read_tr_b16(p + 4 * ROWS);                 // kkey(k+4) == kkey(k)
+            return __builtin_bit_cast(short8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+        }
+    }
+};
+
+template <typename TO, bool AK, bool BKM, int EPI, int WM>
+__global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs g) {
+    using T = bf16_t;
+    constexpr int BM = WM * 32, BN = 128, BK = 32, NST = 3;
+    using TA = GTile<AK, BM>;
+    using TB = GTile<BKM, BN>;
+    constexpr int STAGE = TA::BYTES + TB::BYTES;
+    constexpr int LOADS = TA::PER_WAVE + TB::PER_WAVE;                      // DMA instructions per wave per stage
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+
+    const int tiles_m = (int)((g.M + BM - 1) / BM);
+    const int ntile = tiles_m * g.tiles_n;
+    const int nblk = ntile * g.splits;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nblk >> 3, r8 = nblk & 7;
+    const int vid_all = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    const int split = vid_all / ntile, vid = vid_all - split * ntile;
+    constexpr int GM = (WM == 8) ? 4 : 8;
+    const int group = vid / (GM * g.tiles_n), first_m = group * GM;
+    const int gm = min(GM, tiles_m - first_m);
+    const int in_group = vid - group * GM * g.tiles_n;
+    const int tm = first_m + in_group % gm, tn = in_group / gm;
+    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+    const int64_t kbeg = (int64_t)split * g.k_per_split;
+    const int64_t kend = min(g.K, kbeg + g.k_per_split);
+    const int nt = (int)((kend - kbeg) / BK);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1;
+    const T* A = reinterpret_cast<const T*>(g.A);
+    const T* B = reinterpret_cast<const T*>(g.B);
+
+    const T* pa[TA::PER_WAVE];
+    const T* pb[TB::PER_WAVE];
+#pragma unroll
+    for (int j = 0; j < TA::PER_WAVE; ++j) pa[j] = TA::src(A, g.lda, m0, g.M, (wid * TA::PER_WAVE + j) * 64 + lane) + (AK ? kbeg * g.lda : kbeg);
+#pragma unroll
+    for (int j = 0; j < TB::PER_WAVE; ++j) pb[j] = TB::src(B, g.ldb, n0, g.N, (wid * TB::PER_WAVE + j) * 64 + lane) + (BKM ? kbeg * g.ldb : kbeg);
+    const int64_t astep = AK ? (int64_t)BK * g.lda : BK, bstep = BKM ? (int64_t)BK * g.ldb : BK;
+    const unsigned lds0 = (unsigned)(size_t)smem_raw;
+
+    auto issue = [&](int stage_buf) {                                         // loads the NEXT tile (pointers advance)
+        const unsigned base = lds0 + stage_buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < TA::PER_WAVE; ++j) { glds16(pa[j], base + (wid * TA::PER_WAVE + j) * 1024); pa[j] += astep; }
+#pragma unroll
+        for (int j = 0; j < TB::PER_WAVE; ++j) { glds16(pb[j], base + TA::BYTES + (wid * TB::PER_WAVE + j) * 1024); pb[j] += bstep; }
+    };
+
+    f32x4 acc[WM][4];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    issue(0);
+    if (nt > 1) issue(1);
+    int rd = 0, wrb = 2;                                                      // ring positions: read stage, next write stage
+    for (int t = 0; t < nt; ++t) {
+        // my own DMA of tile t has landed once at most the LOADS of tile t+1 are still outstanding
+        if (t + 1 < nt) { if (LOADS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                         // everyone's tile t landed; tile t-1 fully consumed
+        if (t + 2 < nt) issue(wrb);
+        const unsigned char* as = smem_raw + rd * STAGE;
+        const unsigned char* bs = as + TA::BYTES;
+        short8 af[WM], bf[4];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) af[i] = TA::frag(as, wr * (WM * 16) + i * 16, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[j] = TB::frag(bs, wc * 64 + j * 16, lane);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(bf[j], af[i], acc[i][j]);
+        rd = rd == NST - 1 ? 0 : rd + 1;
+        wrb = wrb == NST - 1 ? 0 : wrb + 1;
+    }
+
+    // epilogue (same contract as v1): lane holds C[m][n..n+3], m = m0+wr*WM*16+i*16+(lane&15), n = n0+wc*64+j*16+(lane>>4)*4
+    if (g.splits > 1) {
+        float* S = g.slabs + (int64_t)split * g.M * g.N;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            const int64_t m = m0 + wr * (WM * 16) + i * 16 + (lane & 15);
+            if (m >= g.M) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t n = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+                if (n >= g.N) continue;
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if (n + 4 <= g.N && (g.N & 3) == 0) store4<float>(S + m * g.N + n, v);
+                else { for (int r = 0; r < 4; ++r) if (n + r < g.N) S[m * g.N + n + r] = v[r]; }
+            }
+        }
+        return;
+    }
+    TO* C = reinterpret_cast<TO*>(g.C);
+    const T* R = reinterpret_cast<const T*>(g.residual);
+    const T* AUXI = reinterpret_cast<const T*>(g.aux_in);
+    T* AUXO = reinterpret_cast<T*>(g.aux_out);
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        const int64_t m = m0 + wr * (WM * 16) + i * 16 + (lane & 15);
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t n = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+            if (n >= g.N) continue;
+            const bool full = (n + 4 <= g.N) && g.vec_c;
+            const int64_t off = m * g.ldc + n;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = g.alpha * acc[i][j][r];
+            if (g.bias != nullptr) {
+                if (full) { const float4 bb = *reinterpret_cast<const float4*>(g.bias + n); v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
+                else { for (int r = 0; r < 4; ++r) if (n + r < g.N) v[r] += g.bias[n + r]; }
+            }
+            if (EPI == CTMI_EPI_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = Cvt<T>::to_f(Cvt<T>::from_f(v[r]));
+                if (full) store4<T>(AUXO + off, v);
+                else { for (int r = 0; r < 4; ++r) if (n + r < g.N) AUXO[off + r] = Cvt<T>::from_f(v[r]); }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(v[r]);
+            } else if (EPI == CTMI_EPI_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            } else if (EPI == CTMI_EPI_DGELU || EPI == CTMI_EPI_DRELU) {
+                float u[4] = {0.f, 0.f, 0.f, 0.f};
+                if (full) load4<T>(AUXI + off, u);
+                else { for (int r = 0; r < 4; ++r) if (n + r < g.N) u[r] = Cvt<T>::to_f(AUXI[off + r]); }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (EPI == CTMI_EPI_DGELU) ? v[r] * gelu_tanh_grad_f(u[r]) : (u[r] > 0.f ? v[r] : 0.f);
+            }
+            if (R != nullptr) {
+                float u[4] = {0.f, 0.f, 0.f, 0.f};
+                if (full) load4<T>(R + off, u);
+                else { for (int r = 0; r < 4; ++r) if (n + r < g.N) u[r] = Cvt<T>::to_f(R[off + r]); }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += u[r];
+            }
+            if (g.beta) {
+                float u[4] = {0.f, 0.f, 0.f, 0.f};
+                if (full) load4<TO>(C + off, u);
+                else { for (int r = 0; r < 4; ++r) if (n + r < g.N) u[r] = Cvt<TO>::to_f(C[off + r]); }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += u[r];
+            }
+            if (full) store4<TO>(C + off, v);
+            else { for (int r = 0; r < 4; ++r) if (n + r < g.N) C[off + r] = Cvt<TO>::from_f(v[r]); }
+        }
+    }
+}
+
 // C[m,n] = alpha * sum_s slabs[s][m][n] (+ C_old)   — deterministic split-K reduction
 template <typename TO>
 __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ slabs, TO* __restrict__ C, int64_t ldc,
@@ -329,12 +554,43 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ s
     }
 }
 
+template <typename TO, bool AK, bool BKM, int EPI, int WM>
+static void glds_launch(GemmArgs& g, hipStream_t st) {
+    constexpr int BM = WM * 32;
+    const size_t lds = 3 * (size_t)(GTile<AK, BM>::BYTES + GTile<BKM, 128>::BYTES);
+    const unsigned grid = (unsigned)(cdiv64(g.M, BM) * g.tiles_n * g.splits);
+    auto kern = &gemm_glds_kernel<TO, AK, BKM, EPI, WM>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, g);
+}
+
+static bool glds_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("CTMI_GEMM_GLDS"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v == 1;
+}
+
 template <typename T, typename TO, bool AK, bool BKM, int EPI>
 static int gemm_launch(GemmArgs& g, bool fast, hipStream_t st) {
     using TA = OpTile<T, AK, Tile<T>::BM>;
     using TB = OpTile<T, BKM, Tile<T>::BN>;
     const size_t lds = 2 * (size_t)(TA::ELEMS + TB::ELEMS) * sizeof(T);
     const unsigned grid = (unsigned)(g.tiles_m * g.tiles_n * g.splits);
+    if constexpr (sizeof(T) == 2) {
+        if (fast && glds_enabled() && g.K % 32 == 0 && g.k_per_split % 32 == 0) {
+            // 256x128 tiles when they still fill the chip (>= ~1.5 blocks per CU), else 128x128
+            const int64_t big = cdiv64(g.M, 256) * g.tiles_n * g.splits;
+            if (big >= 400) glds_launch<TO, AK, BKM, EPI, 8>(g, st); else glds_launch<TO, AK, BKM, EPI, 4>(g, st);
+            CTMI_CHECK_LAUNCH("gemm_glds");
+            if (g.splits > 1) {
+                const int64_t total = g.M * g.N;
+                const unsigned rg = (unsigned)std::min<int64_t>(cdiv64(total, 256), 4096);
+                hipLaunchKernelGGL((splitk_reduce<TO>), dim3(rg), dim3(256), 0, st, g.slabs, reinterpret_cast<TO*>(g.C), g.ldc, g.M, g.N, g.splits, g.alpha, g.beta);
+                CTMI_CHECK_LAUNCH("gemm_splitk_reduce");
+            }
+            return CTMI_OK;
+        }
+    }
     if (fast) {
         auto kern = &gemm_kernel<T, TO, AK, BKM, EPI, true>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

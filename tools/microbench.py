@@ -35,7 +35,10 @@ def rnd(*s, dtype=BF):
 def bench_gemm(T=8192):
     H, V = 1024, 250880
     print(f"--- GEMM bf16, T={T}")
+    only = os.environ.get("MB_ONLY")
     for name, N, K in (("qkv", 3 * H, H), ("dense", H, H), ("h4h", 4 * H, H), ("4hh", H, 4 * H), ("lm_head", V, H)):
+        if only and name not in only.split(","):
+            continue
         x, w, dy = rnd(T, K), rnd(N, K), rnd(T, N)
         fl = 2.0 * T * N * K
         it = 3 if N == V else 10
