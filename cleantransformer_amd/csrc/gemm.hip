@@ -425,12 +425,15 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs g) {
     const int64_t astep = AK ? (int64_t)BK * g.lda : BK, bstep = BKM ? (int64_t)BK * g.ldb : BK;
     const unsigned lds0 = (unsigned)(size_t)smem_raw;
 
-    auto issue = [&](int stage_buf) {                                         // loads the NEXT tile (pointers advance)
+    // one DMA piece (j-th of this wave's LOADS per stage) of the NEXT tile; pointers advance
+    auto issue_one = [&](int stage_buf, int j) {
         const unsigned base = lds0 + stage_buf * STAGE;
+        if (j < TA::PER_WAVE) { glds16(pa[j], base + (wid * TA::PER_WAVE + j) * 1024); pa[j] += astep; }
+        else { const int jb = j - TA::PER_WAVE; glds16(pb[jb], base + TA::BYTES + (wid * TB::PER_WAVE + jb) * 1024); pb[jb] += bstep; }
+    };
+    auto issue = [&](int stage_buf) {
 #pragma unroll
-        for (int j = 0; j < TA::PER_WAVE; ++j) { glds16(pa[j], base + (wid * TA::PER_WAVE + j) * 1024); pa[j] += astep; }
-#pragma unroll
-        for (int j = 0; j < TB::PER_WAVE; ++j) { glds16(pb[j], base + TA::BYTES + (wid * TB::PER_WAVE + j) * 1024); pb[j] += bstep; }
+        for (int j = 0; j < LOADS; ++j) issue_one(stage_buf, j);
     };
 
     f32x4 acc[WM][4];
@@ -442,12 +445,13 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs g) {
     issue(0);
     if (nt > 1) issue(1);
     int rd = 0, wrb = 2;                                                      // ring positions: read stage, next write stage
+    constexpr int EVERY = (WM * 4) / LOADS;                                   // MFMAs between two DMA issues
     for (int t = 0; t < nt; ++t) {
         // my own DMA of tile t has landed once at most the LOADS of tile t+1 are still outstanding
         if (t + 1 < nt) { if (LOADS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                         // everyone's tile t landed; tile t-1 fully consumed
-        if (t + 2 < nt) issue(wrb);
+        const bool more = t + 2 < nt;
         const unsigned char* as = smem_raw + rd * STAGE;
         const unsigned char* bs = as + TA::BYTES;
         short8 af[WM], bf[4];
@@ -455,10 +459,20 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs g) {
         for (int i = 0; i < WM; ++i) af[i] = TA::frag(as, wr * (WM * 16) + i * 16, lane);
 #pragma unroll
         for (int j = 0; j < 4; ++j) bf[j] = TB::frag(bs, wc * 64 + j * 16, lane);
+        // the DMA issues of tile t+2 are spread between the MFMAs (an LDS-DMA issue costs ~60-180 cycles of the
+        // wave's issue slot; back-to-back they would stall the matrix pipe for a whole K-step)
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(bf[j], af[i], acc[i][j]);
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = Mma<T>::mma(bf[j], af[i], acc[i][j]);
+                constexpr int dummy = 0; (void)dummy;
+                const int idx = i * 4 + j;
+                if (idx % EVERY == EVERY - 1 && idx / EVERY < LOADS) {
+                    if (more) issue_one(wrb, idx / EVERY);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         rd = rd == NST - 1 ? 0 : rd + 1;
         wrb = wrb == NST - 1 ? 0 : wrb + 1;
     }
