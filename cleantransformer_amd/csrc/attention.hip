@@ -164,26 +164,25 @@ __device__ __forceinline__ void contract64(f32x4 (&acc)[HDP / 16], const T* __re
     }
 }
 
-// Per-key digest staged once per tile: kb = ALiBi key position (>= 0) if the key may be attended, -1 if it is
-// padding (attention_mask == 0), -2 if it lies beyond Sk.
-__device__ __forceinline__ float key_digest(const AttnP& p, int64_t b, int64_t key) {
-    if (key >= p.Sk) return -2.0f;
-    if (p.kvalid != nullptr && p.kvalid[b * p.Sk + key] == 0) return -1.0f;
-    return p.kpos != nullptr ? p.kpos[b * p.Sk + key] : 0.0f;
+// Per-key additive bias staged once per tile (one float per key):
+//    slope * ALiBi position            for a key that may be attended            (modeling_bloom.py:328-330)
+//    FINFO_MIN                          for a padding key (attention_mask == 0): fma(dot, scale, FINFO_MIN) == FINFO_MIN
+//                                       exactly, i.e. the reference's masked_fill value, with no compare/select
+//    -inf                               for a key index beyond Sk (does not exist: probability exactly 0)
+__device__ __forceinline__ float key_bias(const AttnP& p, int64_t b, int64_t key, float slope) {
+    if (key >= p.Sk) return -INFINITY;
+    if (p.kvalid != nullptr && p.kvalid[b * p.Sk + key] == 0) return FINFO_MIN;
+    return p.kpos != nullptr ? slope * p.kpos[b * p.Sk + key] : 0.0f;
 }
-// score of (q, key) given the raw dot product; masked -> FINFO_MIN (modeling_bloom.py:99-109).  Branch-free: every
-// condition is a select (a divergent branch per score element costs more than the whole softmax).  AM (additive mask,
-// transformer.py:43-45) is a compile-time switch; am_base already points at element (b, h, 0, 0).
+// raw score; AM (additive mask, transformer.py:43-45) is a compile-time switch; am_base points at element (b,h,0,0)
 template <bool AM>
-__device__ __forceinline__ float score_of(const AttnP& p, float dot, float kb, int q, int key, float slope,
-                                          const float* __restrict__ am_base, bool& masked) {
-    masked = (kb < 0.f) | ((p.causal != 0) & (key > q + p.off));
-    float s = fmaf(dot, p.scale, slope * kb);
+__device__ __forceinline__ float score_raw(const AttnP& p, float dot, float kb, int q, int key, const float* __restrict__ am_base) {
+    float s = fmaf(dot, p.scale, kb);
     if (AM) {
         const int qc = min(q, (int)p.Sq - 1), kc = min(key, (int)p.Sk - 1);
         s += am_base[(int64_t)qc * p.am_q + (int64_t)kc * p.am_k];
     }
-    return masked ? FINFO_MIN : s;
+    return s;
 }
 
 template <typename T, int HDP>
@@ -254,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
     float rkb = 0.f;
     A::load(rk, kp, p.k_rs, 0, p.Sk, (int)p.hd, fast, tid);
     A::load(rv, vp, p.v_rs, 0, p.Sk, (int)p.hd, fast, tid);
-    if (tid < 64) rkb = key_digest(p, b, tid);
+    if (tid < 64) rkb = key_bias(p, b, tid, slope);
     A::store_rm(rk, KS(0), tid);
     A::store_tr(rv, VT(0), tid);
     if (tid < 64) KB(0)[tid] = rkb;
@@ -266,21 +265,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
         if (t + 1 < ntiles) {
             A::load(rk, kp, p.k_rs, (int64_t)(t + 1) * 64, p.Sk, (int)p.hd, fast, tid);
             A::load(rv, vp, p.v_rs, (int64_t)(t + 1) * 64, p.Sk, (int)p.hd, fast, tid);
-            if (tid < 64) rkb = key_digest(p, b, (int64_t)(t + 1) * 64 + tid);
+            if (tid < 64) rkb = key_bias(p, b, (int64_t)(t + 1) * 64 + tid, slope);
         }
         f32x4 x[4];
         const float* kbs = KB(cur);
         dot_tile<T, HDP>(x, KS(cur), qf, lane);                              // x[nt][r] = q . k[key]
         const int kv0 = t * 64;
+        const bool diag = p.causal && (kv0 + 63 > (int)q0 + p.off);          // only tiles crossing the diagonal need the causal test
         float mx = -INFINITY;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const f32x4 kb4 = *reinterpret_cast<const f32x4*>(kbs + nt * 16 + g * 4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                bool msk;
-                float s = score_of<AM>(p, x[nt][r], kb4[r], q_eff, kv0 + nt * 16 + g * 4 + r, slope, am_base, msk);
-                s = kb4[r] > -1.5f ? s : -INFINITY;                          // keys beyond Sk do not exist
+                const int key = kv0 + nt * 16 + g * 4 + r;
+                float s = score_raw<AM>(p, x[nt][r], kb4[r], q_eff, key, am_base);
+                if (diag) s = (key > q_eff + p.off) ? fminf(s, FINFO_MIN) : s;      // masked_fill; -inf (no such key) stays -inf
                 x[nt][r] = s;
                 mx = fmaxf(mx, s);
             }
@@ -299,9 +299,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
                 rs += pv;
             }
         lsum = lsum * alpha + rs;
-        m = m_new;
+        if (__any(m_new > m)) {                                              // wave-uniform: rescale only when some row max moved
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) acc[dt] *= alpha;
+            for (int dt = 0; dt < NDT; ++dt) acc[dt] *= alpha;
+        }
+        m = m_new;
         contract64<T, HDP>(acc, VT(cur), x, lane);                          // acc[dt][r] = O^T[d][my_q]
         if (NBUF == 1) __syncthreads();
         if (t + 1 < ntiles) {
@@ -378,8 +380,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
     f32x4 dk[NDT], dv[NDT];
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    const float my_kb = key_digest(p, b, my_k);                              // -2: key row does not exist
-    const bool key_live = my_kb > -1.5f;
+    const float my_kb = key_bias(p, b, my_k, slope);                         // -inf: key row does not exist
+    const bool key_live = my_kb > -INFINITY;
+    const bool key_pad = my_kb <= FINFO_MIN;
     const float* am_base = AM ? p.add_mask + b * p.am_b + h * p.am_h : nullptr;
 
     int qt_begin = 0;
@@ -423,6 +426,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
         const float* st = ST(cur);
         dot_tile<T, HDP>(x, QS(cur), kf, lane);                              // x[nt][r] = q[qi] . k[my_k]
         dot_tile<T, HDP>(y, GS(cur), vf, lane);                              // y[nt][r] = dO[qi] . v[my_k]
+        const bool diag = p.causal && ((int)k0 + 63 > t * 64 + p.off);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const f32x4 mm = *reinterpret_cast<const f32x4*>(st + nt * 16 + g * 4);
@@ -432,8 +436,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
             for (int r = 0; r < 4; ++r) {
                 const int q = t * 64 + nt * 16 + g * 4 + r;
                 const bool valid = key_live & (q < (int)p.Sq);
-                bool msk;
-                const float s = score_of<AM>(p, x[nt][r], my_kb, q, (int)my_k, slope, am_base, msk);
+                const bool msk = key_pad | (diag & ((int)my_k > q + p.off));
+                const float s = msk ? FINFO_MIN : score_raw<AM>(p, x[nt][r], my_kb, q, (int)my_k, am_base);
                 const float pr = valid ? __expf(s - mm[r]) * il[r] : 0.f;
                 x[nt][r] = pr;
                 y[nt][r] = (valid & !msk) ? pr * (y[nt][r] - dl[r]) : 0.f;
@@ -510,7 +514,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
     float rkb = 0.f;
     A::load(rk, kp, p.k_rs, 0, p.Sk, (int)p.hd, fast, tid);
     A::load(rv, vp, p.v_rs, 0, p.Sk, (int)p.hd, fast, tid);
-    if (tid < 64) rkb = key_digest(p, b, tid);
+    if (tid < 64) rkb = key_bias(p, b, tid, slope);
     A::store_rm(rk, KS(0), tid); A::store_tr(rk, KT(0), tid);
     A::store_rm(rv, VS(0), tid);
     if (tid < 64) KB(0)[tid] = rkb;
@@ -520,21 +524,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
         if (t + 1 < ntiles) {
             A::load(rk, kp, p.k_rs, (int64_t)(t + 1) * 64, p.Sk, (int)p.hd, fast, tid);
             A::load(rv, vp, p.v_rs, (int64_t)(t + 1) * 64, p.Sk, (int)p.hd, fast, tid);
-            if (tid < 64) rkb = key_digest(p, b, (int64_t)(t + 1) * 64 + tid);
+            if (tid < 64) rkb = key_bias(p, b, (int64_t)(t + 1) * 64 + tid, slope);
         }
         f32x4 x[4], y[4];
         const float* kbs = KB(cur);
         dot_tile<T, HDP>(x, KS(cur), qf, lane);
         dot_tile<T, HDP>(y, VS(cur), gf, lane);
         const int kv0 = t * 64;
+        const bool diag = p.causal && (kv0 + 63 > (int)q0 + p.off);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const f32x4 kb4 = *reinterpret_cast<const f32x4*>(kbs + nt * 16 + g * 4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                bool msk;
-                const float s = score_of<AM>(p, x[nt][r], kb4[r], q_eff, kv0 + nt * 16 + g * 4 + r, slope, am_base, msk);
-                const bool use = live & (kb4[r] > -1.5f) & !msk;
+                const int key = kv0 + nt * 16 + g * 4 + r;
+                const float s = score_raw<AM>(p, x[nt][r], kb4[r], q_eff, key, am_base);
+                const bool use = live & (kb4[r] > FINFO_MIN) & !(diag & (key > q_eff + p.off));   // padding / missing / future keys: dS = 0
                 y[nt][r] = use ? __expf(s - m) * il * (y[nt][r] - dl) : 0.f;
             }
         }

@@ -267,8 +267,10 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce(const float* __restrict__ w
     const int64_t c = (int64_t)blockIdx.x * 64 + tx;
     const int which = blockIdx.y;
     float t = 0.f;
-    if (c < cols)
+    if (c < cols) {
+#pragma unroll 8
         for (int p = ty; p < nparts; p += 4) t += ws[((int64_t)p * 2 + which) * cols + c];
+    }
     sm[ty][tx] = t;
     __syncthreads();
     if (ty == 0 && c < cols) {
@@ -369,19 +371,30 @@ __global__ __launch_bounds__(256) void colsum_part(const T* __restrict__ x, int6
         if (c < N) ws[(int64_t)blockIdx.y * N + c] = sm[0][i] + sm[1][i] + sm[2][i] + sm[3][i];
     }
 }
+// 64 columns x 4 part-slices per block, LDS combine (the parts loop is unrolled so its loads pipeline)
 __global__ __launch_bounds__(256) void colsum_final(const float* __restrict__ ws, float* __restrict__ out, int parts,
                                                     int64_t N, int accumulate) {
-    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (c >= N) return;
+    __shared__ float sm[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t c = (int64_t)blockIdx.x * 64 + tx;
     float t = 0.f;
-    for (int p = 0; p < parts; ++p) t += ws[(int64_t)p * N + c];
-    out[c] = accumulate ? out[c] + t : t;
+    if (c < N) {
+#pragma unroll 8
+        for (int p = ty; p < parts; p += 4) t += ws[(int64_t)p * N + c];
+    }
+    sm[ty][tx] = t;
+    __syncthreads();
+    if (ty == 0 && c < N) {
+        const float r = sm[0][tx] + sm[1][tx] + sm[2][tx] + sm[3][tx];
+        out[c] = accumulate ? out[c] + r : r;
+    }
 }
 
 extern "C" int ctmi_colsum(const void* x, int64_t ld, float* out, int accumulate, float* ws, int64_t M, int64_t N, int dtype, void* stream) {
     CTMI_REQUIRE(x && out && ws && M > 0 && N > 0, "colsum: bad args");
     hipStream_t st = as_stream(stream);
-    int parts = (int)std::min<int64_t>(COLSUM_PARTS, cdiv64(M, 16));
+    const int64_t xblocks = cdiv64(N, 64 * (dtype == CTMI_F32 ? 4 : 8));
+    int parts = (int)std::min<int64_t>(std::max<int64_t>(16, std::min<int64_t>(COLSUM_PARTS, cdiv64(512, xblocks))), cdiv64(M, 16));
     int64_t rpp = cdiv64(M, parts);
     parts = (int)cdiv64(M, rpp);
     if (dtype == CTMI_F32) {
@@ -392,7 +405,7 @@ extern "C" int ctmi_colsum(const void* x, int64_t ld, float* out, int accumulate
         hipLaunchKernelGGL((colsum_part<bf16_t>), dim3((unsigned)cdiv64(N, 64 * 8), parts), dim3(256), 0, st, (const bf16_t*)x, ld, ws, M, N, rpp, vec_ok);
     } else { ctmi_set_error("colsum: unsupported dtype %d", dtype); return CTMI_ERR_UNSUPPORTED; }
     CTMI_CHECK_LAUNCH("colsum_part");
-    hipLaunchKernelGGL(colsum_final, dim3((unsigned)cdiv64(N, 256)), dim3(256), 0, st, ws, out, parts, N, accumulate);
+    hipLaunchKernelGGL(colsum_final, dim3((unsigned)cdiv64(N, 64)), dim3(256), 0, st, ws, out, parts, N, accumulate);
     CTMI_CHECK_LAUNCH("colsum_final");
     return CTMI_OK;
 }
