@@ -34,6 +34,15 @@ def flops_per_token(S: int) -> float:
     return 6.0 * n_mm + 6.0 * L * S * H
 
 
+def _profiled_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC profile (profiles/r01_lmhead_traffic.json:
+    separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied); None if the profile is absent."""
+    try:
+        return float(json.load(open(os.path.join(ROOT, "profiles", "r01_lmhead_traffic.json")))["traffic_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def build_model(device, compute_dtype):
     from cleantransformer_amd.models.modeling_bloom import BloomConfig, BloomForCausalLM
     cfg = BloomConfig(vocab_size=V, hidden_size=H, n_layer=L, num_attention_heads=NH, compute_dtype=compute_dtype)
@@ -166,9 +175,9 @@ def main():
                                    f"(BASELINE configs[1]), random-init weights, fp32 master/grads/Adam state",
                        "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}"},
             "final_loss": round(final_loss, 4),
-            "roofline": {"bound": "mfma", "kernel": "gemm_kernel<bf16> LM-head forward [T,1024]x[250880,1024]^T",
+            "roofline": {"bound": "mfma", "kernel": "gemm_glds_kernel<bf16,NT,256x128> LM-head forward [T,1024]x[250880,1024]^T",
                          "achieved": round(head_tflops, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(head_tflops / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "frac": round(head_tflops / PEAK_BF16_TFLOPS, 4), "traffic": _profiled_traffic(),
                          "avg_launch_ms": round(head_avg, 4), "launches": len(head_ms),
                          "step_achieved": round(step_tflops, 1), "step_frac": round(step_tflops / PEAK_BF16_TFLOPS, 4),
                          "flops_per_token": f_tok},
