@@ -137,6 +137,8 @@ struct GemmArgs {
     const float* bias; const void* residual; const void* aux_in; void* aux_out;
     int tiles_m, tiles_n, vec_c;
     int splits; int64_t k_per_split; float* slabs;        // split-K: partial products go to slabs[s][M][N] (fp32)
+    int splitk_ok; float* ws; int64_t ws_bytes;           // split-K permission + caller workspace (the launch path decides)
+    int dbg;                                               // timing experiments only (CTMI_GEMM_DBG): 1 = no steady-state DMA, 2 = no barrier, 4 = no LDS reads
 };
 
 template <typename TO> __device__ __forceinline__ void store4(TO* p, const float* v);
@@ -383,27 +385,31 @@ struct GTile {
     }
 };
 
-template <typename TO, bool AK, bool BKM, int EPI, int WM>
-__global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs g) {
+template <typename TO, bool AK, bool BKM, int EPI, int WM, int WGN>
+__global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
     using T = bf16_t;
-    constexpr int BM = WM * 32, BN = 128, BK = 32, NST = 3;
+    constexpr int NW = 2 * WGN;                                             // waves: 2 along M x WGN along N
+    constexpr int BM = WM * 32, BN = WGN * 64, BK = 32, NST = 3;
     using TA = GTile<AK, BM>;
     using TB = GTile<BKM, BN>;
     constexpr int STAGE = TA::BYTES + TB::BYTES;
-    constexpr int LOADS = TA::PER_WAVE + TB::PER_WAVE;                      // DMA instructions per wave per stage
+    constexpr int PA = TA::NINSTR / NW, PB = TB::NINSTR / NW;               // DMA instructions per wave per stage
+    constexpr int LOADS = PA + PB;
+    static_assert(LOADS == 4 || LOADS == 6, "vmcnt immediates below assume 4 or 6 DMA pieces per wave per stage");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
     const int tiles_m = (int)((g.M + BM - 1) / BM);
-    const int ntile = tiles_m * g.tiles_n;
+    const int tiles_n = (int)((g.N + BN - 1) / BN);
+    const int ntile = tiles_m * tiles_n;
     const int nblk = ntile * g.splits;
     const int bid = blockIdx.x;
     const int xcd = bid & 7, q = nblk >> 3, r8 = nblk & 7;
     const int vid_all = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
     const int split = vid_all / ntile, vid = vid_all - split * ntile;
     constexpr int GM = (WM == 8) ? 4 : 8;
-    const int group = vid / (GM * g.tiles_n), first_m = group * GM;
+    const int group = vid / (GM * tiles_n), first_m = group * GM;
     const int gm = min(GM, tiles_m - first_m);
-    const int in_group = vid - group * GM * g.tiles_n;
+    const int in_group = vid - group * GM * tiles_n;
     const int tm = first_m + in_group % gm, tn = in_group / gm;
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
     const int64_t kbeg = (int64_t)split * g.k_per_split;
@@ -412,24 +418,24 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs g) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wid >> 1, wc = wid & 1;
+    const int wr = wid / WGN, wc = wid % WGN;
     const T* A = reinterpret_cast<const T*>(g.A);
     const T* B = reinterpret_cast<const T*>(g.B);
 
-    const T* pa[TA::PER_WAVE];
-    const T* pb[TB::PER_WAVE];
+    const T* pa[PA];
+    const T* pb[PB];
 #pragma unroll
-    for (int j = 0; j < TA::PER_WAVE; ++j) pa[j] = TA::src(A, g.lda, m0, g.M, (wid * TA::PER_WAVE + j) * 64 + lane) + (AK ? kbeg * g.lda : kbeg);
+    for (int j = 0; j < PA; ++j) pa[j] = TA::src(A, g.lda, m0, g.M, (wid * PA + j) * 64 + lane) + (AK ? kbeg * g.lda : kbeg);
 #pragma unroll
-    for (int j = 0; j < TB::PER_WAVE; ++j) pb[j] = TB::src(B, g.ldb, n0, g.N, (wid * TB::PER_WAVE + j) * 64 + lane) + (BKM ? kbeg * g.ldb : kbeg);
+    for (int j = 0; j < PB; ++j) pb[j] = TB::src(B, g.ldb, n0, g.N, (wid * PB + j) * 64 + lane) + (BKM ? kbeg * g.ldb : kbeg);
     const int64_t astep = AK ? (int64_t)BK * g.lda : BK, bstep = BKM ? (int64_t)BK * g.ldb : BK;
     const unsigned lds0 = (unsigned)(size_t)smem_raw;
 
     // one DMA piece (j-th of this wave's LOADS per stage) of the NEXT tile; pointers advance
     auto issue_one = [&](int stage_buf, int j) {
         const unsigned base = lds0 + stage_buf * STAGE;
-        if (j < TA::PER_WAVE) { glds16(pa[j], base + (wid * TA::PER_WAVE + j) * 1024); pa[j] += astep; }
-        else { const int jb = j - TA::PER_WAVE; glds16(pb[jb], base + TA::BYTES + (wid * TB::PER_WAVE + jb) * 1024); pb[jb] += bstep; }
+        if (j < PA) { glds16(pa[j], base + (wid * PA + j) * 1024); pa[j] += astep; }
+        else { const int jb = j - PA; glds16(pb[jb], base + TA::BYTES + (wid * PB + jb) * 1024); pb[jb] += bstep; }
     };
     auto issue = [&](int stage_buf) {
 #pragma unroll
@@ -450,15 +456,17 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmArgs g) {
         // my own DMA of tile t has landed once at most the LOADS of tile t+1 are still outstanding
         if (t + 1 < nt) { if (LOADS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                         // everyone's tile t landed; tile t-1 fully consumed
-        const bool more = t + 2 < nt;
+        if (!(g.dbg & 2)) __builtin_amdgcn_s_barrier();                      // everyone's tile t landed; tile t-1 fully consumed
+        const bool more = (t + 2 < nt) && !(g.dbg & 1);
         const unsigned char* as = smem_raw + rd * STAGE;
         const unsigned char* bs = as + TA::BYTES;
         short8 af[WM], bf[4];
+        if (!(g.dbg & 4) || t == 0) {
 #pragma unroll
-        for (int i = 0; i < WM; ++i) af[i] = TA::frag(as, wr * (WM * 16) + i * 16, lane);
+            for (int i = 0; i < WM; ++i) af[i] = TA::frag(as, wr * (WM * 16) + i * 16, lane);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bf[j] = TB::frag(bs, wc * 64 + j * 16, lane);
+            for (int j = 0; j < 4; ++j) bf[j] = TB::frag(bs, wc * 64 + j * 16, lane);
+        }
         // the DMA issues of tile t+2 are spread between the MFMAs (an LDS-DMA issue costs ~60-180 cycles of the
         // wave's issue slot; back-to-back they would stall the matrix pipe for a whole K-step)
 #pragma unroll
@@ -568,14 +576,40 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ s
     }
 }
 
-template <typename TO, bool AK, bool BKM, int EPI, int WM>
+template <typename TO, bool AK, bool BKM, int EPI, int WM, int WGN>
 static void glds_launch(GemmArgs& g, hipStream_t st) {
-    constexpr int BM = WM * 32;
-    const size_t lds = 3 * (size_t)(GTile<AK, BM>::BYTES + GTile<BKM, 128>::BYTES);
-    const unsigned grid = (unsigned)(cdiv64(g.M, BM) * g.tiles_n * g.splits);
-    auto kern = &gemm_glds_kernel<TO, AK, BKM, EPI, WM>;
+    constexpr int BM = WM * 32, BN = WGN * 64;
+    const size_t lds = 3 * (size_t)(GTile<AK, BM>::BYTES + GTile<BKM, BN>::BYTES);
+    const unsigned grid = (unsigned)(cdiv64(g.M, BM) * cdiv64(g.N, BN) * g.splits);
+    auto kern = &gemm_glds_kernel<TO, AK, BKM, EPI, WM, WGN>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, g);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * WGN), lds, st, g);
+}
+
+// tile / split choice for the LDS-DMA path: 0 = 128x128 (4 waves, 3 workgroups/CU), 1 = 256x128 (4 waves, 2/CU),
+// 2 = 256x256 (8 waves, 1/CU).  Rules distilled from tools/microbench.py sweeps of every Bloom-560M shape on MI355X
+// (profiles/r01_gemm_tile_sweep.txt): big tiles win only when they still give >= 2 full rounds of workgroups; outputs of
+// [T,1024] run best on 128x128 without split-K; weight gradients (both operands K-major, K = T) want ~512+ workgroups
+// via deterministic split-K; the one very-long-K product (LM-head dgrad, K = V) takes 256x256 with a 2-way split.
+static void pick_tile(int64_t M, int64_t N, int64_t K, bool wgrad, int max_splits, int& tile, int& splits) {
+    static int force = -2, force_split = -2;
+    if (force == -2) { const char* e = getenv("CTMI_GEMM_TILE"); force = e ? atoi(e) : -1; }
+    if (force_split == -2) { const char* e = getenv("CTMI_GEMM_SPLIT"); force_split = e ? atoi(e) : -1; }
+    if (force_split >= 1) max_splits = std::min(max_splits, force_split);
+    const int64_t t0 = cdiv64(M, 128) * cdiv64(N, 128), t1 = cdiv64(M, 256) * cdiv64(N, 128), t2 = cdiv64(M, 256) * cdiv64(N, 256);
+    tile = 0; splits = 1;
+    if (wgrad) {
+        if (t1 >= 1024) tile = 1;                                   // LM head: [V,H]
+        else {
+            tile = t1 >= 128 ? 1 : 0;
+            const int64_t tiles = tile ? t1 : t0;
+            while (splits < max_splits && tiles * splits < 512 && K / (splits * 2) >= 1024) splits *= 2;
+        }
+    } else if (K >= 32768 && max_splits >= 2 && t2 * 2 >= 192) { tile = 2; splits = 2; }
+    else if (t2 >= 512) tile = 2;
+    else if (t1 >= 700) tile = 1;
+    else tile = 0;
+    if (force >= 0) tile = force;
 }
 
 static bool glds_enabled() {
@@ -591,10 +625,20 @@ static int gemm_launch(GemmArgs& g, bool fast, hipStream_t st) {
     const size_t lds = 2 * (size_t)(TA::ELEMS + TB::ELEMS) * sizeof(T);
     const unsigned grid = (unsigned)(g.tiles_m * g.tiles_n * g.splits);
     if constexpr (sizeof(T) == 2) {
-        if (fast && glds_enabled() && g.K % 32 == 0 && g.k_per_split % 32 == 0) {
-            // 256x128 tiles when they still fill the chip (>= ~1.5 blocks per CU), else 128x128
-            const int64_t big = cdiv64(g.M, 256) * g.tiles_n * g.splits;
-            if (big >= 400) glds_launch<TO, AK, BKM, EPI, 8>(g, st); else glds_launch<TO, AK, BKM, EPI, 4>(g, st);
+        if (fast && glds_enabled() && g.K % 32 == 0) {
+            int tile, splits;
+            const int64_t slab = g.M * g.N * (int64_t)sizeof(float);
+            const int max_sp = g.splitk_ok ? (int)std::max<int64_t>(1, std::min<int64_t>(8, g.ws_bytes / std::max<int64_t>(slab, 1))) : 1;
+            pick_tile(g.M, g.N, g.K, AK && BKM, max_sp, tile, splits);
+            g.splits = 1; g.k_per_split = g.K; g.slabs = nullptr;
+            if (splits > 1) {
+                const int64_t kps = cdiv64(cdiv64(g.K, splits), 64) * 64;
+                const int sp = (int)cdiv64(g.K, kps);
+                if (sp > 1) { g.splits = sp; g.k_per_split = kps; g.slabs = g.ws; }
+            }
+            if (tile == 2) glds_launch<TO, AK, BKM, EPI, 8, 4>(g, st);
+            else if (tile == 1) glds_launch<TO, AK, BKM, EPI, 8, 2>(g, st);
+            else glds_launch<TO, AK, BKM, EPI, 4, 2>(g, st);
             CTMI_CHECK_LAUNCH("gemm_glds");
             if (g.splits > 1) {
                 const int64_t total = g.M * g.N;
@@ -683,6 +727,9 @@ extern "C" int ctmi_gemm(const void* A, int64_t lda, int a_kmajor, const void* B
     g.vec_c = (ldc % 4 == 0) && al(C, cbytes) && al(residual, 4 * es) && al(aux_in, 4 * es) && al(aux_out, 4 * es) && al(bias, 16);
     // split-K: only for plain accumulations (weight gradients) that would leave most of the 256 CUs idle
     g.splits = 1; g.k_per_split = K; g.slabs = nullptr;
+    g.splitk_ok = (workspace != nullptr && epilogue == CTMI_EPI_NONE && bias == nullptr && residual == nullptr) ? 1 : 0;
+    g.ws = reinterpret_cast<float*>(workspace); g.ws_bytes = workspace_bytes;
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("CTMI_GEMM_DBG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
     if (workspace != nullptr && epilogue == CTMI_EPI_NONE && bias == nullptr && residual == nullptr && ntile < 384 && K >= 8 * bkt) {
         int64_t want = std::min<int64_t>(8, cdiv64(512, ntile));
         want = std::min<int64_t>(want, K / (4 * bkt));

@@ -117,7 +117,7 @@ def gemm(A: Tensor, lda: int, a_kmajor: bool, B: Tensor, ldb: int, b_kmajor: boo
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    ws = _splitk_ws(A.device) if (a_kmajor and b_kmajor and out_f32) else None
+    ws = _splitk_ws(A.device) if (epilogue == _lib.EPI_NONE and bias is None and residual is None) else None
     check(_lib.load().ctmi_gemm(_p(A), lda, int(a_kmajor), _p(B), ldb, int(b_kmajor), _p(out), N, M, N, K, float(alpha), int(beta),
                                 _p(bias), _p(residual), int(epilogue), _p(aux_in), _p(aux_out), int(out_f32), dt_code(dtype),
                                 _p(ws), 0 if ws is None else ws.numel() * 4, _stream()), "gemm")
