@@ -24,6 +24,7 @@ struct AttnP {
     int64_t am_b, am_h, am_q, am_k;
     float scale;
     int causal, off, vec_ok;
+    int dbg;                 // timing experiments only (CTMI_ATTN_DBG): 1 = no steady-state global loads, 2 = no LDS restage
 };
 
 // 64 x HDP tile staging helpers (256 threads).  Thread -> (row = id / CPR, 16-byte chunk = id % CPR): the CPR lanes of
@@ -164,6 +165,22 @@ __device__ __forceinline__ void contract64(f32x4 (&acc)[HDP / 16], const T* __re
     }
 }
 
+// XCD-aware block order.  The dispatcher places workgroup b on XCD b % 8 and each XCD has a private 4 MiB L2.  Give every XCD
+// a contiguous run of logical block ids (bijective for any grid size) so that all the 64-row blocks of one (batch, head) —
+// which stream the same K/V (or Q/dO) tiles — run on the same XCD and hit its L2 instead of re-fetching from HBM/MALL.
+// (Ablation: with no steady-state global loads the forward kernel ran 1.6x faster; the loads were L2 misses.)
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int xcd = bid & 7, q = nblk >> 3, r8 = nblk & 7;
+    return (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+}
+
+// 3-input max in ONE instruction.  (fmaxf on MFMA results makes hipcc insert a canonicalising v_max x,x per operand.)
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // Per-key additive bias staged once per tile (one float per key):
 //    slope * ALiBi position            for a key that may be attended            (modeling_bloom.py:328-330)
 //    FINFO_MIN                          for a padding key (attention_mask == 0): fma(dot, scale, FINFO_MIN) == FINFO_MIN
@@ -222,8 +239,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, li = lane & 15;
     const bool fast = p.vec_ok && p.hd == HDP;
     const int nqb = (int)((p.Sq + 63) / 64);
-    const int qb = nqb - 1 - (int)(blockIdx.x % nqb);                       // longest (latest) query blocks first
-    const int64_t bh = blockIdx.x / nqb, h = bh % p.nh, b = bh / p.nh;
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int qb = nqb - 1 - (vid % nqb);                                   // longest (latest) query blocks first
+    const int64_t bh = vid / nqb, h = bh % p.nh, b = bh / p.nh;
     const int64_t q0 = (int64_t)qb * 64, my_q = q0 + wid * 16 + li;
     const T* qp = reinterpret_cast<const T*>(p.q) + b * p.q_bs + h * p.q_hs;
     const T* kp = reinterpret_cast<const T*>(p.k) + b * p.k_bs + h * p.k_hs;
@@ -262,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
     const float* am_base = AM ? p.add_mask + b * p.am_b + h * p.am_h : nullptr;
 
     for (int t = 0; t < ntiles; ++t) {
-        if (t + 1 < ntiles) {
+        if (t + 1 < ntiles && !(p.dbg & 1)) {
             A::load(rk, kp, p.k_rs, (int64_t)(t + 1) * 64, p.Sk, (int)p.hd, fast, tid);
             A::load(rv, vp, p.v_rs, (int64_t)(t + 1) * 64, p.Sk, (int)p.hd, fast, tid);
             if (tid < 64) rkb = key_bias(p, b, (int64_t)(t + 1) * 64 + tid, slope);
@@ -272,32 +290,42 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
         dot_tile<T, HDP>(x, KS(cur), qf, lane);                              // x[nt][r] = q . k[key]
         const int kv0 = t * 64;
         const bool diag = p.causal && (kv0 + 63 > (int)q0 + p.off);          // only tiles crossing the diagonal need the causal test
+        // softmax arithmetic on 4-wide vectors so that hipcc emits packed fp32 ops (v_pk_fma/add/mul_f32): this kernel
+        // is bound by VALU issue (hd = 64 gives only 16 MFMAs per ~300 VALU instructions per tile), not by the matrix pipe
         float mx = -INFINITY;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const f32x4 kb4 = *reinterpret_cast<const f32x4*>(kbs + nt * 16 + g * 4);
+            f32x4 s4 = x[nt] * p.scale + kb4;                                 // fma(dot, scale, key bias): padding -> finfo.min, no key -> -inf
+            if (AM) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kv0 + nt * 16 + g * 4 + r;
-                float s = score_raw<AM>(p, x[nt][r], kb4[r], q_eff, key, am_base);
-                if (diag) s = (key > q_eff + p.off) ? fminf(s, FINFO_MIN) : s;      // masked_fill; -inf (no such key) stays -inf
-                x[nt][r] = s;
-                mx = fmaxf(mx, s);
+                for (int r = 0; r < 4; ++r) s4[r] = score_raw<true>(p, x[nt][r], kb4[r], q_eff, kv0 + nt * 16 + g * 4 + r, am_base);
             }
+            if (diag) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kv0 + nt * 16 + g * 4 + r;
+                    s4[r] = (key > q_eff + p.off) ? fminf(s4[r], FINFO_MIN) : s4[r];   // masked_fill; -inf (no such key) stays -inf
+                }
+            }
+            x[nt] = s4;
+            mx = max3f(max3f(mx, s4[0], s4[1]), s4[2], s4[3]);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m, mx);                                   // finite: every tile holds >= 1 real key
         const float alpha = __expf(m - m_new);
-        float rs = 0.f;
+        f32x4 rs4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < 4; ++nt) {
+            const f32x4 e4 = (x[nt] - m_new) * 1.4426950408889634f;           // (s - m) first: finfo.min - finfo.min must be 0, not inf - inf
+            f32x4 p4;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float pv = __expf(x[nt][r] - m_new);
-                x[nt][r] = pv;
-                rs += pv;
-            }
+            for (int r = 0; r < 4; ++r) p4[r] = __builtin_amdgcn_exp2f(e4[r]);
+            x[nt] = p4;
+            rs4 += p4;
+        }
+        const float rs = (rs4[0] + rs4[1]) + (rs4[2] + rs4[3]);
         lsum = lsum * alpha + rs;
         if (__any(m_new > m)) {                                              // wave-uniform: rescale only when some row max moved
 #pragma unroll
@@ -306,14 +334,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
         m = m_new;
         contract64<T, HDP>(acc, VT(cur), x, lane);                          // acc[dt][r] = O^T[d][my_q]
         if (NBUF == 1) __syncthreads();
-        if (t + 1 < ntiles) {
+        if (t + 1 < ntiles && !(p.dbg & 2)) {
             const int nx = NBUF == 2 ? cur ^ 1 : 0;
             A::store_rm(rk, KS(nx), tid);
             A::store_tr(rv, VT(nx), tid);
             if (tid < 64) KB(nx)[tid] = rkb;
             cur = nx;
         }
-        __syncthreads();
+        if (!(p.dbg & 4)) __syncthreads();
     }
     lsum += __shfl_xor(lsum, 16, 64);
     lsum += __shfl_xor(lsum, 32, 64);
@@ -362,8 +390,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, li = lane & 15;
     const bool fast = p.vec_ok && p.hd == HDP;
     const int nkb = (int)((p.Sk + 63) / 64);
-    const int kb = (int)(blockIdx.x % nkb);                                  // early key blocks (most work) first
-    const int64_t bh = blockIdx.x / nkb, h = bh % p.nh, b = bh / p.nh;
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int kb = vid % nkb;                                                // early key blocks (most work) first
+    const int64_t bh = vid / nkb, h = bh % p.nh, b = bh / p.nh;
     const int64_t k0 = (int64_t)kb * 64, my_k = k0 + wid * 16 + li;
     const T* qp = reinterpret_cast<const T*>(p.q) + b * p.q_bs + h * p.q_hs;
     const T* kp = reinterpret_cast<const T*>(p.k) + b * p.k_bs + h * p.k_hs;
@@ -479,8 +508,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, li = lane & 15;
     const bool fast = p.vec_ok && p.hd == HDP;
     const int nqb = (int)((p.Sq + 63) / 64);
-    const int qb = nqb - 1 - (int)(blockIdx.x % nqb);
-    const int64_t bh = blockIdx.x / nqb, h = bh % p.nh, b = bh / p.nh;
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int qb = nqb - 1 - (vid % nqb);
+    const int64_t bh = vid / nqb, h = bh % p.nh, b = bh / p.nh;
     const int64_t q0 = (int64_t)qb * 64, my_q = q0 + wid * 16 + li;
     const bool live = my_q < p.Sq;
     const T* qp = reinterpret_cast<const T*>(p.q) + b * p.q_bs + h * p.q_hs;
@@ -570,6 +600,7 @@ static int fill_params(AttnP& p, const ctmi_attn_desc* d, int dtype, const char*
     p.v_bs = d->v_bs; p.v_hs = d->v_hs; p.v_rs = d->v_rs; p.o_bs = d->o_bs; p.o_hs = d->o_hs; p.o_rs = d->o_rs;
     p.am_b = d->am_b; p.am_h = d->am_h; p.am_q = d->am_q; p.am_k = d->am_k;
     p.scale = d->scale; p.causal = d->causal; p.off = (int)(d->Sk - d->Sq);
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("CTMI_ATTN_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
     const int vec = dtype == CTMI_F32 ? 4 : 8;
     auto ok = [&](const void* ptr, int64_t a, int64_t b2, int64_t c) {
         return ptr == nullptr || (((((uintptr_t)ptr) & 15) == 0) && a % vec == 0 && b2 % vec == 0 && c % vec == 0);
