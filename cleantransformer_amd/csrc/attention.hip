@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
     __syncthreads();
 
     for (int t = qt_begin; t < qt_end; ++t) {
-        if (t + 1 < qt_end) {
+        if (t + 1 < qt_end && !(p.dbg & 1)) {
             A::load(rq, qp, p.q_rs, (int64_t)(t + 1) * 64, p.Sq, (int)p.hd, fast, tid);
             A::load(rg, gp, p.o_rs, (int64_t)(t + 1) * 64, p.Sq, (int)p.hd, fast, tid);
             load_stats(t + 1);
@@ -461,21 +461,37 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
             const f32x4 mm = *reinterpret_cast<const f32x4*>(st + nt * 16 + g * 4);
             const f32x4 il = *reinterpret_cast<const f32x4*>(st + 64 + nt * 16 + g * 4);
             const f32x4 dl = *reinterpret_cast<const f32x4*>(st + 128 + nt * 16 + g * 4);
+            const int qb0 = t * 64 + nt * 16 + g * 4;
+            f32x4 s4 = x[nt] * p.scale + my_kb;                                   // packed fma
+            if (AM) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s4[r] = score_raw<true>(p, x[nt][r], my_kb, qb0 + r, (int)my_k, am_base);
+            }
+            bool msk[4], valid[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int q = t * 64 + nt * 16 + g * 4 + r;
-                const bool valid = key_live & (q < (int)p.Sq);
-                const bool msk = key_pad | (diag & ((int)my_k > q + p.off));
-                const float s = msk ? FINFO_MIN : score_raw<AM>(p, x[nt][r], my_kb, q, (int)my_k, am_base);
-                const float pr = valid ? __expf(s - mm[r]) * il[r] : 0.f;
-                x[nt][r] = pr;
-                y[nt][r] = (valid & !msk) ? pr * (y[nt][r] - dl[r]) : 0.f;
+                msk[r] = key_pad | (diag & ((int)my_k > qb0 + r + p.off));
+                valid[r] = key_live & (qb0 + r < (int)p.Sq);
+                s4[r] = msk[r] ? FINFO_MIN : s4[r];
             }
+            const f32x4 e4 = (s4 - mm) * 1.4426950408889634f;                     // (s - m) first (finfo.min - finfo.min = 0)
+            f32x4 p4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p4[r] = __builtin_amdgcn_exp2f(e4[r]);
+            p4 = p4 * il;
+            f32x4 d4 = p4 * (y[nt] - dl);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                p4[r] = valid[r] ? p4[r] : 0.f;
+                d4[r] = (valid[r] & !msk[r]) ? d4[r] : 0.f;
+            }
+            x[nt] = p4;
+            y[nt] = d4;
         }
         contract64<T, HDP>(dv, GT(cur), x, lane);                            // dV^T[d][my_k] += sum_q dO[q][d] P[q][my_k]
         contract64<T, HDP>(dk, QT(cur), y, lane);                            // dK^T[d][my_k] += sum_q Q[q][d] dS[q][my_k]
         if (NBUF == 1) __syncthreads();
-        if (t + 1 < qt_end) {
+        if (t + 1 < qt_end && !(p.dbg & 2)) {
             const int nx = NBUF == 2 ? cur ^ 1 : 0;
             A::store_rm(rq, QS(nx), tid); A::store_tr(rq, QT(nx), tid);
             A::store_rm(rg, GS(nx), tid); A::store_tr(rg, GT(nx), tid);
@@ -551,7 +567,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
     __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
-        if (t + 1 < ntiles) {
+        if (t + 1 < ntiles && !(p.dbg & 1)) {
             A::load(rk, kp, p.k_rs, (int64_t)(t + 1) * 64, p.Sk, (int)p.hd, fast, tid);
             A::load(rv, vp, p.v_rs, (int64_t)(t + 1) * 64, p.Sk, (int)p.hd, fast, tid);
             if (tid < 64) rkb = key_bias(p, b, (int64_t)(t + 1) * 64 + tid, slope);
@@ -565,17 +581,27 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const f32x4 kb4 = *reinterpret_cast<const f32x4*>(kbs + nt * 16 + g * 4);
+            const int k0t = kv0 + nt * 16 + g * 4;
+            f32x4 s4 = x[nt] * p.scale + kb4;
+            if (AM) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s4[r] = score_raw<true>(p, x[nt][r], kb4[r], q_eff, k0t + r, am_base);
+            }
+            const f32x4 e4 = (s4 - m) * 1.4426950408889634f;
+            f32x4 p4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p4[r] = __builtin_amdgcn_exp2f(e4[r]);
+            f32x4 d4 = (p4 * il) * (y[nt] - dl);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int key = kv0 + nt * 16 + g * 4 + r;
-                const float s = score_raw<AM>(p, x[nt][r], kb4[r], q_eff, key, am_base);
-                const bool use = live & (kb4[r] > FINFO_MIN) & !(diag & (key > q_eff + p.off));   // padding / missing / future keys: dS = 0
-                y[nt][r] = use ? __expf(s - m) * il * (y[nt][r] - dl) : 0.f;
+                const bool use = live & (kb4[r] > FINFO_MIN) & !(diag & (k0t + r > q_eff + p.off));   // padding / missing / future keys: dS = 0
+                d4[r] = use ? d4[r] : 0.f;
             }
+            y[nt] = d4;
         }
         contract64<T, HDP>(dq, KT(cur), y, lane);                            // dQ^T[d][my_q] += sum_key K[key][d] dS[my_q][key]
         if (NBUF == 1) __syncthreads();
-        if (t + 1 < ntiles) {
+        if (t + 1 < ntiles && !(p.dbg & 2)) {
             const int nx = NBUF == 2 ? cur ^ 1 : 0;
             A::store_rm(rk, KS(nx), tid); A::store_tr(rk, KT(nx), tid);
             A::store_rm(rv, VS(nx), tid);

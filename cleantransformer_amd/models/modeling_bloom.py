@@ -128,6 +128,7 @@ class BloomBlockFn(torch.autograd.Function):
         ctx.save_for_backward(x2, ln1_w, wqkv, wd, ln2_w, w1, w2, mean1, rstd1, ln1, qkv, att, stat_m, stat_l,
                               h1, mean2, rstd2, ln2, u, g)
         ctx.actx, ctx.desc, ctx.post_ln_res, ctx.shape = actx, desc, post_ln_res, (B, S, H)
+        ctx.set_materialize_grads(False)                 # the K/V "present" outputs carry no gradient: do not zero-fill them
         qv = qkv.view(B, S, nh, 3, hd)
         present_k = qv[:, :, :, 1, :].transpose(1, 2)                                       # views, like the reference's k_v_past
         present_v = qv[:, :, :, 2, :].transpose(1, 2)
@@ -136,6 +137,8 @@ class BloomBlockFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout, _dk, _dv):
+        if dout is None:
+            return (None,) * 16
         (x2, ln1_w, wqkv, wd, ln2_w, w1, w2, mean1, rstd1, ln1, qkv, att, stat_m, stat_l,
          h1, mean2, rstd2, ln2, u, g) = ctx.saved_tensors
         B, S, H = ctx.shape

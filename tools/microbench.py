@@ -66,6 +66,14 @@ def bench_attn(B=8, S=1024, nh=16, hd=64):
     dq = torch.empty_like(qkv)
     t = timeit(lambda: ops.attn_bwd(qkv, qkv[:, hd:], qkv[:, 2 * hd:], out, go, sm, sl, dq, dq[:, hd:], dq[:, 2 * hd:], desc, slopes, mask))
     print(f"bwd: {t:8.3f} ms  {2.5 * fl / t / 1e9:8.1f} TF/s (2.5x fwd flops)")
+    if os.environ.get("MB_KTRACE"):
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for _ in range(5):
+                ops.attn_bwd(qkv, qkv[:, hd:], qkv[:, 2 * hd:], out, go, sm, sl, dq, dq[:, hd:], dq[:, 2 * hd:], desc, slopes, mask)
+            torch.cuda.synchronize()
+        for e in prof.key_averages():
+            print(f"   {e.key[:50]:50s} {e.device_time / 1.0:9.1f} us avg")
 
 
 def bench_ln(T=8192, H=1024):
