@@ -358,8 +358,32 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
 // ------------------------------------------------------------------------------------------------ delta = rowsum(dO * O)
 template <typename T>
 __global__ __launch_bounds__(256) void attn_delta_kernel(AttnP p) {
-    const int lane = threadIdx.x & 63;
+    constexpr int VEC = 16 / sizeof(T);
     const int64_t rows = p.B * p.nh * p.Sq;
+    const bool fast = p.vec_ok && (p.hd % VEC == 0) && (64 % (p.hd / VEC) == 0) && (p.hd / VEC) <= 16;
+    if (fast) {
+        // hd/VEC lanes per row (8 for hd = 64 bf16), 16-byte loads, xor-shuffle reduce inside the lane group
+        const int lpr = (int)p.hd / VEC, rpw = 64 / lpr;
+        const int lane = threadIdx.x & 63, sub = lane % lpr, rin = lane / lpr;
+        const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
+        for (int64_t r0 = wave0 * rpw; r0 < rows; r0 += nw * rpw) {
+            const int64_t row = r0 + rin;
+            float s = 0.f;
+            if (row < rows) {
+                const int64_t q = row % p.Sq, bh = row / p.Sq, h = bh % p.nh, b = bh / p.nh;
+                const int64_t base = b * p.o_bs + h * p.o_hs + q * p.o_rs + sub * VEC;
+                float a[VEC], c[VEC];
+                unpack16<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.o) + base), a);
+                unpack16<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.d_o) + base), c);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) s += a[j] * c[j];
+            }
+            for (int o = lpr >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            if (row < rows && sub == 0) p.delta[row] = s;
+        }
+        return;
+    }
+    const int lane = threadIdx.x & 63;
     for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
         const int64_t q = row % p.Sq, bh = row / p.Sq, h = bh % p.nh, b = bh / p.nh;
         const int64_t base = b * p.o_bs + h * p.o_hs + q * p.o_rs;

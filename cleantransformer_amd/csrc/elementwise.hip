@@ -128,16 +128,17 @@ extern "C" int ctmi_layernorm_fwd(const void* x, const float* w, const float* b,
 // Backward.  dx = rstd * (g - mean(g) - xhat*mean(g*xhat)),  g = dy*w, xhat = (x-mean)*rstd.
 // Each wave keeps per-lane partial sums of dw = sum dy*xhat and db = sum dy for its rows; a block combines its
 // 4 waves through LDS and writes one partial row to ws[blockIdx][2][cols]; ln_bwd_reduce sums the partial rows.
+static constexpr int LNB_WAVES = 8;                     // waves per workgroup in ln_bwd_vec (512 threads: keeps ~16 waves/CU resident)
 template <typename T, int MAXV>
-__global__ __launch_bounds__(256) void ln_bwd_vec(const T* __restrict__ dy, const T* __restrict__ x,
+__global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_vec(const T* __restrict__ dy, const T* __restrict__ x,
                                                   const float* __restrict__ w, const float* __restrict__ mean_i,
                                                   const float* __restrict__ rstd_i, const T* __restrict__ dres,
                                                   T* __restrict__ dx, float* __restrict__ ws, int64_t rows, int cols) {
     constexpr int VEC = 16 / sizeof(T);
-    extern __shared__ __attribute__((aligned(16))) float lds[];      // [4][2][cols]
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // [LNB_WAVES][2][cols]
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int64_t wave0 = (int64_t)blockIdx.x * 4 + wid;
-    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int64_t wave0 = (int64_t)blockIdx.x * LNB_WAVES + wid;
+    const int64_t nwaves = (int64_t)gridDim.x * LNB_WAVES;
     const float inv_n = 1.0f / (float)cols;
     float aw[MAXV][VEC], ab[MAXV][VEC], wv[MAXV][VEC];
 #pragma unroll
@@ -204,11 +205,11 @@ __global__ __launch_bounds__(256) void ln_bwd_vec(const T* __restrict__ dy, cons
     }
     __syncthreads();
     float* out = ws + (int64_t)blockIdx.x * 2 * cols;
-    for (int c = threadIdx.x; c < 2 * cols; c += 256) {
+    for (int c = threadIdx.x; c < 2 * cols; c += 64 * LNB_WAVES) {
         const int which = c / cols, cc = c - which * cols;
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) t += lds[(k * 2 + which) * cols + cc];
+        for (int k = 0; k < LNB_WAVES; ++k) t += lds[(k * 2 + which) * cols + cc];
         out[c] = t;
     }
 }
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce(const float* __restrict__ w
     }
 }
 
-static const int LN_BWD_MAX_BLOCKS = 256;
+static const int LN_BWD_MAX_BLOCKS = 512;
 extern "C" int64_t ctmi_layernorm_bwd_ws(int64_t rows, int64_t cols) {
     (void)rows;
     return (int64_t)LN_BWD_MAX_BLOCKS * 2 * cols;
@@ -292,15 +293,15 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* w, const fl
                          int64_t rows, int64_t cols, hipStream_t st) {
     constexpr int VEC = 16 / sizeof(T);
     const bool vec_ok = (cols % VEC == 0) && aligned16(x) && aligned16(dy) && aligned16(dx) &&
-                        (dres == nullptr || aligned16(dres)) && cols <= 8LL * 64 * VEC && cols * 32 <= 160 * 1024;
+                        (dres == nullptr || aligned16(dres)) && cols <= 8LL * 64 * VEC && cols * 2 * LNB_WAVES * 4 <= 64 * 1024;
     int nparts;
     if (vec_ok) {
-        int grid = (int)std::min<int64_t>(cdiv64(rows, 4), LN_BWD_MAX_BLOCKS);
+        int grid = (int)std::min<int64_t>(cdiv64(rows, LNB_WAVES), LN_BWD_MAX_BLOCKS);
         nparts = grid;
-        size_t lds = (size_t)cols * 8 * sizeof(float);
+        size_t lds = (size_t)cols * 2 * LNB_WAVES * sizeof(float);
 #define LN_BWD_CASE(MV) if (cols <= (int64_t)MV * 64 * VEC) { \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_vec<T, MV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((ln_bwd_vec<T, MV>), dim3(grid), dim3(256), lds, st, (const T*)dy, (const T*)x, w, mean, rstd, \
+            hipLaunchKernelGGL((ln_bwd_vec<T, MV>), dim3(grid), dim3(64 * LNB_WAVES), lds, st, (const T*)dy, (const T*)x, w, mean, rstd, \
                                (const T*)dres, (T*)dx, ws, rows, (int)cols); }
         LN_BWD_CASE(1) else LN_BWD_CASE(2) else LN_BWD_CASE(4) else LN_BWD_CASE(8)
 #undef LN_BWD_CASE

@@ -86,6 +86,11 @@ def alibi_slopes(num_heads: int) -> Tensor:
     return slopes
 
 
+import os as _os
+
+_WGRAD_SIDE_STREAM = _os.environ.get("CTMI_WGRAD_STREAM", "1") != "0"
+
+
 class _AttnCtx:
     """Per-forward digest shared by all blocks: mask info on device, slopes, geometry."""
 
@@ -152,25 +157,38 @@ class BloomBlockFn(torch.autograd.Function):
         dout2 = dout.reshape(T, H)
         dout2 = dout2 if dout2.is_contiguous() else dout2.contiguous()
 
+        # Parameter gradients (wgrad GEMMs + bias column sums) feed nothing further down the backward chain: they run on
+        # a side HIP stream, concurrently with the dgrad GEMMs / attention backward (MFMA-bound next to VALU-bound work,
+        # and their kernel tails overlap).  The side stream waits for each producer; the main stream waits for the side
+        # stream before this node returns, so everything downstream (autograd accumulation, optimizer) is ordered.
+        use_side = _WGRAD_SIDE_STREAM and x2.is_cuda
+        main = torch.cuda.current_stream(x2.device) if use_side else None
+        side = ops.side_stream(x2.device) if use_side else None
+
+        def param_grads(dy, xin):
+            if side is None:
+                return ops.linear_wgrad(dy, xin), ops.colsum(dy)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                return ops.linear_wgrad(dy, xin), ops.colsum(dy)
+
         # MLP: out = res2 + W2 gelu(W1 ln2 + b1) + b2
-        dw2 = ops.linear_wgrad(dout2, g)
-        db2 = ops.colsum(dout2)
+        dw2, db2 = param_grads(dout2, g)
         du = ops.linear_dgrad(dout2, w2_c, epilogue=_lib.EPI_DGELU, aux_in=u)             # dgelu fused (modeling_bloom.py:348-363)
-        dw1 = ops.linear_wgrad(du, ln2)
-        db1 = ops.colsum(du)
+        dw1, db1 = param_grads(du, ln2)
         dln2 = ops.linear_dgrad(du, w1_c, residual=dout2 if post else None)
         dh1, dln2_w, dln2_b = ops.layernorm_bwd(dln2, h1, ln2_w.detach(), mean2, rstd2, dres=None if post else dout2)
         # attention: h1 = res1 + Wd att + bd
-        dwd = ops.linear_wgrad(dh1, att)
-        dbd = ops.colsum(dh1)
+        dwd, dbd = param_grads(dh1, att)
         datt = ops.linear_dgrad(dh1, wd_c)
         dqkv = torch.empty_like(qkv)
         ops.attn_bwd(qkv, qkv[:, hd:], qkv[:, 2 * hd:], att, datt, stat_m, stat_l,
                      dqkv, dqkv[:, hd:], dqkv[:, 2 * hd:], ctx.desc, ctx.actx.slopes, ctx.actx.mask)
-        dwqkv = ops.linear_wgrad(dqkv, ln1)
-        dbqkv = ops.colsum(dqkv)
+        dwqkv, dbqkv = param_grads(dqkv, ln1)
         dln1 = ops.linear_dgrad(dqkv, wqkv_c, residual=dh1 if post else None)
         dx, dln1_w, dln1_b = ops.layernorm_bwd(dln1, x2, ln1_w.detach(), mean1, rstd1, dres=None if post else dh1)
+        if side is not None:
+            main.wait_stream(side)
         return (dx.view(B, S, H), dln1_w, dln1_b, dwqkv, dbqkv, dwd, dbd, dln2_w, dln2_b, dw1, db1, dw2, db2,
                 None, None, None)
 

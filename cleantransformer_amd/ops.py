@@ -97,13 +97,27 @@ _SPLITK_WS = {}
 
 
 def _splitk_ws(device) -> Tensor:
-    """Per-device scratch for split-K weight-gradient GEMMs (fp32 slabs; 8 x [4096,1024] fits).  Kernels on one stream
-    run in order, so one buffer per device is enough."""
-    ws = _SPLITK_WS.get(device)
+    """Scratch for split-K GEMMs (fp32 slabs; 8 x [4096,1024] fits), one per (device, stream): kernels on one stream
+    run in order, but the weight-gradient side stream must not share slabs with the main stream."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _SPLITK_WS.get(key)
     if ws is None:
         ws = torch.empty(8 * 4096 * 1024, dtype=torch.float32, device=device)
-        _SPLITK_WS[device] = ws
+        _SPLITK_WS[key] = ws
     return ws
+
+
+_SIDE_STREAMS = {}
+
+
+def side_stream(device) -> "torch.cuda.Stream":
+    """The per-device side HIP stream on which weight-gradient GEMMs and bias-gradient reductions run concurrently with
+    the dgrad / attention-backward chain (they feed nothing downstream in backward)."""
+    st = _SIDE_STREAMS.get(device)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _SIDE_STREAMS[device] = st
+    return st
 
 
 def gemm(A: Tensor, lda: int, a_kmajor: bool, B: Tensor, ldb: int, b_kmajor: bool, M: int, N: int, K: int, *,
