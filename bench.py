@@ -108,11 +108,13 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    if os.environ.get("CTMI_BENCH_ONE_DEVICE"):            # plumbing test only: all ranks share cuda:0 (with gloo)
+        local_rank = 0
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")                      # RCCL
+        dist.init_process_group(os.environ.get("CTMI_DIST_BACKEND", "nccl"))       # "nccl" == RCCL on ROCm
 
     from cleantransformer_amd import ops
     from cleantransformer_amd.optimizer import AdamW

@@ -507,6 +507,43 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
     const T* R = reinterpret_cast<const T*>(g.residual);
     const T* AUXI = reinterpret_cast<const T*>(g.aux_in);
     T* AUXO = reinterpret_cast<T*>(g.aux_out);
+    // Interior tiles with aligned pointers (the common case) take a straight-line epilogue: no per-lane bounds test, so
+    // hipcc emits no exec-masked branches around the vector loads/stores; edge tiles take the guarded path.
+    const bool interior = g.vec_c && (m0 + BM <= g.M) && (n0 + BN <= g.N);
+    if (interior) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            const int64_t m = m0 + wr * (WM * 16) + i * 16 + (lane & 15);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t n = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+                const int64_t off = m * g.ldc + n;
+                f32x4 v = acc[i][j] * g.alpha;
+                if (g.bias != nullptr) v += *reinterpret_cast<const f32x4*>(g.bias + n);
+                if (EPI == CTMI_EPI_GELU) {
+                    float t[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) t[r] = Cvt<T>::to_f(Cvt<T>::from_f(t[r]));
+                    store4<T>(AUXO + off, t);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(t[r]);
+                } else if (EPI == CTMI_EPI_RELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                } else if (EPI == CTMI_EPI_DGELU || EPI == CTMI_EPI_DRELU) {
+                    float u[4];
+                    load4<T>(AUXI + off, u);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = (EPI == CTMI_EPI_DGELU) ? v[r] * gelu_tanh_grad_f(u[r]) : (u[r] > 0.f ? v[r] : 0.f);
+                }
+                if (R != nullptr) { float u[4]; load4<T>(R + off, u); v += f32x4{u[0], u[1], u[2], u[3]}; }
+                if (g.beta) { float u[4]; load4<TO>(C + off, u); v += f32x4{u[0], u[1], u[2], u[3]}; }
+                const float o[4] = {v[0], v[1], v[2], v[3]};
+                store4<TO>(C + off, o);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
         const int64_t m = m0 + wr * (WM * 16) + i * 16 + (lane & 15);
