@@ -148,6 +148,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    host_enqueue_ms = (time.perf_counter() - t0) / args.steps * 1e3      # host-side launch time per step (GPU runs behind)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -176,7 +177,7 @@ def main():
             "config": {"workload": f"Bloom-560M (24L, H=1024, nh=16, V=250880) SFT step fwd+bwd+AdamW, B={B} S={S} per GPU "
                                    f"(BASELINE configs[1]), random-init weights, fp32 master/grads/Adam state",
                        "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}"},
-            "final_loss": round(final_loss, 4),
+            "final_loss": round(final_loss, 4), "host_enqueue_ms_per_step": round(host_enqueue_ms, 2),
             "roofline": {"bound": "mfma", "kernel": "gemm_glds_kernel<bf16,NT,256x128> LM-head forward [T,1024]x[250880,1024]^T",
                          "achieved": round(head_tflops, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(head_tflops / PEAK_BF16_TFLOPS, 4), "traffic": _profiled_traffic(),

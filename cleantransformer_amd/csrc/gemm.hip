@@ -467,6 +467,7 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) bf[j] = TB::frag(bs, wc * 64 + j * 16, lane);
         }
+        __builtin_amdgcn_s_setprio(1);                                        // MFMA phase outranks the partner wave's DMA / epilogue issue
         // the DMA issues of tile t+2 are spread between the MFMAs (an LDS-DMA issue costs ~60-180 cycles of the
         // wave's issue slot; back-to-back they would stall the matrix pipe for a whole K-step)
 #pragma unroll
@@ -481,6 +482,7 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+        __builtin_amdgcn_s_setprio(0);
         rd = rd == NST - 1 ? 0 : rd + 1;
         wrb = wrb == NST - 1 ? 0 : wrb + 1;
     }
