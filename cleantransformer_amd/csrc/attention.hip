@@ -7,8 +7,8 @@
 // issued so that the wave's own row index sits in the accumulator COLUMN (lane & 15): each lane then owns exactly
 // one query (or key) row, the softmax statistics are per-lane scalars (2 shuffles per tile instead of 16), and the
 // probabilities / dS values come out of the first MFMA already in operand layout for the second one — no LDS
-// round trip for P.  The operand that must be contracted over the streamed dimension (V, K, Q, dO) is staged
-// transposed in LDS ([d][64]) so its fragments are two 8-byte reads.
+// round trip for P.  The operand that must be contracted over the streamed dimension (V, K, Q, dO) is read from the SAME
+// row-major LDS tile with the hardware transpose read (ds_read_b64_tr_b16): no transposed copy is staged anywhere.
 // Masked scores take finfo(float).min like the reference's masked_fill, so all-masked rows become uniform.
 #include "common.h"
 #include "mma.h"
@@ -28,21 +28,15 @@ struct AttnP {
 };
 
 // 64 x HDP tile staging helpers (256 threads).  Thread -> (row = id / CPR, 16-byte chunk = id % CPR): the CPR lanes of
-// one row read one contiguous run of HBM (coalesced: a head row of hd=64 bf16 is exactly one 128-byte line).
-// The transposed image [d][64] is XOR-swizzled on the key/query index by the d-block ((d>>3)&7)<<3, which makes the
-// 2-byte scatter writes of a wave (8 rows x 8 chunks) land in distinct banks while keeping every aligned group of 4
-// (and 8) streamed indices contiguous for the 8-byte fragment reads.
-__device__ __forceinline__ int tr_swz(int d) { return ((d >> 3) & 7) << 3; }
-
+// one row read one contiguous run of HBM (coalesced: a head row of hd=64 bf16 is exactly one 128-byte line) and write one
+// padded row-major LDS row (pitch HDP + 8 elements: ds_write_b128 / ds_read_b128 / ds_read_b64_tr_b16 all spread over banks).
 template <typename T, int HDP>
 struct AT {
     static constexpr int VEC = 16 / sizeof(T);
     static constexpr int CPR = HDP / VEC;
     static constexpr int NCH = (64 * CPR) / 256;
     static constexpr int PRM = HDP + VEC;                                   // row-major pitch
-    static constexpr int PTR = 64 + (sizeof(T) == 2 ? 8 : 4);               // transposed pitch
     static constexpr int RM_ELEMS = 64 * PRM;
-    static constexpr int TR_ELEMS = HDP * PTR;
     static_assert((64 * CPR) % 256 == 0, "tile must split over 256 threads");
 
     // `fast` (wave-uniform: 16-byte aligned strides and hd == HDP): unconditional vector loads; rows beyond the
@@ -76,16 +70,6 @@ struct AT {
         for (int i = 0; i < NCH; ++i) {
             const int id = tid + 256 * i;
             *reinterpret_cast<uint4*>(tile + (id / CPR) * PRM + (id % CPR) * VEC) = regs[i];
-        }
-    }
-    static __device__ __forceinline__ void store_tr(const uint4 (&regs)[NCH], T* __restrict__ tile, int tid) {
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int id = tid + 256 * i;
-            const int row = id / CPR, c = (id % CPR) * VEC;
-            const T* e = reinterpret_cast<const T*>(&regs[i]);
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) tile[(c + j) * PTR + (row ^ tr_swz(c + j))] = e[j];
         }
     }
 };
@@ -128,11 +112,19 @@ __device__ __forceinline__ void dot_tile(f32x4 (&x)[4], const T* __restrict__ rm
     }
 }
 
-// acc[dt][r] += sum_{j in tile} tr_tile[dt*16 + g*4 + r][j] * x(j)      with x in accumulator layout:
-// x[nt][r] belongs to streamed index j = nt*16 + g*4 + r of the lane's own column.
+// acc[dt][r] += sum_{j in tile} tile[j][dt*16 + g*4 + r] * x(j)      with x in accumulator layout:
+// x[nt][r] belongs to streamed row j = nt*16 + g*4 + r of the lane's own column.  `rm_tile` is the ROW-MAJOR
+// [64][HDP] LDS image (the same one dot_tile reads): the operand that must be contracted over the streamed dimension
+// (V, K, Q, dO) is fetched with ds_read_b64_tr_b16 — lane i of a 16-lane group addresses row R0 + (i>>2), columns
+// C0 + 4*(i&3).. and receives column C0 + i for rows R0..R0+3 (probe-verified) — so no transposed copy is ever staged.
+typedef short short4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 lds_tr_b16(const bf16_t* p) {
+    typedef __attribute__((address_space(3))) short4_t lds_v4;
+    return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(unsigned)(size_t)p));
+}
 template <typename T, int HDP>
-__device__ __forceinline__ void contract64(f32x4 (&acc)[HDP / 16], const T* __restrict__ tr_tile, const f32x4 (&x)[4], int lane) {
-    constexpr int PTR = AT<T, HDP>::PTR;
+__device__ __forceinline__ void contract64(f32x4 (&acc)[HDP / 16], const T* __restrict__ rm_tile, const f32x4 (&x)[4], int lane) {
+    constexpr int PRM = AT<T, HDP>::PRM;
     const int g = lane >> 4, li = lane & 15;
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
@@ -140,12 +132,11 @@ __device__ __forceinline__ void contract64(f32x4 (&acc)[HDP / 16], const T* __re
             const f32x4 lo = x[2 * ks], hi = x[2 * ks + 1];
             uint4 pk = make_uint4(pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3]), pack_bf2(hi[0], hi[1]), pack_bf2(hi[2], hi[3]));
             const short8 b = __builtin_bit_cast(short8, pk);
+            const bf16_t* base = rm_tile + (ks * 32 + g * 4 + (li >> 2)) * PRM + 4 * (li & 3);
 #pragma unroll
             for (int dt = 0; dt < HDP / 16; ++dt) {
-                const int d = dt * 16 + li, sw = tr_swz(d);
-                const bf16_t* rowp = tr_tile + d * PTR;
-                const uint2 a0 = *reinterpret_cast<const uint2*>(rowp + ((ks * 32 + g * 4) ^ sw));
-                const uint2 a1 = *reinterpret_cast<const uint2*>(rowp + ((ks * 32 + 16 + g * 4) ^ sw));
+                const uint2 a0 = lds_tr_b16(base + dt * 16);                     // rows ks*32 + g*4 .. +3
+                const uint2 a1 = lds_tr_b16(base + 16 * PRM + dt * 16);          // rows ks*32 + 16 + g*4 .. +3
                 const short8 a = __builtin_bit_cast(short8, make_uint4(a0.x, a0.y, a1.x, a1.y));
                 acc[dt] = Mma<bf16_t>::mma(a, b, acc[dt]);
             }
@@ -157,10 +148,8 @@ __device__ __forceinline__ void contract64(f32x4 (&acc)[HDP / 16], const T* __re
             for (int r = 0; r < 4; ++r) {
                 const float b = x[nt][r];
 #pragma unroll
-                for (int dt = 0; dt < HDP / 16; ++dt) {
-                    const int d = dt * 16 + li;
-                    acc[dt] = Mma<float>::mma(tr_tile[d * PTR + ((nt * 16 + g * 4 + r) ^ tr_swz(d))], b, acc[dt]);
-                }
+                for (int dt = 0; dt < HDP / 16; ++dt)
+                    acc[dt] = Mma<float>::mma(rm_tile[(nt * 16 + g * 4 + r) * PRM + dt * 16 + li], b, acc[dt]);
             }
     }
 }
@@ -221,9 +210,9 @@ __device__ __forceinline__ void store_own_row(T* rowp, const f32x4 (&acc)[HDP / 
 // ------------------------------------------------------------------------------------------------ forward
 // LDS stage sizes (bytes) and buffering depth: two stages (one barrier per tile) whenever they fit in 160 KiB with room
 // for >= 2 workgroups per CU, else one stage (two barriers per tile).
-template <typename T, int HDP> struct FwdStage { static constexpr int BYTES = (AT<T, HDP>::RM_ELEMS + AT<T, HDP>::TR_ELEMS) * (int)sizeof(T) + 256; };
-template <typename T, int HDP> struct DkdvStage { static constexpr int BYTES = (2 * AT<T, HDP>::RM_ELEMS + 2 * AT<T, HDP>::TR_ELEMS) * (int)sizeof(T) + 768; };
-template <typename T, int HDP> struct DqStage { static constexpr int BYTES = (2 * AT<T, HDP>::RM_ELEMS + AT<T, HDP>::TR_ELEMS) * (int)sizeof(T) + 256; };
+template <typename T, int HDP> struct FwdStage { static constexpr int BYTES = 2 * AT<T, HDP>::RM_ELEMS * (int)sizeof(T) + 256; };
+template <typename T, int HDP> struct DkdvStage { static constexpr int BYTES = 2 * AT<T, HDP>::RM_ELEMS * (int)sizeof(T) + 768; };
+template <typename T, int HDP> struct DqStage { static constexpr int BYTES = 2 * AT<T, HDP>::RM_ELEMS * (int)sizeof(T) + 256; };
 constexpr int nbuf_for(int stage_bytes) { return 2 * stage_bytes <= 80 * 1024 ? 2 : 1; }
 
 template <typename T, int HDP, bool AM>
@@ -234,8 +223,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     int cur = 0;
     auto KS = [&](int s_) { return reinterpret_cast<T*>(smem_raw + s_ * STAGE); };
-    auto VT = [&](int s_) { return KS(s_) + A::RM_ELEMS; };
-    auto KB = [&](int s_) { return reinterpret_cast<float*>(VT(s_) + A::TR_ELEMS); };   // [64] per-key digest of the staged tile
+    auto VS = [&](int s_) { return KS(s_) + A::RM_ELEMS; };
+    auto KB = [&](int s_) { return reinterpret_cast<float*>(VS(s_) + A::RM_ELEMS); };   // [64] per-key digest of the staged tile
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, li = lane & 15;
     const bool fast = p.vec_ok && p.hd == HDP;
     const int nqb = (int)((p.Sq + 63) / 64);
@@ -273,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
     A::load(rv, vp, p.v_rs, 0, p.Sk, (int)p.hd, fast, tid);
     if (tid < 64) rkb = key_bias(p, b, tid, slope);
     A::store_rm(rk, KS(0), tid);
-    A::store_tr(rv, VT(0), tid);
+    A::store_rm(rv, VS(0), tid);
     if (tid < 64) KB(0)[tid] = rkb;
     __syncthreads();
     const int q_eff = my_q < p.Sq ? (int)my_q : 0;
@@ -332,12 +321,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
             for (int dt = 0; dt < NDT; ++dt) acc[dt] *= alpha;
         }
         m = m_new;
-        contract64<T, HDP>(acc, VT(cur), x, lane);                          // acc[dt][r] = O^T[d][my_q]
+        contract64<T, HDP>(acc, VS(cur), x, lane);                          // acc[dt][r] = O^T[d][my_q]
         if (NBUF == 1) __syncthreads();
         if (t + 1 < ntiles && !(p.dbg & 2)) {
             const int nx = NBUF == 2 ? cur ^ 1 : 0;
             A::store_rm(rk, KS(nx), tid);
-            A::store_tr(rv, VT(nx), tid);
+            A::store_rm(rv, VS(nx), tid);
             if (tid < 64) KB(nx)[tid] = rkb;
             cur = nx;
         }
@@ -407,10 +396,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     int cur = 0;
     auto QS = [&](int s_) { return reinterpret_cast<T*>(smem_raw + s_ * STAGE); };
-    auto QT = [&](int s_) { return QS(s_) + A::RM_ELEMS; };
-    auto GS = [&](int s_) { return QT(s_) + A::TR_ELEMS; };
-    auto GT = [&](int s_) { return GS(s_) + A::RM_ELEMS; };
-    auto ST = [&](int s_) { return reinterpret_cast<float*>(GT(s_) + A::TR_ELEMS); };   // [3][64]: m, 1/l, delta
+    auto GS = [&](int s_) { return QS(s_) + A::RM_ELEMS; };
+    auto ST = [&](int s_) { return reinterpret_cast<float*>(GS(s_) + A::RM_ELEMS); };   // [3][64]: m, 1/l, delta
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, li = lane & 15;
     const bool fast = p.vec_ok && p.hd == HDP;
     const int nkb = (int)((p.Sk + 63) / 64);
@@ -463,8 +450,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
         A::load(rq, qp, p.q_rs, (int64_t)qt_begin * 64, p.Sq, (int)p.hd, fast, tid);
         A::load(rg, gp, p.o_rs, (int64_t)qt_begin * 64, p.Sq, (int)p.hd, fast, tid);
         load_stats(qt_begin);
-        A::store_rm(rq, QS(0), tid); A::store_tr(rq, QT(0), tid);
-        A::store_rm(rg, GS(0), tid); A::store_tr(rg, GT(0), tid);
+        A::store_rm(rq, QS(0), tid);
+        A::store_rm(rg, GS(0), tid);
         if (tid < 192) ST(0)[tid] = rstat;
     }
     __syncthreads();
@@ -512,13 +499,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
             x[nt] = p4;
             y[nt] = d4;
         }
-        contract64<T, HDP>(dv, GT(cur), x, lane);                            // dV^T[d][my_k] += sum_q dO[q][d] P[q][my_k]
-        contract64<T, HDP>(dk, QT(cur), y, lane);                            // dK^T[d][my_k] += sum_q Q[q][d] dS[q][my_k]
+        contract64<T, HDP>(dv, GS(cur), x, lane);                            // dV^T[d][my_k] += sum_q dO[q][d] P[q][my_k]
+        contract64<T, HDP>(dk, QS(cur), y, lane);                            // dK^T[d][my_k] += sum_q Q[q][d] dS[q][my_k]
         if (NBUF == 1) __syncthreads();
         if (t + 1 < qt_end && !(p.dbg & 2)) {
             const int nx = NBUF == 2 ? cur ^ 1 : 0;
-            A::store_rm(rq, QS(nx), tid); A::store_tr(rq, QT(nx), tid);
-            A::store_rm(rg, GS(nx), tid); A::store_tr(rg, GT(nx), tid);
+            A::store_rm(rq, QS(nx), tid);
+            A::store_rm(rg, GS(nx), tid);
             if (tid < 192) ST(nx)[tid] = rstat;
             cur = nx;
         }
@@ -542,8 +529,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     int cur = 0;
     auto KS = [&](int s_) { return reinterpret_cast<T*>(smem_raw + s_ * STAGE); };
-    auto KT = [&](int s_) { return KS(s_) + A::RM_ELEMS; };
-    auto VS = [&](int s_) { return KT(s_) + A::TR_ELEMS; };
+    auto VS = [&](int s_) { return KS(s_) + A::RM_ELEMS; };
     auto KB = [&](int s_) { return reinterpret_cast<float*>(VS(s_) + A::RM_ELEMS); };
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, li = lane & 15;
     const bool fast = p.vec_ok && p.hd == HDP;
@@ -585,7 +571,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
     A::load(rk, kp, p.k_rs, 0, p.Sk, (int)p.hd, fast, tid);
     A::load(rv, vp, p.v_rs, 0, p.Sk, (int)p.hd, fast, tid);
     if (tid < 64) rkb = key_bias(p, b, tid, slope);
-    A::store_rm(rk, KS(0), tid); A::store_tr(rk, KT(0), tid);
+    A::store_rm(rk, KS(0), tid);
     A::store_rm(rv, VS(0), tid);
     if (tid < 64) KB(0)[tid] = rkb;
     __syncthreads();
@@ -623,11 +609,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
             }
             y[nt] = d4;
         }
-        contract64<T, HDP>(dq, KT(cur), y, lane);                            // dQ^T[d][my_q] += sum_key K[key][d] dS[my_q][key]
+        contract64<T, HDP>(dq, KS(cur), y, lane);                            // dQ^T[d][my_q] += sum_key K[key][d] dS[my_q][key]
         if (NBUF == 1) __syncthreads();
         if (t + 1 < ntiles && !(p.dbg & 2)) {
             const int nx = NBUF == 2 ? cur ^ 1 : 0;
-            A::store_rm(rk, KS(nx), tid); A::store_tr(rk, KT(nx), tid);
+            A::store_rm(rk, KS(nx), tid);
             A::store_rm(rv, VS(nx), tid);
             if (tid < 64) KB(nx)[tid] = rkb;
             cur = nx;
