@@ -401,45 +401,55 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
     const int tiles_m = (int)((g.M + BM - 1) / BM);
     const int tiles_n = (int)((g.N + BN - 1) / BN);
     const int ntile = tiles_m * tiles_n;
-    const int nblk = ntile * g.splits;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, q = nblk >> 3, r8 = nblk & 7;
-    const int vid_all = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
-    const int split = vid_all / ntile, vid = vid_all - split * ntile;
+    const int nwork = ntile * g.splits;                                       // work items: (split, output tile)
+    const int bid = blockIdx.x, G = gridDim.x;                                // G == nwork, or a multiple of 8 (persistent)
     constexpr int GM = (WM == 8) ? 4 : 8;
-    const int group = vid / (GM * tiles_n), first_m = group * GM;
-    const int gm = min(GM, tiles_m - first_m);
-    const int in_group = vid - group * GM * tiles_n;
-    const int tm = first_m + in_group % gm, tn = in_group / gm;
-    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
-    const int64_t kbeg = (int64_t)split * g.k_per_split;
-    const int64_t kend = min(g.K, kbeg + g.k_per_split);
-    const int nt = (int)((kend - kbeg) / BK);
+    // work item w -> (split, tile origin).  Items w, w+8, w+16, ... run on one XCD (workgroup b lands on XCD b % 8), so
+    // each XCD gets a CONTIGUOUS range of the grouped tile order and its private L2 sees the operand panels reused.
+    auto decode = [&](int w, int64_t& m0, int64_t& n0, int& split) {
+        const int xcd = w & 7, q = nwork >> 3, r8 = nwork & 7;
+        const int vid_all = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (w >> 3);
+        split = vid_all / ntile;
+        const int vid = vid_all - split * ntile;
+        const int group = vid / (GM * tiles_n), first_m = group * GM;
+        const int gm = min(GM, tiles_m - first_m);
+        const int in_group = vid - group * GM * tiles_n;
+        m0 = (int64_t)(first_m + in_group % gm) * BM;
+        n0 = (int64_t)(in_group / gm) * BN;
+    };
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid / WGN, wc = wid % WGN;
     const T* A = reinterpret_cast<const T*>(g.A);
     const T* B = reinterpret_cast<const T*>(g.B);
-
-    const T* pa[PA];
-    const T* pb[PB];
-#pragma unroll
-    for (int j = 0; j < PA; ++j) pa[j] = TA::src(A, g.lda, m0, g.M, (wid * PA + j) * 64 + lane) + (AK ? kbeg * g.lda : kbeg);
-#pragma unroll
-    for (int j = 0; j < PB; ++j) pb[j] = TB::src(B, g.ldb, n0, g.N, (wid * PB + j) * 64 + lane) + (BKM ? kbeg * g.ldb : kbeg);
     const int64_t astep = AK ? (int64_t)BK * g.lda : BK, bstep = BKM ? (int64_t)BK * g.ldb : BK;
     const unsigned lds0 = (unsigned)(size_t)smem_raw;
 
-    // one DMA piece (j-th of this wave's LOADS per stage) of the NEXT tile; pointers advance
+    // ---- issue side: the DMA stream runs ahead of the MFMA stream by two K-steps and crosses work-item boundaries,
+    // so the first stages of the next output tile land while this tile's last K-steps and its epilogue execute.
+    const T* pa[PA];
+    const T* pb[PB];
+    int wi = bid, ti = 0, nti = 0;                                            // issue-side work item, K-step, K-steps
+    auto setup_issue = [&]() {
+        int64_t m0, n0; int split;
+        decode(wi, m0, n0, split);
+        const int64_t kbeg = (int64_t)split * g.k_per_split;
+        const int64_t kend = min(g.K, kbeg + g.k_per_split);
+        nti = (int)((kend - kbeg) / BK); ti = 0;
+#pragma unroll
+        for (int j = 0; j < PA; ++j) pa[j] = TA::src(A, g.lda, m0, g.M, (wid * PA + j) * 64 + lane) + (AK ? kbeg * g.lda : kbeg);
+#pragma unroll
+        for (int j = 0; j < PB; ++j) pb[j] = TB::src(B, g.ldb, n0, g.N, (wid * PB + j) * 64 + lane) + (BKM ? kbeg * g.ldb : kbeg);
+    };
+    // one DMA piece (j-th of this wave's LOADS per stage) of the stage being issued; pointers advance
     auto issue_one = [&](int stage_buf, int j) {
         const unsigned base = lds0 + stage_buf * STAGE;
         if (j < PA) { glds16(pa[j], base + (wid * PA + j) * 1024); pa[j] += astep; }
         else { const int jb = j - PA; glds16(pb[jb], base + TA::BYTES + (wid * PB + jb) * 1024); pb[jb] += bstep; }
     };
-    auto issue = [&](int stage_buf) {
-#pragma unroll
-        for (int j = 0; j < LOADS; ++j) issue_one(stage_buf, j);
+    auto stage_issued = [&]() {                                               // bookkeeping after a whole stage went out
+        if (++ti == nti) { wi += G; if (wi < nwork) setup_issue(); }
     };
 
     f32x4 acc[WM][4];
@@ -448,45 +458,7 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    issue(0);
-    if (nt > 1) issue(1);
-    int rd = 0, wrb = 2;                                                      // ring positions: read stage, next write stage
-    constexpr int EVERY = (WM * 4) / LOADS;                                   // MFMAs between two DMA issues
-    for (int t = 0; t < nt; ++t) {
-        // my own DMA of tile t has landed once at most the LOADS of tile t+1 are still outstanding
-        if (t + 1 < nt) { if (LOADS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!(g.dbg & 2)) __builtin_amdgcn_s_barrier();                      // everyone's tile t landed; tile t-1 fully consumed
-        const bool more = (t + 2 < nt) && !(g.dbg & 1);
-        const unsigned char* as = smem_raw + rd * STAGE;
-        const unsigned char* bs = as + TA::BYTES;
-        short8 af[WM], bf[4];
-        if (!(g.dbg & 4) || t == 0) {
-#pragma unroll
-            for (int i = 0; i < WM; ++i) af[i] = TA::frag(as, wr * (WM * 16) + i * 16, lane);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bf[j] = TB::frag(bs, wc * 64 + j * 16, lane);
-        }
-        __builtin_amdgcn_s_setprio(1);                                        // MFMA phase outranks the partner wave's DMA / epilogue issue
-        // the DMA issues of tile t+2 are spread between the MFMAs (an LDS-DMA issue costs ~60-180 cycles of the
-        // wave's issue slot; back-to-back they would stall the matrix pipe for a whole K-step)
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[i][j] = Mma<T>::mma(bf[j], af[i], acc[i][j]);
-                constexpr int dummy = 0; (void)dummy;
-                const int idx = i * 4 + j;
-                if (idx % EVERY == EVERY - 1 && idx / EVERY < LOADS) {
-                    if (more) issue_one(wrb, idx / EVERY);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        __builtin_amdgcn_s_setprio(0);
-        rd = rd == NST - 1 ? 0 : rd + 1;
-        wrb = wrb == NST - 1 ? 0 : wrb + 1;
-    }
-
+    auto epilogue = [&](const int64_t m0, const int64_t n0, const int split) {
     // epilogue (same contract as v1): lane holds C[m][n..n+3], m = m0+wr*WM*16+i*16+(lane&15), n = n0+wc*64+j*16+(lane>>4)*4
     if (g.splits > 1) {
         float* S = g.slabs + (int64_t)split * g.M * g.N;
@@ -598,6 +570,70 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
             else { for (int r = 0; r < 4; ++r) if (n + r < g.N) C[off + r] = Cvt<TO>::from_f(v[r]); }
         }
     }
+    };
+
+    setup_issue();
+    int inflight = 0;                                                         // stages issued and not yet consumed
+    int rd = 0, wrb = 0;                                                      // ring positions: read stage, next write stage
+#pragma unroll 1
+    for (int s = 0; s < 2 && wi < nwork; ++s) {
+#pragma unroll
+        for (int j = 0; j < LOADS; ++j) issue_one(wrb, j);
+        stage_issued(); ++inflight; wrb = wrb == NST - 1 ? 0 : wrb + 1;
+    }
+    // ---- compute side
+    int cw = bid, tc = 0, ntc;
+    int64_t m0, n0; int split;
+    decode(cw, m0, n0, split);
+    ntc = (int)((min(g.K, (int64_t)(split + 1) * g.k_per_split) - (int64_t)split * g.k_per_split) / BK);
+    constexpr int EVERY = (WM * 4) / LOADS;                                   // MFMAs between two DMA issues
+    for (;;) {
+        // My DMA of the stage about to be consumed has landed once at most the LOADS of the next stage are still
+        // outstanding (loads retire in order; the epilogue's stores, which are older than that next stage only when
+        // they have to be, are covered by the same count).
+        if (inflight >= 2) { if (LOADS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(g.dbg & 2)) __builtin_amdgcn_s_barrier();                      // everyone's stage landed; the previous one is fully consumed
+        const bool more = (wi < nwork) && !(g.dbg & 1);
+        const unsigned char* as = smem_raw + rd * STAGE;
+        const unsigned char* bs = as + TA::BYTES;
+        short8 af[WM], bf[4];
+        if (!(g.dbg & 4) || tc == 0) {
+#pragma unroll
+            for (int i = 0; i < WM; ++i) af[i] = TA::frag(as, wr * (WM * 16) + i * 16, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = TB::frag(bs, wc * 64 + j * 16, lane);
+        }
+        __builtin_amdgcn_s_setprio(1);                                        // MFMA phase outranks the partner wave's DMA / epilogue issue
+        // the DMA issues of the stage two K-steps ahead are spread between the MFMAs (an LDS-DMA issue costs ~60-180
+        // cycles of the wave's issue slot; back-to-back they would stall the matrix pipe for a whole K-step)
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = Mma<T>::mma(bf[j], af[i], acc[i][j]);
+                const int idx = i * 4 + j;
+                if (idx % EVERY == EVERY - 1 && idx / EVERY < LOADS) {
+                    if (more) issue_one(wrb, idx / EVERY);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        __builtin_amdgcn_s_setprio(0);
+        rd = rd == NST - 1 ? 0 : rd + 1;
+        --inflight;
+        if (more) { stage_issued(); ++inflight; wrb = wrb == NST - 1 ? 0 : wrb + 1; }
+        if (++tc < ntc) continue;
+        epilogue(m0, n0, split);
+        cw += G;
+        if (cw >= nwork) break;
+        decode(cw, m0, n0, split);
+        ntc = (int)((min(g.K, (int64_t)(split + 1) * g.k_per_split) - (int64_t)split * g.k_per_split) / BK);
+        tc = 0;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 }
 
 // C[m,n] = alpha * sum_s slabs[s][m][n] (+ C_old)   — deterministic split-K reduction
@@ -619,7 +655,13 @@ template <typename TO, bool AK, bool BKM, int EPI, int WM, int WGN>
 static void glds_launch(GemmArgs& g, hipStream_t st) {
     constexpr int BM = WM * 32, BN = WGN * 64;
     const size_t lds = 3 * (size_t)(GTile<AK, BM>::BYTES + GTile<BKM, BN>::BYTES);
-    const unsigned grid = (unsigned)(cdiv64(g.M, BM) * cdiv64(g.N, BN) * g.splits);
+    const int64_t nwork = cdiv64(g.M, BM) * cdiv64(g.N, BN) * g.splits;
+    // persistent launch: one resident workgroup per occupancy slot (256 CUs x workgroups that fit a CU's 160 KiB LDS),
+    // each walking work items bid, bid+G, ... with its DMA stream prefetching across item boundaries
+    static int persist = -1;
+    if (persist < 0) { const char* e = getenv("CTMI_GEMM_PERSIST"); persist = e ? atoi(e) : 1; }
+    const int64_t slots = 256 * (int64_t)std::min<size_t>((size_t)(WGN == 4 ? 1 : 8), (160 * 1024) / lds);
+    const unsigned grid = (unsigned)((persist && nwork > slots) ? slots : nwork);
     auto kern = &gemm_glds_kernel<TO, AK, BKM, EPI, WM, WGN>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * WGN), lds, st, g);
