@@ -178,7 +178,7 @@ def main():
                                    f"(BASELINE configs[1]), random-init weights, fp32 master/grads/Adam state",
                        "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}"},
             "final_loss": round(final_loss, 4), "host_enqueue_ms_per_step": round(host_enqueue_ms, 2),
-            "roofline": {"bound": "mfma", "kernel": "gemm_glds_kernel<bf16,NT,256x128> LM-head forward [T,1024]x[250880,1024]^T",
+            "roofline": {"bound": "mfma", "kernel": "gemm_glds_kernel<bf16,NT,256x256 ping-pong> LM-head forward [T,1024]x[250880,1024]^T",
                          "achieved": round(head_tflops, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(head_tflops / PEAK_BF16_TFLOPS, 4), "traffic": _profiled_traffic(),
                          "avg_launch_ms": round(head_avg, 4), "launches": len(head_ms),

@@ -135,7 +135,7 @@ struct GemmArgs {
     int64_t lda, ldb, ldc, M, N, K;
     float alpha; int beta;
     const float* bias; const void* residual; const void* aux_in; void* aux_out;
-    int tiles_m, tiles_n, vec_c;
+    int tiles_m, tiles_n, vec_c, vec8;
     int splits; int64_t k_per_split; float* slabs;        // split-K: partial products go to slabs[s][M][N] (fp32)
     int splitk_ok; float* ws; int64_t ws_bytes;           // split-K permission + caller workspace (the launch path decides)
     int dbg;                                               // timing experiments only (CTMI_GEMM_DBG): 1 = no steady-state DMA, 2 = no barrier, 4 = no LDS reads
@@ -385,17 +385,17 @@ struct GTile {
     }
 };
 
-template <typename TO, bool AK, bool BKM, int EPI, int WM, int WGN>
+template <typename TO, bool AK, bool BKM, int EPI, int WM, int WGN, bool PP = false>
 __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
     using T = bf16_t;
     constexpr int NW = 2 * WGN;                                             // waves: 2 along M x WGN along N
-    constexpr int BM = WM * 32, BN = WGN * 64, BK = 32, NST = 3;
+    constexpr int BM = WM * 32, BN = WGN * 64, BK = 32, NST = PP ? 4 : 3;
     using TA = GTile<AK, BM>;
     using TB = GTile<BKM, BN>;
     constexpr int STAGE = TA::BYTES + TB::BYTES;
     constexpr int PA = TA::NINSTR / NW, PB = TB::NINSTR / NW;               // DMA instructions per wave per stage
     constexpr int LOADS = PA + PB;
-    static_assert(LOADS == 4 || LOADS == 6, "vmcnt immediates below assume 4 or 6 DMA pieces per wave per stage");
+    static_assert(PP ? (LOADS == 3 || LOADS == 4) : (LOADS == 4 || LOADS == 6), "vmcnt immediates below assume these DMA piece counts");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
     const int tiles_m = (int)((g.M + BM - 1) / BM);
@@ -418,12 +418,12 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
         n0 = (int64_t)(in_group / gm) * BN;
     };
 
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63, lane_ = lane;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid / WGN, wc = wid % WGN;
     const T* A = reinterpret_cast<const T*>(g.A);
     const T* B = reinterpret_cast<const T*>(g.B);
-    const int64_t astep = AK ? (int64_t)BK * g.lda : BK, bstep = BKM ? (int64_t)BK * g.ldb : BK;
+    const int64_t astep = (g.dbg & 8) ? 0 : (AK ? (int64_t)BK * g.lda : BK), bstep = (g.dbg & 8) ? 0 : (BKM ? (int64_t)BK * g.ldb : BK);
     const unsigned lds0 = (unsigned)(size_t)smem_raw;
 
     // ---- issue side: the DMA stream runs ahead of the MFMA stream by two K-steps and crosses work-item boundaries,
@@ -459,6 +459,11 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto epilogue = [&](const int64_t m0, const int64_t n0, const int split) {
+        // the lane id is laundered through an empty asm so none of the address arithmetic below is loop-invariant for
+        // hipcc: hoisted out of the persistent tile loop it stayed live across the MFMA loop, spilled, and every reload
+        // (a scratch load: vmcnt) then waited for the stores in front of it
+        int lane = lane_;
+        asm volatile("" : "+v"(lane));
     // epilogue (same contract as v1): lane holds C[m][n..n+3], m = m0+wr*WM*16+i*16+(lane&15), n = n0+wc*64+j*16+(lane>>4)*4
     if (g.splits > 1) {
         float* S = g.slabs + (int64_t)split * g.M * g.N;
@@ -484,6 +489,91 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
     // Interior tiles with aligned pointers (the common case) take a straight-line epilogue: no per-lane bounds test, so
     // hipcc emits no exec-masked branches around the vector loads/stores; edge tiles take the guarded path.
     const bool interior = g.vec_c && (m0 + BM <= g.M) && (n0 + BN <= g.N);
+    if (g.dbg & 16) {                                                        // ablation: keep the accumulators live, store nothing
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[i][j]));
+        return;
+    }
+    if constexpr (PP) {
+        // LDS-shuffled epilogue: the MFMA accumulator layout (lane = one row, 4 columns) makes 8-byte stores that touch
+        // 16 rows per instruction; measured on the LM-head forward those stores cost 26 % of the kernel.  Each wave
+        // instead passes its tile through a private 8 KiB LDS patch as fp32, 32 rows at a time (XOR-swizzled 16-byte
+        // chunks, conflict-free both ways), and reads it back with 8 lanes per row: residual / GELU-input / C loads
+        // and all stores become 16-byte row-contiguous accesses (8 full 128-byte lines per bf16 store instruction).
+        if (interior && g.vec8) {
+            unsigned char* scr = smem_raw + NST * STAGE + wc * 8192;          // the two row groups never overlap in time
+            const int64_t mw = m0 + wr * (WM * 16), nw = n0 + wc * 64;
+            f32x4 bias4[4];
+            if (g.bias != nullptr) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bias4[j] = *reinterpret_cast<const f32x4*>(g.bias + nw + j * 16 + (lane >> 4) * 4);
+            }
+#pragma unroll
+            for (int p = 0; p < WM / 2; ++p) {
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        f32x4 v = acc[p * 2 + ii][j] * g.alpha;
+                        if (g.bias != nullptr) v += bias4[j];
+                        const int row = ii * 16 + (lane & 15), c = j * 4 + (lane >> 4);
+                        *reinterpret_cast<f32x4*>(scr + row * 256 + ((c ^ (row & 15)) << 4)) = v;
+                    }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int row = it * 8 + (lane >> 3), c0 = (lane & 7) * 2;
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(scr + row * 256 + ((c0 ^ (row & 15)) << 4));
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(scr + row * 256 + (((c0 ^ (row & 15)) ^ 1) << 4));
+                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    const int64_t off = (mw + p * 32 + row) * g.ldc + nw + (lane & 7) * 8;
+                    if (EPI == CTMI_EPI_GELU) {
+                        const uint4 tb = pack16<T>(v);
+                        *reinterpret_cast<uint4*>(AUXO + off) = tb;
+                        unpack16<T>(tb, v);
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] = gelu_tanh_f(v[r]);
+                    } else if (EPI == CTMI_EPI_RELU) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+                    } else if (EPI == CTMI_EPI_DGELU || EPI == CTMI_EPI_DRELU) {
+                        float u[8];
+                        unpack16<T>(*reinterpret_cast<const uint4*>(AUXI + off), u);
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] = (EPI == CTMI_EPI_DGELU) ? v[r] * gelu_tanh_grad_f(u[r]) : (u[r] > 0.f ? v[r] : 0.f);
+                    }
+                    if (R != nullptr) {
+                        float u[8];
+                        unpack16<T>(*reinterpret_cast<const uint4*>(R + off), u);
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] += u[r];
+                    }
+                    if constexpr (sizeof(TO) == 4) {
+                        float* Cf = reinterpret_cast<float*>(C) + off;
+                        if (g.beta) {
+                            const f32x4 c0v = *reinterpret_cast<const f32x4*>(Cf), c1v = *reinterpret_cast<const f32x4*>(Cf + 4);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { v[r] += c0v[r]; v[4 + r] += c1v[r]; }
+                        }
+                        *reinterpret_cast<f32x4*>(Cf) = f32x4{v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(Cf + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                    } else {
+                        if (g.beta) {
+                            float u[8];
+                            unpack16<T>(*reinterpret_cast<const uint4*>(C + off), u);
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) v[r] += u[r];
+                        }
+                        *reinterpret_cast<uint4*>(C + off) = pack16<T>(v);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);                             // one pass at a time: keeps the live set at acc + one pass
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // patch reads retired before the other row group may write it
+            return;
+        }
+    }
     if (interior) {
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
@@ -575,6 +665,79 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
     setup_issue();
     int inflight = 0;                                                         // stages issued and not yet consumed
     int rd = 0, wrb = 0;                                                      // ring positions: read stage, next write stage
+    if constexpr (PP) {
+        // ---- ping-pong schedule (8 waves, one workgroup per CU).  Every SIMD holds one wave of row-group wr = 0 and one
+        // of wr = 1; group 1 runs one barrier behind group 0, so while one group's 32 MFMAs own the matrix pipe the
+        // other group reads its fragments from LDS and issues its LDS-DMA pieces.  Two barriers per K-step:
+        //   phase A: ds_read fragments of stage c | DMA-issue stage c+3 | wait own pieces of stage c+1 | lgkmcnt(0)
+        //   phase B: MFMA
+        // RAW: a stage is read one full K-step after every wave's counted wait for it (the lagging group's wait
+        // precedes the barrier the leading group passes before reading).  WAR: stage c+3 reuses the slot of stage c-1,
+        // whose last reads (lagging group, phase A of c-1) were retired by lgkmcnt(0) before the barrier in between.
+        auto wait_stages = [&](int n) {                                       // allow n younger stages to stay in flight
+            if (n >= 2) { if (LOADS == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+            else if (n == 1) { if (LOADS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+#pragma unroll 1
+        for (int s = 0; s < 3 && wi < nwork; ++s) {
+#pragma unroll
+            for (int j = 0; j < LOADS; ++j) issue_one(wrb, j);
+            stage_issued(); ++inflight; wrb = wrb == NST - 1 ? 0 : wrb + 1;
+        }
+        wait_stages(inflight - 1);
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();                            // stagger the two row groups by one phase
+        int cw = bid, tc = 0, ntc;
+        int64_t m0, n0; int split;
+        decode(cw, m0, n0, split);
+        ntc = (int)((min(g.K, (int64_t)(split + 1) * g.k_per_split) - (int64_t)split * g.k_per_split) / BK);
+        for (;;) {
+            const unsigned char* as = smem_raw + rd * STAGE;
+            const unsigned char* bs = as + TA::BYTES;
+            short8 af[WM], bf[4];
+            if (!(g.dbg & 4) || tc == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bf[j] = TB::frag(bs, wc * 64 + j * 16, lane);
+#pragma unroll
+                for (int i = 0; i < WM; ++i) af[i] = TA::frag(as, wr * (WM * 16) + i * 16, lane);
+            }
+            if (wi < nwork && !(g.dbg & 1)) {
+#pragma unroll
+                for (int j = 0; j < LOADS; ++j) issue_one(wrb, j);
+                stage_issued(); ++inflight; wrb = wrb == NST - 1 ? 0 : wrb + 1;
+            }
+            wait_stages(inflight - 2);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(bf[j], af[i], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            rd = rd == NST - 1 ? 0 : rd + 1;
+            --inflight;
+            if (++tc < ntc) continue;
+            epilogue(m0, n0, split);
+            cw += G;
+            if (cw >= nwork) break;
+            decode(cw, m0, n0, split);
+            ntc = (int)((min(g.K, (int64_t)(split + 1) * g.k_per_split) - (int64_t)split * g.k_per_split) / BK);
+            tc = 0;
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();
+        return;
+    }
 #pragma unroll 1
     for (int s = 0; s < 2 && wi < nwork; ++s) {
 #pragma unroll
@@ -651,10 +814,10 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ s
     }
 }
 
-template <typename TO, bool AK, bool BKM, int EPI, int WM, int WGN>
+template <typename TO, bool AK, bool BKM, int EPI, int WM, int WGN, bool PP = false>
 static void glds_launch(GemmArgs& g, hipStream_t st) {
     constexpr int BM = WM * 32, BN = WGN * 64;
-    const size_t lds = 3 * (size_t)(GTile<AK, BM>::BYTES + GTile<BKM, BN>::BYTES);
+    const size_t lds = (PP ? 4 : 3) * (size_t)(GTile<AK, BM>::BYTES + GTile<BKM, BN>::BYTES) + (PP ? 4 * 8192 : 0);   // PP: + epilogue patches
     const int64_t nwork = cdiv64(g.M, BM) * cdiv64(g.N, BN) * g.splits;
     // persistent launch: one resident workgroup per occupancy slot (256 CUs x workgroups that fit a CU's 160 KiB LDS),
     // each walking work items bid, bid+G, ... with its DMA stream prefetching across item boundaries
@@ -662,32 +825,37 @@ static void glds_launch(GemmArgs& g, hipStream_t st) {
     if (persist < 0) { const char* e = getenv("CTMI_GEMM_PERSIST"); persist = e ? atoi(e) : 1; }
     const int64_t slots = 256 * (int64_t)std::min<size_t>((size_t)(WGN == 4 ? 1 : 8), (160 * 1024) / lds);
     const unsigned grid = (unsigned)((persist && nwork > slots) ? slots : nwork);
-    auto kern = &gemm_glds_kernel<TO, AK, BKM, EPI, WM, WGN>;
+    auto kern = &gemm_glds_kernel<TO, AK, BKM, EPI, WM, WGN, PP>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * WGN), lds, st, g);
 }
 
-// tile / split choice for the LDS-DMA path: 0 = 128x128 (4 waves, 3 workgroups/CU), 1 = 256x128 (4 waves, 2/CU),
-// 2 = 256x256 (8 waves, 1/CU).  Rules distilled from tools/microbench.py sweeps of every Bloom-560M shape on MI355X
-// (profiles/r01_gemm_tile_sweep.txt): big tiles win only when they still give >= 2 full rounds of workgroups; outputs of
-// [T,1024] run best on 128x128 without split-K; weight gradients (both operands K-major, K = T) want ~512+ workgroups
-// via deterministic split-K; the one very-long-K product (LM-head dgrad, K = V) takes 256x256 with a 2-way split.
-static void pick_tile(int64_t M, int64_t N, int64_t K, bool wgrad, int max_splits, int& tile, int& splits) {
+// tile / split choice for the LDS-DMA path:
+//   0 = 128x128 (4 waves, 3 workgroups/CU)   1 = 256x128 (4 waves, 2/CU)   2 = 256x256 (8 waves, 1/CU, free-running)
+//   3 = 256x256 ping-pong (8 waves, 1/CU)    4 = 128x256 ping-pong
+// Rules distilled from tools/microbench.py sweeps of every Bloom-560M shape on MI355X (profiles/r01_gemm_tile_sweep.txt):
+// the ping-pong schedule wins whenever its tiles fill the 256 CUs (>= ~1.4 rounds of 256x256, or one full round of
+// 128x256 for [T,1024] outputs); row-major-B dgrads with long K and the layer weight gradients (both operands K-major,
+// K = T, ~512+ workgroups via deterministic split-K) stay on the free-running tiles; the very-long-K LM-head dgrad
+// (K = V) takes ping-pong 256x256 with a 2-way split.
+static void pick_tile(int64_t M, int64_t N, int64_t K, bool wgrad, bool bkm, int max_splits, int& tile, int& splits) {
     static int force = -2, force_split = -2;
     if (force == -2) { const char* e = getenv("CTMI_GEMM_TILE"); force = e ? atoi(e) : -1; }
     if (force_split == -2) { const char* e = getenv("CTMI_GEMM_SPLIT"); force_split = e ? atoi(e) : -1; }
     if (force_split >= 1) max_splits = std::min(max_splits, force_split);
     const int64_t t0 = cdiv64(M, 128) * cdiv64(N, 128), t1 = cdiv64(M, 256) * cdiv64(N, 128), t2 = cdiv64(M, 256) * cdiv64(N, 256);
+    const int64_t t4 = cdiv64(M, 128) * cdiv64(N, 256);
     tile = 0; splits = 1;
     if (wgrad) {
-        if (t1 >= 1024) tile = 1;                                   // LM head: [V,H]
+        if (t1 >= 1024) tile = 3;                                   // LM head: [V,H]
         else {
             tile = t1 >= 128 ? 1 : 0;
             const int64_t tiles = tile ? t1 : t0;
             while (splits < max_splits && tiles * splits < 512 && K / (splits * 2) >= 1024) splits *= 2;
         }
-    } else if (K >= 32768 && max_splits >= 2 && t2 * 2 >= 192) { tile = 2; splits = 2; }
-    else if (t2 >= 512) tile = 2;
+    } else if (K >= 32768 && max_splits >= 2 && t2 * 2 >= 192) { tile = 3; splits = 2; }
+    else if (t2 >= 350) tile = 3;
+    else if (t4 >= 256 && (!bkm || K <= 1024)) tile = 4;
     else if (t1 >= 700) tile = 1;
     else tile = 0;
     if (force >= 0) tile = force;
@@ -710,14 +878,16 @@ static int gemm_launch(GemmArgs& g, bool fast, hipStream_t st) {
             int tile, splits;
             const int64_t slab = g.M * g.N * (int64_t)sizeof(float);
             const int max_sp = g.splitk_ok ? (int)std::max<int64_t>(1, std::min<int64_t>(8, g.ws_bytes / std::max<int64_t>(slab, 1))) : 1;
-            pick_tile(g.M, g.N, g.K, AK && BKM, max_sp, tile, splits);
+            pick_tile(g.M, g.N, g.K, AK && BKM, BKM, max_sp, tile, splits);
             g.splits = 1; g.k_per_split = g.K; g.slabs = nullptr;
             if (splits > 1) {
                 const int64_t kps = cdiv64(cdiv64(g.K, splits), 64) * 64;
                 const int sp = (int)cdiv64(g.K, kps);
                 if (sp > 1) { g.splits = sp; g.k_per_split = kps; g.slabs = g.ws; }
             }
-            if (tile == 2) glds_launch<TO, AK, BKM, EPI, 8, 4>(g, st);
+            if (tile == 3) glds_launch<TO, AK, BKM, EPI, 8, 4, true>(g, st);
+            else if (tile == 4) glds_launch<TO, AK, BKM, EPI, 4, 4, true>(g, st);
+            else if (tile == 2) glds_launch<TO, AK, BKM, EPI, 8, 4>(g, st);
             else if (tile == 1) glds_launch<TO, AK, BKM, EPI, 8, 2>(g, st);
             else glds_launch<TO, AK, BKM, EPI, 4, 2>(g, st);
             CTMI_CHECK_LAUNCH("gemm_glds");
@@ -806,6 +976,7 @@ extern "C" int ctmi_gemm(const void* A, int64_t lda, int a_kmajor, const void* B
     auto al = [](const void* p, int bytes) { return p == nullptr || ((((uintptr_t)p) & (bytes - 1)) == 0); };
     const int cbytes = (out_f32 || dtype == CTMI_F32) ? 16 : 8;
     g.vec_c = (ldc % 4 == 0) && al(C, cbytes) && al(residual, 4 * es) && al(aux_in, 4 * es) && al(aux_out, 4 * es) && al(bias, 16);
+    g.vec8 = g.vec_c && (ldc % 8 == 0) && al(C, 16) && al(residual, 16) && al(aux_in, 16) && al(aux_out, 16);   // 8-element rows (LDS-shuffled epilogue)
     // split-K: only for plain accumulations (weight gradients) that would leave most of the 256 CUs idle
     g.splits = 1; g.k_per_split = K; g.slabs = nullptr;
     g.splitk_ok = (workspace != nullptr && epilogue == CTMI_EPI_NONE && bias == nullptr && residual == nullptr) ? 1 : 0;
