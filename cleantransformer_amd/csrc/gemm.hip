@@ -136,11 +136,13 @@ struct GemmArgs {
     float alpha; int beta;
     const float* bias; const void* residual; const void* aux_in; void* aux_out;
     int tiles_m, tiles_n, vec_c, vec8;
+    int nt_c;                                              // C is far larger than the 256 MiB Infinity Cache: write it non-temporally
     int splits; int64_t k_per_split; float* slabs;        // split-K: partial products go to slabs[s][M][N] (fp32)
     int splitk_ok; float* ws; int64_t ws_bytes;           // split-K permission + caller workspace (the launch path decides)
     int dbg;                                               // timing experiments only (CTMI_GEMM_DBG): 1 = no steady-state DMA, 2 = no barrier, 4 = no LDS reads
 };
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <typename TO> __device__ __forceinline__ void store4(TO* p, const float* v);
 template <> __device__ __forceinline__ void store4<float>(float* p, const float* v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
 template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float* v) { *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])); }
@@ -565,7 +567,12 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
 #pragma unroll
                             for (int r = 0; r < 8; ++r) v[r] += u[r];
                         }
-                        *reinterpret_cast<uint4*>(C + off) = pack16<T>(v);
+                        const uint4 pk = pack16<T>(v);
+                        // logits-sized outputs (>> the 256 MiB Infinity Cache) are written non-temporally so they do not
+                        // push the operand panels out of L2; asm because hipcc merges a plain and a nontemporal store
+                        // to one address into one plain store
+                        if (g.nt_c) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(C + off), "v"(__builtin_bit_cast(u32x4, pk)) : "memory");
+                        else *reinterpret_cast<uint4*>(C + off) = pk;
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);                             // one pass at a time: keeps the live set at acc + one pass
@@ -976,6 +983,9 @@ extern "C" int ctmi_gemm(const void* A, int64_t lda, int a_kmajor, const void* B
     auto al = [](const void* p, int bytes) { return p == nullptr || ((((uintptr_t)p) & (bytes - 1)) == 0); };
     const int cbytes = (out_f32 || dtype == CTMI_F32) ? 16 : 8;
     g.vec_c = (ldc % 4 == 0) && al(C, cbytes) && al(residual, 4 * es) && al(aux_in, 4 * es) && al(aux_out, 4 * es) && al(bias, 16);
+    static int nt_on = -1;
+    if (nt_on < 0) { const char* e = getenv("CTMI_GEMM_NT"); nt_on = e ? atoi(e) : 1; }
+    g.nt_c = nt_on && (M * N * (int64_t)((out_f32 || dtype == CTMI_F32) ? 4 : 2) > (1LL << 30)) ? 1 : 0;
     g.vec8 = g.vec_c && (ldc % 8 == 0) && al(C, 16) && al(residual, 16) && al(aux_in, 16) && al(aux_out, 16);   // 8-element rows (LDS-shuffled epilogue)
     // split-K: only for plain accumulations (weight gradients) that would leave most of the 256 CUs idle
     g.splits = 1; g.k_per_split = K; g.slabs = nullptr;
