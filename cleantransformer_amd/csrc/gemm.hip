@@ -450,6 +450,30 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
         if (j < PA) { glds16(pa[j], base + (wid * PA + j) * 1024); pa[j] += astep; }
         else { const int jb = j - PA; glds16(pb[jb], base + TA::BYTES + (wid * PB + jb) * 1024); pb[jb] += bstep; }
     };
+    // all pieces of one stage in ONE statement: M0 saved/restored once, the second piece of each operand reached by
+    // bumping M0 (the ping-pong schedule issues a stage back-to-back, so the SALU traffic around each DMA matters)
+    auto issue_stage = [&](int stage_buf) {
+        const unsigned da = lds0 + stage_buf * STAGE + wid * PA * 1024, db = lds0 + stage_buf * STAGE + TA::BYTES + wid * PB * 1024;
+        unsigned keep;
+        static_assert(!PP || (PB == 2 && (PA == 1 || PA == 2)), "issue_stage handles 1-2 A pieces and 2 B pieces per wave");
+        if constexpr (!PP) { (void)da; (void)db; (void)keep; }
+        else if constexpr (PA == 2) {
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+                         "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(pa[0]), "v"(pa[1]), "v"(pb[0]), "v"(pb[1]), "s"(da), "s"(db) : "memory", "scc");
+        } else {
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                         "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(pa[0]), "v"(pb[0]), "v"(pb[1]), "s"(da), "s"(db) : "memory", "scc");
+        }
+#pragma unroll
+        for (int j = 0; j < PA; ++j) pa[j] += astep;
+#pragma unroll
+        for (int j = 0; j < PB; ++j) pb[j] += bstep;
+    };
     auto stage_issued = [&]() {                                               // bookkeeping after a whole stage went out
         if (++ti == nti) { wi += G; if (wi < nwork) setup_issue(); }
     };
@@ -688,8 +712,7 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
         };
 #pragma unroll 1
         for (int s = 0; s < 3 && wi < nwork; ++s) {
-#pragma unroll
-            for (int j = 0; j < LOADS; ++j) issue_one(wrb, j);
+            issue_stage(wrb);
             stage_issued(); ++inflight; wrb = wrb == NST - 1 ? 0 : wrb + 1;
         }
         wait_stages(inflight - 1);
@@ -710,8 +733,7 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
                 for (int i = 0; i < WM; ++i) af[i] = TA::frag(as, wr * (WM * 16) + i * 16, lane);
             }
             if (wi < nwork && !(g.dbg & 1)) {
-#pragma unroll
-                for (int j = 0; j < LOADS; ++j) issue_one(wrb, j);
+                issue_stage(wrb);
                 stage_issued(); ++inflight; wrb = wrb == NST - 1 ? 0 : wrb + 1;
             }
             wait_stages(inflight - 2);
