@@ -71,19 +71,26 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---------------------------------------------------------------- math
-// tanh via one v_exp_f32 + one reciprocal: tanh(|a|) = (1 - e) / (1 + e), e = exp(-2|a|)  (abs error ~1e-7; the libm
-// tanhf is ~40 instructions and doubled the time of the GELU-epilogue GEMMs)
-__device__ __forceinline__ float fast_tanh(float a) {
-    const float e = __expf(-2.0f * fabsf(a));
-    return copysignf(__fdividef(1.0f - e, 1.0f + e), a);
+// GELU(tanh) through the logistic form: 0.5 * (1 + tanh(a)) == sigma(2a), a = 0.79788456 x (1 + 0.044715 x^2), so
+//   gelu(x)  = x * s                                   (modeling_bloom.py:344)
+//   gelu'(x) = s * (1 + x (1 - s) (2*0.79788456 + 2*0.1070322243 x^2))   (modeling_bloom.py:360-362, same algebra)
+// with s = 1 / (1 + 2^z), z = -x (c1 + c2 x^2), c1 = 2*0.79788456*log2(e), c2 = 0.044715 c1: one v_exp_f32 and one
+// v_rcp_f32 per element (abs error ~1e-7) and about half the VALU work of the tanh form; the f32x2 versions compile to
+// v_pk_mul/fma/add_f32.  The GEMM epilogues that apply them are not hidden behind MFMA work, so their length matters.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_sigma_pk(f32x2 x, f32x2 x2) {
+    const f32x2 z = -x * (x2 * 0.10294324f + 2.3022082f);
+    const f32x2 d = f32x2{__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])} + 1.0f;
+    return f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
 }
-__device__ __forceinline__ float gelu_tanh_f(float x) {            // modeling_bloom.py:344
-    return x * 0.5f * (1.0f + fast_tanh(0.79788456f * x * (1.0f + 0.044715f * x * x)));
+__device__ __forceinline__ f32x2 gelu_tanh_pk(f32x2 x) { return x * gelu_sigma_pk(x, x * x); }
+__device__ __forceinline__ f32x2 gelu_tanh_grad_pk(f32x2 x) {
+    const f32x2 x2 = x * x;
+    const f32x2 s = gelu_sigma_pk(x, x2);
+    return s * (x * (1.0f - s) * (x2 * 0.21406445f + 1.5957691f) + 1.0f);
 }
-__device__ __forceinline__ float gelu_tanh_grad_f(float x) {       // modeling_bloom.py:360-362
-    float t = fast_tanh(0.79788456f * x * (1.0f + 0.044715f * x * x));
-    return 0.5f * x * ((1.0f - t * t) * (0.79788456f + 0.1070322243f * x * x)) + 0.5f * (1.0f + t);
-}
+__device__ __forceinline__ float gelu_tanh_f(float x) { return gelu_tanh_pk(f32x2{x, x})[0]; }
+__device__ __forceinline__ float gelu_tanh_grad_f(float x) { return gelu_tanh_grad_pk(f32x2{x, x})[0]; }
 
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

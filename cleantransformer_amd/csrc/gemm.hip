@@ -387,7 +387,7 @@ struct GTile {
     }
 };
 
-template <typename TO, bool AK, bool BKM, int EPI, int WM, int WGN, bool PP = false>
+template <typename TO, bool AK, bool BKM, int EPI, int WM, int WGN, bool PP = false, bool RES = false>
 __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
     using T = bf16_t;
     constexpr int NW = 2 * WGN;                                             // waves: 2 along M x WGN along N
@@ -536,6 +536,23 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) bias4[j] = *reinterpret_cast<const f32x4*>(g.bias + nw + j * 16 + (lane >> 4) * 4);
             }
+            // the side input of a pass (GELU-derivative input, or the residual rows when the kernel is instantiated with
+            // RES) is fetched one pass ahead, into the registers the previous pass's accumulators just freed: loaded
+            // where it is used, each of the 16 row groups of a tile would expose a full global-load latency
+            // (only the 128-row tiles have the registers for it: with 128 accumulators live hipcc spills the prefetch)
+            constexpr bool PRE_AUX = (EPI == CTMI_EPI_DGELU || EPI == CTMI_EPI_DRELU) && WM == 4;
+            constexpr bool PRE_RES = RES && !PRE_AUX && WM == 4;
+            constexpr bool PRE = PRE_AUX || PRE_RES;
+            const T* side = PRE_AUX ? AUXI : R;
+            uint4 pre[2][PRE ? 4 : 1];
+            auto prefetch = [&](int p, int slot) {
+                if constexpr (PRE) {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it)
+                        pre[slot][it] = *reinterpret_cast<const uint4*>(side + (mw + p * 32 + it * 8 + (lane >> 3)) * g.ldc + nw + (lane & 7) * 8);
+                }
+            };
+            prefetch(0, 0);
 #pragma unroll
             for (int p = 0; p < WM / 2; ++p) {
 #pragma unroll
@@ -547,6 +564,8 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
                         const int row = ii * 16 + (lane & 15), c = j * 4 + (lane >> 4);
                         *reinterpret_cast<f32x4*>(scr + row * 256 + ((c ^ (row & 15)) << 4)) = v;
                     }
+                __builtin_amdgcn_sched_barrier(0);                             // the next pass's inputs go into the registers these accumulators just freed
+                if (p + 1 < WM / 2) prefetch(p + 1, (p + 1) & 1);
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int row = it * 8 + (lane >> 3), c0 = (lane & 7) * 2;
@@ -559,19 +578,26 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
                         *reinterpret_cast<uint4*>(AUXO + off) = tb;
                         unpack16<T>(tb, v);
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) v[r] = gelu_tanh_f(v[r]);
+                        for (int r = 0; r < 8; r += 2) { const f32x2 y = gelu_tanh_pk(f32x2{v[r], v[r + 1]}); v[r] = y[0]; v[r + 1] = y[1]; }
                     } else if (EPI == CTMI_EPI_RELU) {
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
                     } else if (EPI == CTMI_EPI_DGELU || EPI == CTMI_EPI_DRELU) {
                         float u[8];
-                        unpack16<T>(*reinterpret_cast<const uint4*>(AUXI + off), u);
+                        if constexpr (PRE_AUX) unpack16<T>(pre[p & 1][it], u);
+                        else unpack16<T>(*reinterpret_cast<const uint4*>(AUXI + off), u);
+                        if (EPI == CTMI_EPI_DGELU) {
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) v[r] = (EPI == CTMI_EPI_DGELU) ? v[r] * gelu_tanh_grad_f(u[r]) : (u[r] > 0.f ? v[r] : 0.f);
+                            for (int r = 0; r < 8; r += 2) { const f32x2 y = f32x2{v[r], v[r + 1]} * gelu_tanh_grad_pk(f32x2{u[r], u[r + 1]}); v[r] = y[0]; v[r + 1] = y[1]; }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) v[r] = u[r] > 0.f ? v[r] : 0.f;
+                        }
                     }
-                    if (R != nullptr) {
+                    if (PRE_RES || R != nullptr) {
                         float u[8];
-                        unpack16<T>(*reinterpret_cast<const uint4*>(R + off), u);
+                        if constexpr (PRE_RES) unpack16<T>(pre[p & 1][it], u);
+                        else unpack16<T>(*reinterpret_cast<const uint4*>(R + off), u);
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] += u[r];
                     }
@@ -843,7 +869,7 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ s
     }
 }
 
-template <typename TO, bool AK, bool BKM, int EPI, int WM, int WGN, bool PP = false>
+template <typename TO, bool AK, bool BKM, int EPI, int WM, int WGN, bool PP = false, bool RES = false>
 static void glds_launch(GemmArgs& g, hipStream_t st) {
     constexpr int BM = WM * 32, BN = WGN * 64;
     const size_t lds = (PP ? 4 : 3) * (size_t)(GTile<AK, BM>::BYTES + GTile<BKM, BN>::BYTES) + (PP ? 4 * 8192 : 0);   // PP: + epilogue patches
@@ -854,7 +880,7 @@ static void glds_launch(GemmArgs& g, hipStream_t st) {
     if (persist < 0) { const char* e = getenv("CTMI_GEMM_PERSIST"); persist = e ? atoi(e) : 1; }
     const int64_t slots = 256 * (int64_t)std::min<size_t>((size_t)(WGN == 4 ? 1 : 8), (160 * 1024) / lds);
     const unsigned grid = (unsigned)((persist && nwork > slots) ? slots : nwork);
-    auto kern = &gemm_glds_kernel<TO, AK, BKM, EPI, WM, WGN, PP>;
+    auto kern = &gemm_glds_kernel<TO, AK, BKM, EPI, WM, WGN, PP, RES>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * WGN), lds, st, g);
 }
@@ -867,7 +893,7 @@ static void glds_launch(GemmArgs& g, hipStream_t st) {
 // 128x256 for [T,1024] outputs); row-major-B dgrads with long K and the layer weight gradients (both operands K-major,
 // K = T, ~512+ workgroups via deterministic split-K) stay on the free-running tiles; the very-long-K LM-head dgrad
 // (K = V) takes ping-pong 256x256 with a 2-way split.
-static void pick_tile(int64_t M, int64_t N, int64_t K, bool wgrad, bool bkm, int max_splits, int& tile, int& splits) {
+static void pick_tile(int64_t M, int64_t N, int64_t K, bool wgrad, bool bkm, int epi, int max_splits, int& tile, int& splits) {
     static int force = -2, force_split = -2;
     if (force == -2) { const char* e = getenv("CTMI_GEMM_TILE"); force = e ? atoi(e) : -1; }
     if (force_split == -2) { const char* e = getenv("CTMI_GEMM_SPLIT"); force_split = e ? atoi(e) : -1; }
@@ -876,7 +902,10 @@ static void pick_tile(int64_t M, int64_t N, int64_t K, bool wgrad, bool bkm, int
     const int64_t t4 = cdiv64(M, 128) * cdiv64(N, 256);
     tile = 0; splits = 1;
     if (wgrad) {
+        static int nosplit = -1;
+        if (nosplit < 0) { const char* e = getenv("CTMI_WGRAD_NOSPLIT"); nosplit = e ? atoi(e) : 0; }
         if (t1 >= 1024) tile = 3;                                   // LM head: [V,H]
+        else if (nosplit) tile = nosplit == 2 ? 4 : 3;
         else {
             tile = t1 >= 128 ? 1 : 0;
             const int64_t tiles = tile ? t1 : t0;
@@ -887,6 +916,9 @@ static void pick_tile(int64_t M, int64_t N, int64_t K, bool wgrad, bool bkm, int
     else if (t4 >= 256 && (!bkm || K <= 1024)) tile = 4;
     else if (t1 >= 700) tile = 1;
     else tile = 0;
+    static int aux_tile = -2;
+    if (aux_tile == -2) { const char* e = getenv("CTMI_GEMM_AUX_TILE"); aux_tile = e ? atoi(e) : -1; }
+    if (aux_tile >= 0 && (epi == CTMI_EPI_DGELU || epi == CTMI_EPI_DRELU) && tile == 3) tile = aux_tile;
     if (force >= 0) tile = force;
 }
 
@@ -907,15 +939,19 @@ static int gemm_launch(GemmArgs& g, bool fast, hipStream_t st) {
             int tile, splits;
             const int64_t slab = g.M * g.N * (int64_t)sizeof(float);
             const int max_sp = g.splitk_ok ? (int)std::max<int64_t>(1, std::min<int64_t>(8, g.ws_bytes / std::max<int64_t>(slab, 1))) : 1;
-            pick_tile(g.M, g.N, g.K, AK && BKM, BKM, max_sp, tile, splits);
+            pick_tile(g.M, g.N, g.K, AK && BKM, BKM, EPI, max_sp, tile, splits);
             g.splits = 1; g.k_per_split = g.K; g.slabs = nullptr;
             if (splits > 1) {
                 const int64_t kps = cdiv64(cdiv64(g.K, splits), 64) * 64;
                 const int sp = (int)cdiv64(g.K, kps);
                 if (sp > 1) { g.splits = sp; g.k_per_split = kps; g.slabs = g.ws; }
             }
-            if (tile == 3) glds_launch<TO, AK, BKM, EPI, 8, 4, true>(g, st);
-            else if (tile == 4) glds_launch<TO, AK, BKM, EPI, 4, 4, true>(g, st);
+            constexpr bool CAN_RES = (EPI == CTMI_EPI_NONE) && !AK && sizeof(TO) == 2;      // residual-prefetching instantiations
+            const bool res = CAN_RES && g.residual != nullptr;
+            if (tile == 3) { if constexpr (CAN_RES) { if (res) glds_launch<TO, AK, BKM, EPI, 8, 4, true, true>(g, st); else glds_launch<TO, AK, BKM, EPI, 8, 4, true>(g, st); }
+                             else glds_launch<TO, AK, BKM, EPI, 8, 4, true>(g, st); }
+            else if (tile == 4) { if constexpr (CAN_RES) { if (res) glds_launch<TO, AK, BKM, EPI, 4, 4, true, true>(g, st); else glds_launch<TO, AK, BKM, EPI, 4, 4, true>(g, st); }
+                                  else glds_launch<TO, AK, BKM, EPI, 4, 4, true>(g, st); }
             else if (tile == 2) glds_launch<TO, AK, BKM, EPI, 8, 4>(g, st);
             else if (tile == 1) glds_launch<TO, AK, BKM, EPI, 8, 2>(g, st);
             else glds_launch<TO, AK, BKM, EPI, 4, 2>(g, st);
