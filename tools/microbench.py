@@ -44,6 +44,9 @@ def bench_gemm(T=8192):
         it = 3 if N == V else 10
         t = timeit(lambda: ops.linear_fwd(x, w, None), it)
         print(f"{name:8s} fwd   M={T} N={N} K={K}: {t:8.3f} ms  {fl / t / 1e9:8.1f} TF/s")
+        if os.environ.get("MB_FWD_ONLY"):
+            del x, w, dy
+            continue
         t = timeit(lambda: ops.linear_dgrad(dy, w), it)
         print(f"{name:8s} dgrad M={T} N={K} K={N}: {t:8.3f} ms  {fl / t / 1e9:8.1f} TF/s")
         t = timeit(lambda: ops.linear_wgrad(dy, x), it)

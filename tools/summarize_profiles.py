@@ -1,0 +1,63 @@
+"""Turn the raw rocprofv3 CSVs of tools/collect_profiles.sh into the small summaries committed under profiles/.
+
+usage: python tools/summarize_profiles.py gpurun_out/evidence profiles r01
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+src, dst, rnd = sys.argv[1], sys.argv[2], sys.argv[3]
+LM = "gemm_glds_kernel<unsigned short, false, false, 0, 8, 4, true, false>"     # bf16 NT, no epilogue, 256x256 ping-pong
+
+
+def one(pattern):
+    return glob.glob(os.path.join(src, pattern))[0]
+
+
+def kernel_table(run_dir, steps_traced, title, out_name):
+    rows = list(csv.DictReader(open(one(f"{run_dir}/*/*_kernel_stats.csv"))))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    lines = [title, f"(rocprofv3 --kernel-trace --stats; {steps_traced} steps traced incl. warm-up; per-step = total / {steps_traced})",
+             f"sum of kernel time: {tot / 1e6 / steps_traced:.2f} ms/step", ""]
+    lines.append(f"{'ms/step':>8} {'calls/step':>10} {'avg us':>9}  kernel")
+    for r in rows[:40]:
+        lines.append(f"{float(r['TotalDurationNs']) / 1e6 / steps_traced:8.3f} {int(r['Calls']) / steps_traced:10.1f} {float(r['AverageNs']) / 1e3:9.1f}  {r['Name'][:150]}")
+    tr = list(csv.DictReader(open(one(f"{run_dir}/*/*_kernel_trace.csv"))))
+    lm = [float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in tr if r["Kernel_Name"].startswith("void " + LM)]
+    lm = [d for d in lm if d > 1e6]                                     # the [T,1024]x[250880,1024]^T launches (the QKV ones are ~65 us)
+    lines += ["", f"LM-head forward launches of {LM}: {len(lm)} launches, average {sum(lm) / len(lm) / 1e6:.4f} ms "
+              f"(= {2 * 8192 * 250880 * 1024 / (sum(lm) / len(lm)) / 1e3:.1f} TFLOP/s); bench.py's live HIP-event figure for the same run is in "
+              f"{rnd}_bench_under_rocprof.json"]
+    open(os.path.join(dst, out_name), "w").write("\n".join(lines) + "\n")
+    return sum(lm) / len(lm) / 1e6
+
+
+def pmc(counter):
+    rows = list(csv.DictReader(open(one(f"pmc_{counter}/*/*_counter_collection.csv"))))
+    v = [float(r["Counter_Value"]) for r in rows if r["Kernel_Name"].startswith("void " + LM) and r["Counter_Name"] == counter]
+    return v
+
+
+steps = 13                                                                # bench.py default: 3 warm-up + 10 timed
+a = kernel_table("prof_bench", steps, f"{rnd}: python bench.py --no-cpu-baseline (default: weight-gradient GEMMs on a side stream, kernels overlap)",
+                 f"{rnd}_bench_kernel_summary.txt")
+b = kernel_table("prof_bench_1stream", steps, f"{rnd}: CTMI_WGRAD_STREAM=0 python bench.py --no-cpu-baseline (single stream: clean per-kernel durations)",
+                 f"{rnd}_bench_1stream_kernel_summary.txt")
+fetch, write = pmc("FETCH_SIZE"), pmc("WRITE_SIZE")
+fk, wk = sum(fetch) / len(fetch), sum(write) / len(write)
+traffic = {
+    "kernel": LM + " = LM-head forward [8192,1024]x[250880,1024]^T",
+    "launches_profiled": [len(fetch), len(write)],
+    "FETCH_SIZE_KB_raw": fk, "WRITE_SIZE_KB_raw": wk,
+    "fetch_bytes_corrected": fk * 1024 * 2, "write_bytes": wk * 1024,
+    "traffic_bytes_per_launch": fk * 1024 * 2 + wk * 1024,
+    "algorithmic_bytes_per_launch": 8192 * 1024 * 2 + 250880 * 1024 * 2 + 8192 * 250880 * 2,
+    "note": "separate --pmc passes (FETCH_SIZE, WRITE_SIZE; --kernel-trace only) on MB_ONLY=lm_head MB_FWD_ONLY=1 tools/microbench.py gemm; "
+            "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies the 128-B requests of wide coalesced reads at 64 B). "
+            "Algorithmic bytes: A 16.8 MB + B 514 MB read, C 4.11 GB written (non-temporal). Reads exceed A+B because each of the 8 XCDs "
+            "(private 4 MiB L2) streams the weight panel for each group of 4 tile rows; they are served by the 256 MiB Infinity Cache.",
+}
+json.dump(traffic, open(os.path.join(dst, f"{rnd}_lmhead_traffic.json"), "w"), indent=1)
+print("LM-head fwd avg ms: side-stream run %.4f, single-stream run %.4f; traffic %.2f GB/launch" % (a, b, traffic["traffic_bytes_per_launch"] / 1e9))
