@@ -45,7 +45,7 @@ PROTOTYPES = {
     "ctmi_attn_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(AttnDesc), i32, vp]),
     "ctmi_mask_prep": (i32, [vp, vp, vp, vp, i64, i64, vp]),
     "ctmi_embed_fwd": (i32, [vp, vp, vp, i64, i64, i64, i32, vp, vp]),
-    "ctmi_embed_bwd": (i32, [vp, vp, vp, i64, i64, i64, i32, vp]),
+    "ctmi_embed_bwd": (i32, [vp, vp, vp, i64, i64, i64, i32, f32, vp]),
     "ctmi_ce_fwd": (i32, [vp, i64, vp, vp, vp, vp, i64, i64, i64, i64, i64, i32, i64, i32, vp]),
     "ctmi_ce_bwd": (i32, [vp, i64, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i32, vp]),
     "ctmi_adamw_step": (i32, [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64),
@@ -55,6 +55,7 @@ PROTOTYPES = {
     "ctmi_cast": (i32, [vp, i32, vp, i32, i64, vp]),
     "ctmi_sumsq": (i32, [vp, i64, vp, i32, vp]),
     "ctmi_scale": (i32, [vp, i64, f32, vp, vp]),
+    "ctmi_scale_copy": (i32, [vp, vp, i64, f32, vp]),
     "ctmi_argmax": (i32, [vp, i64, vp, i64, i64, i32, vp]),
     "ctmi_probe": (i32, [i32, vp, vp, vp]),
 }

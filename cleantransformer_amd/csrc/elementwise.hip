@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void embed_fwd_k(const T* __restrict__ table, 
 }
 template <typename T>
 __global__ __launch_bounds__(256) void embed_bwd_k(const T* __restrict__ dout, const int64_t* __restrict__ ids,
-                                                   float* __restrict__ dtable, int64_t n, int64_t H, int64_t V) {
+                                                   float* __restrict__ dtable, int64_t n, int64_t H, int64_t V, float scale) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     for (int64_t t = wave0; t < n; t += (int64_t)gridDim.x * 4) {
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256) void embed_bwd_k(const T* __restrict__ dout, c
         if (id < 0 || id >= V) continue;
         float* dst = dtable + id * H;
         const T* src = dout + t * H;
-        for (int64_t c = lane; c < H; c += 64) unsafeAtomicAdd(dst + c, Cvt<T>::to_f(src[c]));
+        for (int64_t c = lane; c < H; c += 64) unsafeAtomicAdd(dst + c, scale * Cvt<T>::to_f(src[c]));
     }
 }
 
@@ -464,12 +464,12 @@ extern "C" int ctmi_embed_fwd(const void* table, const int64_t* ids, void* out, 
     return CTMI_OK;
 }
 extern "C" int ctmi_embed_bwd(const void* dout, const int64_t* ids, float* dtable, int64_t n, int64_t H, int64_t V,
-                              int dtype, void* stream) {
+                              int dtype, float scale, void* stream) {
     CTMI_REQUIRE(dout && ids && dtable && n >= 0 && H > 0 && V > 0, "embed_bwd: bad args");
     if (n == 0) return CTMI_OK;
     int grid = (int)std::min<int64_t>(cdiv64(n, 4), 4096);
-    if (dtype == CTMI_F32) hipLaunchKernelGGL((embed_bwd_k<float>), dim3(grid), dim3(256), 0, as_stream(stream), (const float*)dout, ids, dtable, n, H, V);
-    else if (dtype == CTMI_BF16) hipLaunchKernelGGL((embed_bwd_k<bf16_t>), dim3(grid), dim3(256), 0, as_stream(stream), (const bf16_t*)dout, ids, dtable, n, H, V);
+    if (dtype == CTMI_F32) hipLaunchKernelGGL((embed_bwd_k<float>), dim3(grid), dim3(256), 0, as_stream(stream), (const float*)dout, ids, dtable, n, H, V, scale);
+    else if (dtype == CTMI_BF16) hipLaunchKernelGGL((embed_bwd_k<bf16_t>), dim3(grid), dim3(256), 0, as_stream(stream), (const bf16_t*)dout, ids, dtable, n, H, V, scale);
     else { ctmi_set_error("embed_bwd: unsupported dtype %d", dtype); return CTMI_ERR_UNSUPPORTED; }
     CTMI_CHECK_LAUNCH("embed_bwd");
     return CTMI_OK;
@@ -808,17 +808,33 @@ extern "C" int ctmi_sumsq(const float* x, int64_t n, double* out, int accumulate
     return CTMI_OK;
 }
 
-__global__ __launch_bounds__(256) void scale_k(float* __restrict__ x, int64_t n, float s, const float* __restrict__ sd) {
+// dst[i] = f * src[i]  (dst may alias src).  float4 body when both pointers are 16-byte aligned, scalar tail.
+__global__ __launch_bounds__(256) void scale_copy_k(const float* src, float* dst, int64_t n, float s, const float* __restrict__ sd, int vec) {
     const float f = sd ? s * sd[0] : s;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] *= f;
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
+    const int64_t n4 = vec ? n / 4 : 0;
+    for (int64_t i = tid; i < n4; i += nth) {
+        float4 v = reinterpret_cast<const float4*>(src)[i];
+        v.x *= f; v.y *= f; v.z *= f; v.w *= f;
+        reinterpret_cast<float4*>(dst)[i] = v;
+    }
+    for (int64_t i = n4 * 4 + tid; i < n; i += nth) dst[i] = f * src[i];
+}
+static int scale_copy_launch(const float* src, float* dst, int64_t n, float s, const float* s_dev, void* stream, const char* what) {
+    if (n == 0) return CTMI_OK;
+    const int vec = ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0;
+    int grid = (int)std::min<int64_t>(cdiv64(n, 256 * 16), 4096);
+    hipLaunchKernelGGL(scale_copy_k, dim3(grid), dim3(256), 0, as_stream(stream), src, dst, n, s, s_dev, vec);
+    CTMI_CHECK_LAUNCH(what);
+    return CTMI_OK;
 }
 extern "C" int ctmi_scale(float* x, int64_t n, float s, const float* s_dev, void* stream) {
     CTMI_REQUIRE(x && n >= 0, "scale: bad args");
-    if (n == 0) return CTMI_OK;
-    int grid = (int)std::min<int64_t>(cdiv64(n, 256 * 4), 4096);
-    hipLaunchKernelGGL(scale_k, dim3(grid), dim3(256), 0, as_stream(stream), x, n, s, s_dev);
-    CTMI_CHECK_LAUNCH("scale");
-    return CTMI_OK;
+    return scale_copy_launch(x, x, n, s, s_dev, stream, "scale");
+}
+extern "C" int ctmi_scale_copy(const float* src, float* dst, int64_t n, float s, void* stream) {
+    CTMI_REQUIRE(src && dst && n >= 0, "scale_copy: bad args");
+    return scale_copy_launch(src, dst, n, s, nullptr, stream, "scale_copy");
 }
 
 template <typename T>

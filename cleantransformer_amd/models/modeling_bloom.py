@@ -232,6 +232,7 @@ class _TieCtx:
     def __init__(self):
         self.pending: Optional[Tensor] = None
         self.embed_wants = False
+        self.early = None              # the data-parallel wrapper's tied-gradient reducer, once it took the LM-head part
 
 
 class EmbedFn(torch.autograd.Function):
@@ -257,7 +258,13 @@ class EmbedFn(torch.autograd.Function):
             dw, tie.pending = tie.pending, None
         else:
             dw = torch.zeros(ctx.vh, dtype=torch.float32, device=dout.device)
-        ops.embed_bwd(dout.view(-1, ctx.vh[1]), ids, dw)
+        if tie is not None and tie.early is not None:
+            # data parallel: dw already holds the AVERAGED LM-head part (its all-reduce ran under the whole backward);
+            # the embedding part is T rows per rank, exchanged as rows instead of as a second dense [V,H] reduction
+            early, tie.early = tie.early, None
+            early.finish(dw, dout.view(-1, ctx.vh[1]), ids)
+        else:
+            ops.embed_bwd(dout.view(-1, ctx.vh[1]), ids, dw)
         return None, dw, None, None
 
 
@@ -282,10 +289,16 @@ class LMHeadFn(torch.autograd.Function):
         d2 = dlogits.reshape(B * S, V)
         d2 = d2 if d2.is_contiguous() else d2.contiguous()
         dh = ops.linear_dgrad(d2, ops.compute_weight(weight, h2.dtype))
-        dw = ops.linear_wgrad(d2, h2)
         tie = ctx.tie
-        if tie is not None and tie.embed_wants:
+        tied = tie is not None and tie.embed_wants
+        sync = getattr(weight, "_ct_tied_sync", None) if tied else None       # set by trainer/ddp.py on the shared [V,H] parameter
+        pre = sync.prescale(weight) if sync is not None else None             # 1/world when this step reduces the dense part early
+        dw = ops.linear_wgrad(d2, h2, alpha=1.0 if pre is None else pre)
+        if tied:
             tie.pending = dw                                   # the embedding backward (always later) finishes and returns it
+            if pre is not None:
+                sync.begin(dw)
+                tie.early = sync
             dw = None
         return dh.view(B, S, H), dw, None
 
@@ -444,6 +457,12 @@ class BloomForCausalLM(torch.nn.Module, GenerationMixin):
 
     def _tie_weight(self):
         self.lm_head.weight = self.bloom.word_embeddings.weight
+
+    def ct_tied_weight(self):
+        """The [V,H] parameter shared by the embedding and the LM head (None when untied): its gradient is the sum of a
+        dense part produced FIRST in backward and T sparse rows produced LAST — trainer/ddp.py reduces them separately."""
+        w = self.bloom.word_embeddings.weight
+        return w if self.lm_head.weight is w else None
 
     def set_compute_dtype(self, dtype):
         """'fp32' (parity mode) or 'bf16' (MFMA bf16 path, fp32 master weights / grads / optimizer state)."""

@@ -157,11 +157,11 @@ def linear_dgrad(dy: Tensor, w: Tensor, epilogue: int = _lib.EPI_NONE, aux_in: O
     return gemm(dy, Nout, False, w, Kin, True, T, Kin, Nout, epilogue=epilogue, aux_in=aux_in, residual=residual)
 
 
-def linear_wgrad(dy: Tensor, x2d: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
-    """dW[out,in] (fp32) = dy[T,out]^T @ x[T,in]."""
+def linear_wgrad(dy: Tensor, x2d: Tensor, out: Optional[Tensor] = None, accumulate: bool = False, alpha: float = 1.0) -> Tensor:
+    """dW[out,in] (fp32) = alpha * dy[T,out]^T @ x[T,in]."""
     T, Nout = dy.shape
     Kin = x2d.shape[1]
-    return gemm(dy, Nout, True, x2d, Kin, True, Nout, Kin, T, out=out, out_f32=True, beta=int(accumulate))
+    return gemm(dy, Nout, True, x2d, Kin, True, Nout, Kin, T, out=out, out_f32=True, beta=int(accumulate), alpha=alpha)
 
 
 def colsum(x2d: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
@@ -252,12 +252,12 @@ def embed_fwd(table: Tensor, ids: Tensor, err_flag: Optional[Tensor] = None) -> 
     return out
 
 
-def embed_bwd(dout: Tensor, ids: Tensor, dtable: Tensor) -> None:
-    """dtable (fp32 [V,H]) += scatter(dout rows by ids)."""
+def embed_bwd(dout: Tensor, ids: Tensor, dtable: Tensor, scale: float = 1.0) -> None:
+    """dtable (fp32 [V,H]) += scale * scatter(dout rows by ids)."""
     V, H = dtable.shape
     ids_c = _c(ids)
-    check(_lib.load().ctmi_embed_bwd(_p(dout), _p(ids_c), _p(dtable), ids_c.numel(), H, V, dt_code(dout.dtype), _stream()),
-          "embed_bwd")
+    check(_lib.load().ctmi_embed_bwd(_p(dout), _p(ids_c), _p(dtable), ids_c.numel(), H, V, dt_code(dout.dtype), float(scale),
+                                     _stream()), "embed_bwd")
 
 
 def ce_fwd(logits2d: Tensor, labels: Tensor, seq: int, shift: int, ignore_index: int = -100, denom_mode: int = 0,
@@ -304,6 +304,12 @@ def sumsq(x: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> 
 def scale_(x: Tensor, s: float, s_dev: Optional[Tensor] = None) -> Tensor:
     check(_lib.load().ctmi_scale(_p(x), x.numel(), float(s), _p(s_dev), _stream()), "scale")
     return x
+
+
+def scale_copy(src: Tensor, dst: Tensor, s: float) -> Tensor:
+    """dst = s * src (fp32, flat; dst may alias src)."""
+    check(_lib.load().ctmi_scale_copy(_p(src), _p(dst), src.numel(), float(s), _stream()), "scale_copy")
+    return dst
 
 
 def argmax_lastdim(x2d: Tensor) -> Tensor:

@@ -9,6 +9,8 @@ size and sum-all-reduced as soon as its last gradient is produced, asynchronousl
 is built MI355X-first:
 
   * one flat fp32 buffer per bucket, allocated once (sized for 288 GB HBM: no per-step allocation, no re-bucketing);
+    a gradient is touched ONCE on its way through: the copy into the bucket carries the 1/world pre-division, and after the
+    all-reduce ``p.grad`` simply becomes the view of its bucket slot (no copy back);
   * the all-reduce is issued from the autograd hook through ``torch.distributed`` (backend "nccl" == RCCL on ROCm):
     RCCL runs it on its own HIP stream, fenced against the compute stream by events, so buckets overlap with the
     remaining backward kernels; the compute stream only waits at the end of backward;
@@ -43,6 +45,63 @@ class _Bucket:
         self.flat: Optional[torch.Tensor] = None
         self.pending = 0
         self.work = None
+
+
+class _TiedGradSync:
+    """Early reduction of a tied embedding / LM-head gradient.  The [V,H] parameter is the FIRST parameter,
+    so under plain bucketing its 1 GB gradient is the last all-reduce of the step and fully exposed.  Its value is
+    ``dW_lm_head`` (dense, produced by the first backward op) + ``scatter(d_embedding_rows)`` (T rows, produced by the last).
+    The dense part is pre-divided and all-reduced as soon as the LM-head weight gradient exists — under the whole rest of
+    backward — and the sparse part is exchanged as rows: ``all_gather`` of every rank's token ids and row gradients
+    (world·T·H elements instead of V·H), scatter-added with the 1/world factor.  The sum is linear, so this equals
+    torch-DDP's average of the dense per-rank gradients up to fp32 summation order."""
+
+    def __init__(self, owner: "DistributedDataParallel"):
+        self.owner = owner
+        self.work = None
+        self.active = False
+        self.steps = 0                                               # how many backward passes took the early path
+
+    def prescale(self, weight: torch.nn.Parameter):
+        """1/world if this backward pass reduces the dense part early (the LM-head weight-gradient GEMM then applies it as
+        its alpha: torch-DDP's pre-division at no cost), None for the generic bucket path (no sync, a single rank, or
+        gradient accumulation pending in ``weight.grad``)."""
+        o = self.owner
+        if not o.require_backward_grad_sync or o.world_size == 1 or weight.grad is not None:
+            return None
+        return 1.0 / o.world_size
+
+    def begin(self, dw: torch.Tensor) -> None:
+        """dw = dW_lm_head / world (contiguous fp32 [V,H]): start its all-reduce now, under the rest of backward."""
+        o = self.owner
+        self.work = dist.all_reduce(dw, op=dist.ReduceOp.SUM, group=o.process_group, async_op=True)
+        self.active = True
+        self.steps += 1
+
+    def finish(self, dw: torch.Tensor, drows: torch.Tensor, ids: torch.Tensor) -> None:
+        o = self.owner
+        W = o.world_size
+        ids = ids.reshape(-1).contiguous()
+        drows = drows.contiguous()
+        all_ids = torch.empty((W,) + tuple(ids.shape), dtype=ids.dtype, device=ids.device)
+        all_rows = torch.empty((W,) + tuple(drows.shape), dtype=drows.dtype, device=drows.device)
+        if ids.is_cuda and dist.get_backend(o.process_group) == "gloo":
+            # gloo has no device all_gather (debug configuration only: several ranks sharing one GPU); RCCL takes the direct path
+            hi, hr = ids.cpu(), drows.float().cpu()
+            li, lr = [torch.empty_like(hi) for _ in range(W)], [torch.empty_like(hr) for _ in range(W)]
+            dist.all_gather(li, hi, group=o.process_group)
+            dist.all_gather(lr, hr, group=o.process_group)
+            all_ids.copy_(torch.stack(li))
+            all_rows.copy_(torch.stack(lr))
+        elif ids.is_cuda:                                            # RCCL: straight into the [world, ...] buffers
+            dist.all_gather_into_tensor(all_ids, ids, group=o.process_group)
+            dist.all_gather_into_tensor(all_rows, drows, group=o.process_group)
+        else:
+            dist.all_gather(list(all_ids.unbind(0)), ids, group=o.process_group)
+            dist.all_gather(list(all_rows.unbind(0)), drows, group=o.process_group)
+        self.work.wait()
+        self.work = None
+        _embed_scatter(all_rows.view(-1, drows.shape[-1]), all_ids.view(-1), dw, 1.0 / W)
 
 
 def build_buckets(params: List[torch.nn.Parameter], bucket_cap_bytes: int, first_bucket_bytes: int = _MiB) -> List[List[int]]:
@@ -88,6 +147,18 @@ class DistributedDataParallel(torch.nn.Module):
         self._sync_module_states()
         cap = int(self.bucket_cap_mb * _MiB)
         layout = build_buckets(self._params, cap, first_bucket_bytes=min(_MiB, cap))
+        # a tied embedding / LM-head parameter gets a bucket of its own: most steps it is reduced early (_TiedGradSync) and
+        # its bucket is skipped; the bucket is the fallback (gradient accumulation, non-contiguous gradient)
+        tied = getattr(module, "ct_tied_weight", lambda: None)()
+        # (stored through __dict__: assigning a Parameter attribute on an nn.Module would register it as a new parameter)
+        self.__dict__["_tied_param"] = tied if (tied is not None and tied.requires_grad) else None
+        self._tied_sync = None
+        if self._tied_param is not None:
+            ti = next(i for i, p in enumerate(self._params) if p is self._tied_param)
+            layout = [[i for i in idxs if i != ti] for idxs in layout]
+            layout = [idxs for idxs in layout if idxs] + [[ti]]
+            self._tied_sync = _TiedGradSync(self)
+            self._tied_param._ct_tied_sync = self._tied_sync
         self._buckets = [_Bucket(bi, [self._params[i] for i in idxs]) for bi, idxs in enumerate(layout)]
         self._where = {}
         for b in self._buckets:
@@ -137,16 +208,24 @@ class DistributedDataParallel(torch.nn.Module):
                 b.work = None
             torch.autograd.Variable._execution_engine.queue_callback(self._finalize_backward)
         b, j = self._where[id(p)]
+        if p is self._tied_param and self._tied_sync.active:
+            self._tied_sync.active = False                          # reduced early, rows exchanged: p.grad is final already
+            b.pending -= 1
+            return
         if b.flat is None or b.flat.device != p.grad.device:
             b.flat = torch.empty(b.numel, dtype=torch.float32, device=p.grad.device)
         off = b.offsets[j]
-        b.flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
+        slot = b.flat[off:off + p.numel()]
+        g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+        # torch-DDP order: divide by the world size, then sum.  The division rides on the copy into the bucket (one pass
+        # over the gradient instead of copy + scale + copy-back); a gradient that already lives in its bucket slot (it was
+        # accumulated in place into last step's view, see _finalize_backward) is scaled where it is.
+        _scale_copy(g.reshape(-1), slot, 1.0 / self.world_size)
         b.pending -= 1
         if b.pending == 0:
             self._launch(b)
 
     def _launch(self, b: _Bucket):
-        _scale_(b.flat, 1.0 / self.world_size)                       # torch-DDP order: divide, then sum
         b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
 
     def _finalize_backward(self):
@@ -156,9 +235,13 @@ class DistributedDataParallel(torch.nn.Module):
             raise RuntimeError(f"DistributedDataParallel: buckets {missing} did not receive all of their gradients in this "
                                f"backward pass (unused parameters are not supported)")
         for b in self._buckets:
+            if b.work is None:                                      # the tied parameter's bucket in a step that reduced it early
+                continue
             b.work.wait()                                           # compute stream waits on the RCCL stream; host does not block
             for p, off in zip(b.params, b.offsets):
-                p.grad.copy_(b.flat[off:off + p.numel()].view_as(p.grad))
+                # the averaged gradient IS the bucket slot from here on: no copy back (a dense, sliceable [shape] fp32
+                # view — what lm_head.weight.grad[100:110, 100:110], ft_bloom_DDP.py:148, needs)
+                p.grad = b.flat[off:off + p.numel()].view(p.shape)
             b.work = None
 
     @contextmanager
@@ -178,9 +261,16 @@ class DistributedDataParallel(torch.nn.Module):
         return [(b.index, len(b.params), b.numel * 4) for b in self._buckets]
 
 
-def _scale_(flat: torch.Tensor, s: float) -> None:
-    if flat.is_cuda:
+def _embed_scatter(rows: torch.Tensor, ids: torch.Tensor, dtable: torch.Tensor, s: float) -> None:
+    from .. import ops
+    ops.embed_bwd(rows, ids, dtable, s)                             # (the CPU/gloo semantics tests patch ops.* with emulations)
+
+
+def _scale_copy(src: torch.Tensor, dst: torch.Tensor, s: float) -> None:
+    if src.is_cuda:
         from .. import ops
-        ops.scale_(flat, s)
-    else:                                                           # gloo / CPU: semantics tests only
-        flat.mul_(s)
+        ops.scale_copy(src, dst, s)
+    elif src.data_ptr() == dst.data_ptr():                          # gloo / CPU: semantics tests only
+        dst.mul_(s)
+    else:
+        torch.mul(src, s, out=dst)

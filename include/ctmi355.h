@@ -110,8 +110,9 @@ int ctmi_mask_prep(const int64_t* attention_mask, float* kpos, int32_t* kvalid, 
  * ids are int64; out-of-range ids raise CTMI_ERR_ARG lazily via *err_flag (int32 device word, may be NULL). */
 int ctmi_embed_fwd(const void* table, const int64_t* ids, void* out, int64_t n_tokens, int64_t H, int64_t V,
                    int dtype, int32_t* err_flag, void* stream);
-int ctmi_embed_bwd(const void* dout, const int64_t* ids, float* dtable /* fp32 [V,H], += */, int64_t n_tokens,
-                   int64_t H, int64_t V, int dtype, void* stream);
+int ctmi_embed_bwd(const void* dout, const int64_t* ids, float* dtable /* fp32 [V,H], += scale * row */, int64_t n_tokens,
+                   int64_t H, int64_t V, int dtype, float scale /* 1 locally; 1/world for rows gathered from DDP peers */,
+                   void* stream);
 
 /* ---- cross entropy  (torch.nn.CrossEntropyLoss at modeling_bloom.py:224-230; repo loss.py:29-49)
  * logits [N, C] (ld = row stride).  Row r = (b, s) with b = r / seq, s = r % seq takes its target from
@@ -151,6 +152,8 @@ int ctmi_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t 
 /* out[0] (+)= sum(x^2), fp64 accumulation (device double) — global grad-norm (trainer.py:491-498 clip_grad_norm_) */
 int ctmi_sumsq(const float* x, int64_t n, double* out, int accumulate, void* stream);
 int ctmi_scale(float* x, int64_t n, float s, const float* s_dev /* optional device scalar multiplier */, void* stream);
+/* dst = s * src (fp32; dst may alias src) — DDP bucket fill with torch-DDP's pre-division fused (torch Reducer: divide, then all-reduce) */
+int ctmi_scale_copy(const float* src, float* dst, int64_t n, float s, void* stream);
 /* argmax over the last dim of x[rows, cols] -> int64 (first maximal index, as torch.argmax; generation_util.py:86) */
 int ctmi_argmax(const void* x, int64_t ld, int64_t* out, int64_t rows, int64_t cols, int dtype, void* stream);
 

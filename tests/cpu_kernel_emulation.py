@@ -150,8 +150,8 @@ def embed_fwd(table, ids, err_flag=None):
     return table[ids]
 
 
-def embed_bwd(dout, ids, dtable):
-    dtable.index_add_(0, ids.reshape(-1), dout.float().reshape(-1, dtable.shape[1]))
+def embed_bwd(dout, ids, dtable, scale=1.0):
+    dtable.index_add_(0, ids.reshape(-1), dout.float().reshape(-1, dtable.shape[1]) * torch.tensor(scale, dtype=torch.float32))
 
 
 def _targets(labels, N, seq, shift, ignore):

@@ -79,11 +79,21 @@ def _worker(rank, world, port, bucket_mb, ret):
     lo2, hi2 = local.clone(), local.clone()
     dist.all_reduce(lo2, op=dist.ReduceOp.MIN)
     dist.all_reduce(hi2, op=dist.ReduceOp.MAX)
+    # gradient accumulation: a synced backward on top of the local gradients reduces the SUM of both passes (torch-DDP
+    # semantics); the tied [V,H] gradient must take its bucket fallback here (its early path needs .grad to be None)
+    early_before = ddp._tied_sync.steps
+    (l4, _, _), _ = ddp(input_ids=ids, attention_mask=am, labels=ids.clone())
+    l4.backward()
+    accum = {n: p.grad.numpy().copy() for n, p in m.named_parameters()}
+    early_in_accum = ddp._tied_sync.steps - early_before
     if rank == 0:
         ret["same_on_all_ranks"] = same
         ret["no_sync_differs"] = not bool(torch.equal(lo2, hi2))
         ret["loss0"] = float(loss)
         ret["buckets"] = ddp.bucket_summary()
+        ret["early_in_accum"] = early_in_accum
+        for n, a in accum.items():
+            ret["acc_" + n] = a
         (l3, _, _), _ = ddp(input_ids=ids, attention_mask=am, labels=ids.clone())     # recompute synced grads for export
     for p in m.parameters():
         p.grad = None
@@ -92,6 +102,7 @@ def _worker(rank, world, port, bucket_mb, ret):
     if rank == 0:
         for n, p in m.named_parameters():
             ret["g_" + n] = p.grad.numpy().copy()
+        ret["early_steps"] = ddp._tied_sync.steps
     dist.destroy_process_group()
 
 
@@ -111,3 +122,8 @@ def test_ddp_matches_torch_ddp_on_reference_model(world, bucket_mb):
             a, b = ret["g_" + name], gold[k]
             assert a.shape == b.shape
             assert np.allclose(a, b, rtol=1e-4, atol=1e-8), (name, float(np.abs(a - b).max()))
+            acc = ret["acc_" + name]                              # no_sync pass + synced pass on the same batch = 2 x the average
+            assert np.allclose(acc, 2.0 * b, rtol=1e-4, atol=2e-8), ("accumulated", name, float(np.abs(acc - 2.0 * b).max()))
+    # the tied embedding / LM-head gradient went through the early dense all-reduce + row exchange in every plain synced
+    # backward (3 of them), and through its bucket in the accumulation step
+    assert ret["early_steps"] == 2 and ret["early_in_accum"] == 0, (ret["early_steps"], ret["early_in_accum"])

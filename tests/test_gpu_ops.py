@@ -476,3 +476,24 @@ def test_utils_cast_sumsq_argmax():
     tie[:, 7] = 1
     tie[:, 30] = 1
     assert o.argmax_lastdim(tie).tolist() == [7, 7, 7]                               # first maximal index, like torch.argmax
+
+
+def test_scale_and_scale_copy_bit_exact():
+    """DDP bucket fill: dst = s * src is one fp32 multiply per element (bit-exact vs torch), aligned and unaligned,
+    out of place and in place (trainer/ddp.py: torch-DDP's divide-then-all-reduce order)."""
+    o = ops()
+    for n, off in ((1 << 20, 0), (12345, 0), (4099, 1), (7, 3)):
+        base = rnd(n + 8, seed=n).to(DEV)
+        src = base[off:off + n]
+        dst = torch.empty(n + 8, device=DEV)[off:off + n]
+        o.scale_copy(src, dst, 0.125)
+        assert torch.equal(dst.cpu(), (src * 0.125).cpu())
+        o.scale_copy(src, dst, 1.0 / 3.0)
+        assert torch.equal(dst.cpu(), (src * torch.tensor(1.0 / 3.0, dtype=torch.float32)).cpu())
+        want = (src * torch.tensor(1.0 / 7.0, dtype=torch.float32)).cpu()
+        o.scale_copy(src, src, 1.0 / 7.0)                                              # aliasing: scaled where it is
+        assert torch.equal(src.cpu(), want)
+        y = rnd(n, seed=3).to(DEV)
+        want = (y * 0.5).cpu()
+        o.scale_(y, 0.5)
+        assert torch.equal(y.cpu(), want)
