@@ -113,6 +113,7 @@ def main():
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
     if world > 1:
+        os.environ.setdefault("CTMI_GEMM_SHARED", "1")     # RCCL kernels share the CUs under backward
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(os.environ.get("CTMI_DIST_BACKEND", "nccl"))       # "nccl" == RCCL on ROCm
 

@@ -869,6 +869,8 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ s
     }
 }
 
+static bool shared_mode();
+
 template <typename TO, bool AK, bool BKM, int EPI, int WM, int WGN, bool PP = false, bool RES = false>
 static void glds_launch(GemmArgs& g, hipStream_t st) {
     constexpr int BM = WM * 32, BN = WGN * 64;
@@ -877,8 +879,15 @@ static void glds_launch(GemmArgs& g, hipStream_t st) {
     // persistent launch: one resident workgroup per occupancy slot (256 CUs x workgroups that fit a CU's 160 KiB LDS),
     // each walking work items bid, bid+G, ... with its DMA stream prefetching across item boundaries
     static int persist = -1;
-    if (persist < 0) { const char* e = getenv("CTMI_GEMM_PERSIST"); persist = e ? atoi(e) : 1; }
-    const int64_t slots = 256 * (int64_t)std::min<size_t>((size_t)(WGN == 4 ? 1 : 8), (160 * 1024) / lds);
+    if (persist < 0) { const char* e = getenv("CTMI_GEMM_PERSIST"); persist = e ? atoi(e) : (shared_mode() ? 0 : 1); }
+    // CTMI_GEMM_RESERVE_CUS = R leaves R of the 256 CUs out of every persistent launch.  A persistent GEMM owns each CU it
+    // runs on until it ends (all LDS, all VGPRs), so with R = 0 a concurrent RCCL all-reduce kernel makes no progress for
+    // the length of the GEMM (up to ~4 ms for the LM head); data-parallel runs set R ~ 16 so communication streams
+    // continuously under backward (bench.py does for --gpus > 1).
+    static int reserve = -1;
+    if (reserve < 0) { const char* e = getenv("CTMI_GEMM_RESERVE_CUS"); reserve = e ? std::max(0, std::min(128, atoi(e))) : 0; }
+    const int64_t per_cu = (int64_t)std::min<size_t>((size_t)(WGN == 4 ? 1 : 8), (160 * 1024) / lds);
+    const int64_t slots = (256 - reserve) / 8 * 8 * per_cu;                  // multiple of 8: the XCD-aware item order needs it
     const unsigned grid = (unsigned)((persist && nwork > slots) ? slots : nwork);
     auto kern = &gemm_glds_kernel<TO, AK, BKM, EPI, WM, WGN, PP, RES>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -893,6 +902,20 @@ static void glds_launch(GemmArgs& g, hipStream_t st) {
 // 128x256 for [T,1024] outputs); row-major-B dgrads with long K and the layer weight gradients (both operands K-major,
 // K = T, ~512+ workgroups via deterministic split-K) stay on the free-running tiles; the very-long-K LM-head dgrad
 // (K = V) takes ping-pong 256x256 with a 2-way split.
+// CTMI_GEMM_SHARED=1: the GPU is shared with somebody else's long-running kernels — in practice the RCCL all-reduce of a
+// data-parallel job, which holds a few dozen CUs for milliseconds under backward.  Measured with tools/contention_probe.py
+// (ONE CU held by a spin kernel): the default policy loses 23 % of the step, because a persistent launch sized to the CU
+// count, or a ping-pong launch whose tiles fill the chip in exactly 1-2 rounds, waits a whole extra round for the CU it
+// cannot get.  Shared mode therefore (a) never launches persistently (one workgroup per work item: the hardware dispatcher
+// balances), (b) keeps the one-workgroup-per-CU ping-pong tiles for launches of >= 2048 items only (the LM head), with an
+// 8-way split of the K = V dgrad, and (c) runs the layer GEMMs on the 128x128 / 256x128 tiles (2-3 workgroups per CU,
+// which also co-reside with a small foreign workgroup).
+static bool shared_mode() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("CTMI_GEMM_SHARED"); v = (e && e[0] != '0') ? 1 : 0; }
+    return v == 1;
+}
+
 static void pick_tile(int64_t M, int64_t N, int64_t K, bool wgrad, bool bkm, int epi, int max_splits, int& tile, int& splits) {
     static int force = -2, force_split = -2;
     if (force == -2) { const char* e = getenv("CTMI_GEMM_TILE"); force = e ? atoi(e) : -1; }
@@ -901,6 +924,21 @@ static void pick_tile(int64_t M, int64_t N, int64_t K, bool wgrad, bool bkm, int
     const int64_t t0 = cdiv64(M, 128) * cdiv64(N, 128), t1 = cdiv64(M, 256) * cdiv64(N, 128), t2 = cdiv64(M, 256) * cdiv64(N, 256);
     const int64_t t4 = cdiv64(M, 128) * cdiv64(N, 256);
     tile = 0; splits = 1;
+    if (shared_mode()) {
+        if (wgrad) {
+            if (t1 >= 1024) tile = t2 >= 2048 ? 3 : 1;
+            else {
+                tile = t1 >= 128 ? 1 : 0;
+                const int64_t tiles = tile ? t1 : t0;
+                while (splits < max_splits && tiles * splits < 512 && K / (splits * 2) >= 1024) splits *= 2;
+            }
+        } else if (K >= 32768 && max_splits >= 2) { tile = 3; splits = (int)std::min<int64_t>(max_splits, std::max<int64_t>(2, 1024 / std::max<int64_t>(t2, 1))); }
+        else if (t2 >= 2048) tile = 3;
+        else if (t1 >= 700) tile = 1;
+        else tile = 0;
+        if (force >= 0) tile = force;
+        return;
+    }
     if (wgrad) {
         static int nosplit = -1;
         if (nosplit < 0) { const char* e = getenv("CTMI_WGRAD_NOSPLIT"); nosplit = e ? atoi(e) : 0; }

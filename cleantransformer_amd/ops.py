@@ -97,12 +97,12 @@ _SPLITK_WS = {}
 
 
 def _splitk_ws(device) -> Tensor:
-    """Scratch for split-K GEMMs (fp32 slabs; 8 x [4096,1024] fits), one per (device, stream): kernels on one stream
+    """Scratch for split-K GEMMs (fp32 slabs; 8 x [8192,1024] fits), one per (device, stream): kernels on one stream
     run in order, but the weight-gradient side stream must not share slabs with the main stream."""
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     ws = _SPLITK_WS.get(key)
     if ws is None:
-        ws = torch.empty(8 * 4096 * 1024, dtype=torch.float32, device=device)
+        ws = torch.empty(16 * 4096 * 1024, dtype=torch.float32, device=device)
         _SPLITK_WS[key] = ws
     return ws
 

@@ -21,6 +21,7 @@ It is transport-agnostic (``gloo`` on CPU works and is how the semantics are tes
 """
 from __future__ import annotations
 
+import os
 from contextlib import contextmanager
 from typing import List, Optional
 
@@ -137,6 +138,10 @@ class DistributedDataParallel(torch.nn.Module):
         self.module = module
         self.process_group = process_group if process_group is not None else dist.group.WORLD
         self.world_size = dist.get_world_size(self.process_group)
+        if self.world_size > 1:
+            # the all-reduce kernels will hold CUs under backward: switch the GEMM launcher to its shared-GPU policy
+            # (csrc/gemm.hip shared_mode(); read once, at the first GEMM launch, so wrap the model before running it)
+            os.environ.setdefault("CTMI_GEMM_SHARED", "1")
         self.device_ids = device_ids
         self.broadcast_buffers = broadcast_buffers
         self.bucket_cap_mb = 25 if bucket_cap_mb is None else bucket_cap_mb
