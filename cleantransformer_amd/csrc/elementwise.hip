@@ -153,13 +153,25 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_vec(const T* __restrict
         const T* gr = dy + row * cols;
         float xh[MAXV][VEC], g[MAXV][VEC];
         float s1 = 0.f, s2 = 0.f;
+        // all three input rows are requested before anything is reduced: the residual-gradient row is only needed after the
+        // two wave reductions, and loaded there it exposed a full HBM latency per row
+        uint4 xraw[MAXV], graw[MAXV], rraw[MAXV];
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = (i * 64 + lane) * VEC;
+            if (c < cols) {
+                xraw[i] = *reinterpret_cast<const uint4*>(xr + c);
+                graw[i] = *reinterpret_cast<const uint4*>(gr + c);
+                if (dres != nullptr) rraw[i] = *reinterpret_cast<const uint4*>(dres + row * cols + c);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
             const int c = (i * 64 + lane) * VEC;
             if (c < cols) {
                 float xv[VEC], dv[VEC];
-                unpack16<T>(*reinterpret_cast<const uint4*>(xr + c), xv);
-                unpack16<T>(*reinterpret_cast<const uint4*>(gr + c), dv);
+                unpack16<T>(xraw[i], xv);
+                unpack16<T>(graw[i], dv);
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
                     xh[i][j] = (xv[j] - mean) * rstd;
@@ -183,7 +195,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_vec(const T* __restrict
                 for (int j = 0; j < VEC; ++j) o[j] = rstd * (g[i][j] - s1 - xh[i][j] * s2);
                 if (dres != nullptr) {
                     float r[VEC];
-                    unpack16<T>(*reinterpret_cast<const uint4*>(dres + row * cols + c), r);
+                    unpack16<T>(rraw[i], r);
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) o[j] += r[j];
                 }

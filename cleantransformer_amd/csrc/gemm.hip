@@ -14,6 +14,7 @@
 // handles any shape/alignment element-wise.  Small-tile-count problems (weight gradients) are split along K into
 // fp32 slabs in a caller-provided workspace and reduced deterministically by a second kernel.
 #include "common.h"
+#include <type_traits>
 #include "mma.h"
 
 template <typename T> struct Tile;
@@ -544,89 +545,121 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
             constexpr bool PRE_RES = RES && !PRE_AUX && WM == 4;
             constexpr bool PRE = PRE_AUX || PRE_RES;
             const T* side = PRE_AUX ? AUXI : R;
-            uint4 pre[2][PRE ? 4 : 1];
-            auto prefetch = [&](int p, int slot) {
-                if constexpr (PRE) {
+            // per-lane element offset of (row lane>>3, column chunk lane&7) of the wave tile; rows advance by 8 * ldc
+            const int64_t off0 = (mw + (lane >> 3)) * g.ldc + nw + (lane & 7) * 8;
+            const int64_t row8 = 8 * g.ldc;
+            // The runtime-uniform switches (residual / beta / non-temporal) are lifted OUT of the unrolled body into
+            // compile-time variants: as branches inside it they cut every 8-row step into its own basic block, so hipcc
+            // could not batch the LDS reads and each step exposed an LDS round trip plus a 64-bit multiply for its address.
+            auto shuffle = [&](auto plain_c, auto nt_flag) {
+                constexpr bool PLAIN = decltype(plain_c)::value;            // no inline residual load, no beta
+                constexpr bool NT = decltype(nt_flag)::value;
+                uint4 pre[2][PRE ? 4 : 1];
+                auto prefetch = [&](int p, int slot) {
+                    if constexpr (PRE) {
 #pragma unroll
-                    for (int it = 0; it < 4; ++it)
-                        pre[slot][it] = *reinterpret_cast<const uint4*>(side + (mw + p * 32 + it * 8 + (lane >> 3)) * g.ldc + nw + (lane & 7) * 8);
-                }
-            };
-            prefetch(0, 0);
-#pragma unroll
-            for (int p = 0; p < WM / 2; ++p) {
-#pragma unroll
-                for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        f32x4 v = acc[p * 2 + ii][j] * g.alpha;
-                        if (g.bias != nullptr) v += bias4[j];
-                        const int row = ii * 16 + (lane & 15), c = j * 4 + (lane >> 4);
-                        *reinterpret_cast<f32x4*>(scr + row * 256 + ((c ^ (row & 15)) << 4)) = v;
+                        for (int it = 0; it < 4; ++it) pre[slot][it] = *reinterpret_cast<const uint4*>(side + off0 + (p * 4 + it) * row8);
                     }
-                __builtin_amdgcn_sched_barrier(0);                             // the next pass's inputs go into the registers these accumulators just freed
-                if (p + 1 < WM / 2) prefetch(p + 1, (p + 1) & 1);
+                };
+                prefetch(0, 0);
 #pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int row = it * 8 + (lane >> 3), c0 = (lane & 7) * 2;
-                    const f32x4 lo = *reinterpret_cast<const f32x4*>(scr + row * 256 + ((c0 ^ (row & 15)) << 4));
-                    const f32x4 hi = *reinterpret_cast<const f32x4*>(scr + row * 256 + (((c0 ^ (row & 15)) ^ 1) << 4));
-                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    const int64_t off = (mw + p * 32 + row) * g.ldc + nw + (lane & 7) * 8;
-                    if (EPI == CTMI_EPI_GELU) {
-                        const uint4 tb = pack16<T>(v);
-                        *reinterpret_cast<uint4*>(AUXO + off) = tb;
-                        unpack16<T>(tb, v);
+                for (int p = 0; p < WM / 2; ++p) {
 #pragma unroll
-                        for (int r = 0; r < 8; r += 2) { const f32x2 y = gelu_tanh_pk(f32x2{v[r], v[r + 1]}); v[r] = y[0]; v[r + 1] = y[1]; }
-                    } else if (EPI == CTMI_EPI_RELU) {
+                    for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
-                    } else if (EPI == CTMI_EPI_DGELU || EPI == CTMI_EPI_DRELU) {
-                        float u[8];
-                        if constexpr (PRE_AUX) unpack16<T>(pre[p & 1][it], u);
-                        else unpack16<T>(*reinterpret_cast<const uint4*>(AUXI + off), u);
-                        if (EPI == CTMI_EPI_DGELU) {
-#pragma unroll
-                            for (int r = 0; r < 8; r += 2) { const f32x2 y = f32x2{v[r], v[r + 1]} * gelu_tanh_grad_pk(f32x2{u[r], u[r + 1]}); v[r] = y[0]; v[r + 1] = y[1]; }
-                        } else {
-#pragma unroll
-                            for (int r = 0; r < 8; ++r) v[r] = u[r] > 0.f ? v[r] : 0.f;
+                        for (int j = 0; j < 4; ++j) {
+                            f32x4 v = acc[p * 2 + ii][j] * g.alpha;
+                            if (g.bias != nullptr) v += bias4[j];
+                            const int row = ii * 16 + (lane & 15), c = j * 4 + (lane >> 4);
+                            *reinterpret_cast<f32x4*>(scr + row * 256 + ((c ^ (row & 15)) << 4)) = v;
                         }
-                    }
-                    if (PRE_RES || R != nullptr) {
-                        float u[8];
-                        if constexpr (PRE_RES) unpack16<T>(pre[p & 1][it], u);
-                        else unpack16<T>(*reinterpret_cast<const uint4*>(R + off), u);
+                    __builtin_amdgcn_sched_barrier(0);                         // the next pass's inputs go into the registers these accumulators just freed
+                    if (p + 1 < WM / 2) prefetch(p + 1, (p + 1) & 1);
+                    constexpr int RB = (WM == 8) ? 2 : 4;                       // 8-row steps read back together (register budget)
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) v[r] += u[r];
-                    }
-                    if constexpr (sizeof(TO) == 4) {
-                        float* Cf = reinterpret_cast<float*>(C) + off;
-                        if (g.beta) {
-                            const f32x4 c0v = *reinterpret_cast<const f32x4*>(Cf), c1v = *reinterpret_cast<const f32x4*>(Cf + 4);
+                    for (int ib = 0; ib < 4; ib += RB) {
+                    f32x4 lo[RB], hi[RB];
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) { v[r] += c0v[r]; v[4 + r] += c1v[r]; }
-                        }
-                        *reinterpret_cast<f32x4*>(Cf) = f32x4{v[0], v[1], v[2], v[3]};
-                        *reinterpret_cast<f32x4*>(Cf + 4) = f32x4{v[4], v[5], v[6], v[7]};
-                    } else {
-                        if (g.beta) {
+                    for (int k = 0; k < RB; ++k) {
+                        const int row = (ib + k) * 8 + (lane >> 3), c0 = (lane & 7) * 2;
+                        lo[k] = *reinterpret_cast<const f32x4*>(scr + row * 256 + ((c0 ^ (row & 15)) << 4));
+                        hi[k] = *reinterpret_cast<const f32x4*>(scr + row * 256 + (((c0 ^ (row & 15)) ^ 1) << 4));
+                    }
+#pragma unroll
+                    for (int k = 0; k < RB; ++k) {
+                        const int it = ib + k;
+                        float v[8] = {lo[k][0], lo[k][1], lo[k][2], lo[k][3], hi[k][0], hi[k][1], hi[k][2], hi[k][3]};
+                        const int64_t off = off0 + (p * 4 + it) * row8;
+                        if (EPI == CTMI_EPI_GELU) {
+                            const uint4 tb = pack16<T>(v);
+                            *reinterpret_cast<uint4*>(AUXO + off) = tb;
+                            unpack16<T>(tb, v);
+#pragma unroll
+                            for (int r = 0; r < 8; r += 2) { const f32x2 y = gelu_tanh_pk(f32x2{v[r], v[r + 1]}); v[r] = y[0]; v[r + 1] = y[1]; }
+                        } else if (EPI == CTMI_EPI_RELU) {
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+                        } else if (EPI == CTMI_EPI_DGELU || EPI == CTMI_EPI_DRELU) {
                             float u[8];
-                            unpack16<T>(*reinterpret_cast<const uint4*>(C + off), u);
+                            if constexpr (PRE_AUX) unpack16<T>(pre[p & 1][it], u);
+                            else unpack16<T>(*reinterpret_cast<const uint4*>(AUXI + off), u);
+                            if (EPI == CTMI_EPI_DGELU) {
+#pragma unroll
+                                for (int r = 0; r < 8; r += 2) { const f32x2 y = f32x2{v[r], v[r + 1]} * gelu_tanh_grad_pk(f32x2{u[r], u[r + 1]}); v[r] = y[0]; v[r + 1] = y[1]; }
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 8; ++r) v[r] = u[r] > 0.f ? v[r] : 0.f;
+                            }
+                        }
+                        if constexpr (PRE_RES) {
+                            float u[8];
+                            unpack16<T>(pre[p & 1][it], u);
 #pragma unroll
                             for (int r = 0; r < 8; ++r) v[r] += u[r];
+                        } else if constexpr (!PLAIN) {
+                            if (R != nullptr) {
+                                float u[8];
+                                unpack16<T>(*reinterpret_cast<const uint4*>(R + off), u);
+#pragma unroll
+                                for (int r = 0; r < 8; ++r) v[r] += u[r];
+                            }
                         }
-                        const uint4 pk = pack16<T>(v);
-                        // logits-sized outputs (>> the 256 MiB Infinity Cache) are written non-temporally so they do not
-                        // push the operand panels out of L2; asm because hipcc merges a plain and a nontemporal store
-                        // to one address into one plain store
-                        if (g.nt_c) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(C + off), "v"(__builtin_bit_cast(u32x4, pk)) : "memory");
-                        else *reinterpret_cast<uint4*>(C + off) = pk;
+                        if constexpr (sizeof(TO) == 4) {
+                            float* Cf = reinterpret_cast<float*>(C) + off;
+                            if constexpr (!PLAIN) {
+                                if (g.beta) {
+                                    const f32x4 c0v = *reinterpret_cast<const f32x4*>(Cf), c1v = *reinterpret_cast<const f32x4*>(Cf + 4);
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) { v[r] += c0v[r]; v[4 + r] += c1v[r]; }
+                                }
+                            }
+                            *reinterpret_cast<f32x4*>(Cf) = f32x4{v[0], v[1], v[2], v[3]};
+                            *reinterpret_cast<f32x4*>(Cf + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                        } else {
+                            if constexpr (!PLAIN) {
+                                if (g.beta) {
+                                    float u[8];
+                                    unpack16<T>(*reinterpret_cast<const uint4*>(C + off), u);
+#pragma unroll
+                                    for (int r = 0; r < 8; ++r) v[r] += u[r];
+                                }
+                            }
+                            const uint4 pk = pack16<T>(v);
+                            // logits-sized outputs (>> the 256 MiB Infinity Cache) are written non-temporally so they do
+                            // not push the operand panels out of L2 (asm: hipcc would merge a plain and a nontemporal store
+                            // to one address into one plain store)
+                            if (NT && g.nt_c) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(C + off), "v"(__builtin_bit_cast(u32x4, pk)) : "memory");
+                            else *reinterpret_cast<uint4*>(C + off) = pk;
+                        }
                     }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);                         // one pass at a time: keeps the live set at acc + one pass
                 }
-                __builtin_amdgcn_sched_barrier(0);                             // one pass at a time: keeps the live set at acc + one pass
-            }
+            };
+            const bool plain = (PRE_RES || R == nullptr) && !g.beta;
+            constexpr bool CAN_NT = sizeof(TO) == 2 && EPI == CTMI_EPI_NONE && !RES;
+            if (plain) shuffle(std::true_type{}, std::integral_constant<bool, CAN_NT>{});
+            else shuffle(std::false_type{}, std::false_type{});
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // patch reads retired before the other row group may write it
             return;
         }
