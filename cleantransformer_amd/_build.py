@@ -10,7 +10,9 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libctmi355.so")
-SOURCES = ["elementwise.hip", "gemm.hip", "attention.hip", "probe.hip"]
+# (source, object, extra flags): gemm.hip is built as four translation units so its template instantiations compile in parallel
+SOURCES = [("elementwise.hip", "elementwise.o", []), ("attention.hip", "attention.o", []), ("probe.hip", "probe.o", [])] + \
+          [("gemm.hip", f"gemm_p{i}.o", [f"-DCTMI_GEMM_PART={i}"]) for i in range(4)]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wno-unused-value"]
 
@@ -35,21 +37,21 @@ def build(force: bool = False, verbose: bool = True) -> str:
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(PKG), "include", "ctmi355.h"))
     objs, jobs = [], []
-    for src in SOURCES:
+    for src, obj, extra in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
+        o = os.path.join(LIB_DIR, obj)
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            jobs.append([hipcc, *FLAGS, "-c", s, "-o", o])
+            jobs.append([hipcc, *FLAGS, *extra, "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
-            print("[ctmi355 build]", " ".join(cmd[-4:]), flush=True)
+            print("[ctmi355 build]", " ".join(cmd[-5:]), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=8) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB_PATH, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH])

@@ -1055,34 +1055,66 @@ static int gemm_launch(GemmArgs& g, bool fast, hipStream_t st) {
     return CTMI_OK;
 }
 
-template <typename T>
-static int gemm_dispatch(GemmArgs& g, int ak, int bk, int epi, int out_f32, bool fast, hipStream_t st) {
-    const bool of = out_f32 || sizeof(T) == 4;
-    if (!ak && !bk && !of) {
-        if (epi == CTMI_EPI_NONE) return gemm_launch<T, T, false, false, CTMI_EPI_NONE>(g, fast, st);
-        if (epi == CTMI_EPI_GELU) return gemm_launch<T, T, false, false, CTMI_EPI_GELU>(g, fast, st);
-        if (epi == CTMI_EPI_RELU) return gemm_launch<T, T, false, false, CTMI_EPI_RELU>(g, fast, st);
-    }
-    if (!ak && bk && !of) {
-        if (epi == CTMI_EPI_NONE) return gemm_launch<T, T, false, true, CTMI_EPI_NONE>(g, fast, st);
-        if (epi == CTMI_EPI_DGELU) return gemm_launch<T, T, false, true, CTMI_EPI_DGELU>(g, fast, st);
-        if (epi == CTMI_EPI_DRELU) return gemm_launch<T, T, false, true, CTMI_EPI_DRELU>(g, fast, st);
-    }
-    if (ak && bk && of && epi == CTMI_EPI_NONE) return gemm_launch<T, float, true, true, CTMI_EPI_NONE>(g, fast, st);
-    if constexpr (sizeof(T) == 4) {                         // fp32 storage: output is fp32 either way
-        if (!ak && !bk) {
-            if (epi == CTMI_EPI_NONE) return gemm_launch<T, float, false, false, CTMI_EPI_NONE>(g, fast, st);
-            if (epi == CTMI_EPI_GELU) return gemm_launch<T, float, false, false, CTMI_EPI_GELU>(g, fast, st);
-            if (epi == CTMI_EPI_RELU) return gemm_launch<T, float, false, false, CTMI_EPI_RELU>(g, fast, st);
-        }
-        if (!ak && bk) {
-            if (epi == CTMI_EPI_NONE) return gemm_launch<T, float, false, true, CTMI_EPI_NONE>(g, fast, st);
-            if (epi == CTMI_EPI_DGELU) return gemm_launch<T, float, false, true, CTMI_EPI_DGELU>(g, fast, st);
-            if (epi == CTMI_EPI_DRELU) return gemm_launch<T, float, false, true, CTMI_EPI_DRELU>(g, fast, st);
-        }
-    }
+// This file is compiled as FOUR translation units (-DCTMI_GEMM_PART=0..3, see _build.py) so the bf16 kernel instantiations
+// — three operand layouts x epilogues x five tile shapes — build in parallel: part 0 = C entry point + fp32 (parity mode),
+// parts 1/2/3 = bf16 forward (NT) / data-gradient (NN) / weight-gradient (TN) families.  Undefined = everything in one unit.
+#ifndef CTMI_GEMM_PART
+#define CTMI_GEMM_PART (-1)
+#endif
+#define CTMI_GEMM_HAS(p) (CTMI_GEMM_PART == -1 || CTMI_GEMM_PART == (p))
+int ctmi_gemm_bf16_nt(GemmArgs& g, int epi, bool fast, hipStream_t st);
+int ctmi_gemm_bf16_nn(GemmArgs& g, int epi, bool fast, hipStream_t st);
+int ctmi_gemm_bf16_tn(GemmArgs& g, int epi, bool fast, hipStream_t st);
+static int gemm_unsupported(int ak, int bk, int epi, int out_f32) {
     ctmi_set_error("gemm: unsupported combination a_kmajor=%d b_kmajor=%d epilogue=%d out_f32=%d", ak, bk, epi, out_f32);
     return CTMI_ERR_UNSUPPORTED;
+}
+
+#if CTMI_GEMM_HAS(1)
+int ctmi_gemm_bf16_nt(GemmArgs& g, int epi, bool fast, hipStream_t st) {
+    if (epi == CTMI_EPI_NONE) return gemm_launch<bf16_t, bf16_t, false, false, CTMI_EPI_NONE>(g, fast, st);
+    if (epi == CTMI_EPI_GELU) return gemm_launch<bf16_t, bf16_t, false, false, CTMI_EPI_GELU>(g, fast, st);
+    if (epi == CTMI_EPI_RELU) return gemm_launch<bf16_t, bf16_t, false, false, CTMI_EPI_RELU>(g, fast, st);
+    return gemm_unsupported(0, 0, epi, 0);
+}
+#endif
+#if CTMI_GEMM_HAS(2)
+int ctmi_gemm_bf16_nn(GemmArgs& g, int epi, bool fast, hipStream_t st) {
+    if (epi == CTMI_EPI_NONE) return gemm_launch<bf16_t, bf16_t, false, true, CTMI_EPI_NONE>(g, fast, st);
+    if (epi == CTMI_EPI_DGELU) return gemm_launch<bf16_t, bf16_t, false, true, CTMI_EPI_DGELU>(g, fast, st);
+    if (epi == CTMI_EPI_DRELU) return gemm_launch<bf16_t, bf16_t, false, true, CTMI_EPI_DRELU>(g, fast, st);
+    return gemm_unsupported(0, 1, epi, 0);
+}
+#endif
+#if CTMI_GEMM_HAS(3)
+int ctmi_gemm_bf16_tn(GemmArgs& g, int epi, bool fast, hipStream_t st) {
+    if (epi == CTMI_EPI_NONE) return gemm_launch<bf16_t, float, true, true, CTMI_EPI_NONE>(g, fast, st);
+    return gemm_unsupported(1, 1, epi, 1);
+}
+#endif
+
+#if CTMI_GEMM_HAS(0)
+static int gemm_dispatch_bf16(GemmArgs& g, int ak, int bk, int epi, int out_f32, bool fast, hipStream_t st) {
+    if (!ak && !bk && !out_f32) return ctmi_gemm_bf16_nt(g, epi, fast, st);
+    if (!ak && bk && !out_f32) return ctmi_gemm_bf16_nn(g, epi, fast, st);
+    if (ak && bk && out_f32) return ctmi_gemm_bf16_tn(g, epi, fast, st);
+    return gemm_unsupported(ak, bk, epi, out_f32);
+}
+
+static int gemm_dispatch_f32(GemmArgs& g, int ak, int bk, int epi, bool fast, hipStream_t st) {   // fp32 storage: output is fp32 either way
+    using T = float;
+    if (!ak && !bk) {
+        if (epi == CTMI_EPI_NONE) return gemm_launch<T, float, false, false, CTMI_EPI_NONE>(g, fast, st);
+        if (epi == CTMI_EPI_GELU) return gemm_launch<T, float, false, false, CTMI_EPI_GELU>(g, fast, st);
+        if (epi == CTMI_EPI_RELU) return gemm_launch<T, float, false, false, CTMI_EPI_RELU>(g, fast, st);
+    }
+    if (!ak && bk) {
+        if (epi == CTMI_EPI_NONE) return gemm_launch<T, float, false, true, CTMI_EPI_NONE>(g, fast, st);
+        if (epi == CTMI_EPI_DGELU) return gemm_launch<T, float, false, true, CTMI_EPI_DGELU>(g, fast, st);
+        if (epi == CTMI_EPI_DRELU) return gemm_launch<T, float, false, true, CTMI_EPI_DRELU>(g, fast, st);
+    }
+    if (ak && bk && epi == CTMI_EPI_NONE) return gemm_launch<T, float, true, true, CTMI_EPI_NONE>(g, fast, st);
+    return gemm_unsupported(ak, bk, epi, 1);
 }
 
 extern "C" int ctmi_gemm(const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor,
@@ -1131,6 +1163,7 @@ extern "C" int ctmi_gemm(const void* A, int64_t lda, int a_kmajor, const void* B
             if (g.splits <= 1) { g.splits = 1; g.k_per_split = K; g.slabs = nullptr; }
         }
     }
-    if (dtype == CTMI_F32) return gemm_dispatch<float>(g, a_kmajor, b_kmajor, epilogue, out_f32, fast, as_stream(stream));
-    return gemm_dispatch<bf16_t>(g, a_kmajor, b_kmajor, epilogue, out_f32, fast, as_stream(stream));
+    if (dtype == CTMI_F32) return gemm_dispatch_f32(g, a_kmajor, b_kmajor, epilogue, fast, as_stream(stream));
+    return gemm_dispatch_bf16(g, a_kmajor, b_kmajor, epilogue, out_f32, fast, as_stream(stream));
 }
+#endif  // CTMI_GEMM_HAS(0)
