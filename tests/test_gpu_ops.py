@@ -497,3 +497,23 @@ def test_scale_and_scale_copy_bit_exact():
         want = (y * 0.5).cpu()
         o.scale_(y, 0.5)
         assert torch.equal(y.cpu(), want)
+
+
+@pytest.mark.parametrize("env", [{"CTMI_GEMM_TILE": "0"}, {"CTMI_GEMM_TILE": "1"}, {"CTMI_GEMM_TILE": "2"}, {"CTMI_GEMM_TILE": "3"},
+                                 {"CTMI_GEMM_TILE": "4"}, {"CTMI_GEMM_SHARED": "1"}, {"CTMI_GEMM_PERSIST": "0"},
+                                 {"CTMI_GEMM_TILE": "3", "CTMI_GEMM_SPLIT": "1"}, {"CTMI_GEMM_GLDS": "0"}],
+                         ids=lambda e: ",".join(f"{k[10:]}={v}" for k, v in e.items()))
+def test_gemm_every_tile_schedule_and_policy(env):
+    """The launcher picks tile / schedule / split per shape and caches its environment overrides per process, so the
+    default run exercises only what the picker chooses for the test shapes.  Re-run the GEMM parity tests in a fresh
+    process under every override: 128x128, 256x128, 256x256 free-running, 256x256 and 128x256 ping-pong (LDS-shuffled
+    epilogue), the shared-GPU policy, non-persistent launches, no split-K, and the register-staged v1 kernel."""
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k",
+                        "test_gemm_forward_dgrad_wgrad or test_gemm_transpose_detecting_identity or test_linear"],
+                       env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:]
