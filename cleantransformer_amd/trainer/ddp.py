@@ -68,7 +68,8 @@ class _TiedGradSync:
         its alpha: torch-DDP's pre-division at no cost), None for the generic bucket path (no sync, a single rank, or
         gradient accumulation pending in ``weight.grad``)."""
         o = self.owner
-        if not o.require_backward_grad_sync or o.world_size == 1 or weight.grad is not None:
+        single = o.world_size == 1 and os.environ.get("CTMI_DDP_TIED_EARLY_AT_WORLD1") != "1"     # (test hook: exercise the path on 1 rank)
+        if not o.require_backward_grad_sync or single or weight.grad is not None:
             return None
         return 1.0 / o.world_size
 

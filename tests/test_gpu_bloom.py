@@ -255,3 +255,50 @@ def test_full_size_properties_bf16():
         losses.append(float(loss))
     assert all(math.isfinite(x) for x in losses) and losses[0] > losses[1] > losses[2], losses
     assert 12.0 < losses[0] < 20.0, losses                                                    # > ln V = 12.43
+
+
+def test_ddp_wrapper_on_rccl_single_rank():
+    """One-rank RCCL process group on the GPU: the data-parallel wrapper's collectives (bucket all-reduce from the autograd
+    hooks, the tied-gradient early all-reduce, the id / row all_gather_into_tensor) run on the real backend and leave the
+    gradients of the plain model unchanged (world = 1: averaging is the identity).  Multi-rank semantics are covered on CPU
+    over gloo (tests/test_ddp_gloo.py); this is the check that RCCL accepts the calls, dtypes and stream usage."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", CTMI_DDP_TIED_EARLY_AT_WORLD1="1")
+dist.init_process_group("nccl", rank=0, world_size=1)
+from cleantransformer_amd.models.modeling_bloom import BloomConfig, BloomForCausalLM
+from cleantransformer_amd.trainer.ddp import DistributedDataParallel as DDP
+torch.manual_seed(0)
+dev = torch.device("cuda:0")
+def make():
+    torch.manual_seed(1)
+    m = BloomForCausalLM(BloomConfig(vocab_size=1000, hidden_size=128, n_layer=2, num_attention_heads=4, compute_dtype="bf16")).to(dev)
+    m._tie_weight()
+    return m.train()
+ids = torch.randint(0, 1000, (2, 64), device=dev)
+am = torch.ones(2, 64, dtype=torch.long, device=dev)
+ref = make()
+(l0, _, _), _ = ref(input_ids=ids, attention_mask=am, labels=ids.clone()); l0.backward()
+m = make(); ddp = DDP(m, device_ids=[0], bucket_cap_mb=0.25)
+for it in range(2):
+    for p in m.parameters(): p.grad = None
+    (l1, _, _), _ = ddp(input_ids=ids, attention_mask=am, labels=ids.clone()); l1.backward()
+torch.cuda.synchronize()
+assert ddp._tied_sync.steps == 2, ddp._tied_sync.steps
+assert len(ddp.bucket_summary()) >= 3
+assert abs(float(l0) - float(l1)) < 1e-6
+for (n, a), (_, b) in zip(ref.named_parameters(), m.named_parameters()):
+    assert b.grad is not None and a.grad.shape == b.grad.shape, n
+    tol = 1e-5 * float(a.grad.abs().max()) + 1e-12          # embedding rows: fp32 atomics, order may differ
+    assert float((a.grad - b.grad).abs().max()) <= tol, (n, float((a.grad - b.grad).abs().max()), tol)
+dist.destroy_process_group()
+print("RCCL_DDP_OK")
+'''
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_DDP_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
