@@ -11,6 +11,7 @@ Files written:
     tiny_bloom.npz   tiny Bloom (V=211,H=64,nh=8,L=2,B=4,S=16): logits, every grad, 4-step trajectory,
                      left-padded variant (uniform-row quirk), greedy tokens
     c1_bloom.json    config-1 shape (V=250880,H=1024,nh=16,L=2,B=2,S=128): scalars + slices
+    c5_bloom.json    Bloom-7B1 geometry (V=250880,H=4096,nh=32,hd=128), L=1,B=1,S=512: scalars + slices
     ddp_tiny.npz     2- and 4-rank torch-DDP(gloo) averaged grads of the reference tiny model
     known_answers.json   the reference's own printed self-check values (loss.py:76-100 etc.)
 """
@@ -285,6 +286,32 @@ def gen_c1():
     print("c1: sha", sha[:16], "ids", ids_sha[:16], "traj", rec)
 
 
+def gen_c5():
+    """Bloom-7B1 geometry (BASELINE configs[4]: H=4096, nh=32 -> hd=128, V=250880), one layer, B=1, S=512: the head-dim-128
+    attention tiles and the 4096-wide GEMM / LayerNorm paths against the reference itself (scalars + slices only)."""
+    V, H, L, nh, B, S = 250880, 4096, 1, 32, 1, 512
+    cfg, m = build(V, H, L, nh)
+    sha = weights_sha(m)
+    ids = torch.randint(0, V, (B, S), generator=torch.Generator().manual_seed(7))
+    am = torch.ones(B, S, dtype=torch.long)
+    am[0, 400:] = 0
+    ids_sha = hashlib.sha256(ids.numpy().tobytes()).hexdigest()
+    rec, first = run_steps(m, ids, am, 2)
+    lg = first["logits"]
+    per_param = {n: float(g.double().pow(2).sum().sqrt()) for n, g in first["grads"].items()}
+    doc = dict(cfg=dict(V=V, H=H, L=L, nh=nh, B=B, S=S, pad_row=0, pad_from=400),
+               weights_sha256=sha, ids_sha256=ids_sha,
+               traj=[[float(a), float(b)] for a, b in rec],
+               argmax=lg.argmax(-1).tolist(),
+               logits_first8=lg[:, ::16, :8].tolist(),
+               lm_head_grad_probe=first["grads"]["bloom.word_embeddings.weight"][100:110, 100:110].tolist(),
+               qkv_grad_probe=first["grads"]["bloom.blocks.0.self_attention.query_key_value.weight"][:6, :6].tolist(),
+               per_param_grad_norm=per_param,
+               hidden_first4=first["hidden"][:, ::16, :4].tolist())
+    json.dump(doc, open(os.path.join(HERE, "c5_bloom.json"), "w"))
+    print("c5: sha", sha[:16], "ids", ids_sha[:16], "traj", rec)
+
+
 # ---------------------------------------------------------------------------------------
 def _ddp_worker(rank, world, port, ret):
     import torch.distributed as dist
@@ -345,13 +372,15 @@ def gen_known():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["ops", "tiny", "c1", "ddp", "known"]
+    which = sys.argv[1:] or ["ops", "tiny", "c1", "c5", "ddp", "known"]
     if "ops" in which:
         gen_ops()
     if "tiny" in which:
         gen_tiny()
     if "c1" in which:
         gen_c1()
+    if "c5" in which:
+        gen_c5()
     if "ddp" in which:
         gen_ddp()
     if "known" in which:

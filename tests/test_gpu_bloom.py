@@ -199,6 +199,60 @@ def test_c1_config_bf16_loss_curve_equivalent():
         assert abs(gn - doc["traj"][t][1]) <= 3e-2 * gn, (t, gn, doc["traj"][t])
 
 
+def _c5_inputs(doc):
+    c = doc["cfg"]
+    ids = torch.randint(0, c["V"], (c["B"], c["S"]), generator=torch.Generator().manual_seed(7))
+    assert hashlib.sha256(ids.numpy().tobytes()).hexdigest() == doc["ids_sha256"]
+    am = torch.ones(c["B"], c["S"], dtype=torch.long)
+    am[c["pad_row"], c["pad_from"]:] = 0
+    return c, ids.to(DEV), am.to(DEV)
+
+
+def test_c5_bloom7b1_geometry_fp32_matches_reference():
+    """BASELINE config 5 geometry (Bloom-7B1: H=4096, nh=32, head_dim=128, V=250880), one layer, B=1 S=512, fp32: the
+    head-dim-128 attention tiles and the 4096-wide GEMM / LayerNorm / AdamW paths against values produced by the
+    reference itself (tests/golden/make_golden.py c5)."""
+    doc = json.load(open(os.path.join(G, "c5_bloom.json")))
+    c, ids, am = _c5_inputs(doc)
+    m = build(c["V"], c["H"], c["L"], c["nh"])
+    from cleantransformer_amd.optimizer import AdamW
+    opt = AdamW(m.parameters(), lr=1e-5, weight_decay=0.01, decoupled=True)
+    for t in range(2):
+        (loss, logits, hidden), _ = m(input_ids=ids, attention_mask=am, labels=ids.clone())
+        opt.zero_grad()
+        loss.backward()
+        gn = gnorm(m)
+        if t == 0:
+            assert logits.argmax(-1).cpu().tolist() == doc["argmax"]                       # bit-exact token ids
+            close("c5.logits", logits[:, ::16, :8], torch.tensor(doc["logits_first8"]), 1e-4, 1e-5)
+            close("c5.hidden", hidden[:, ::16, :4], torch.tensor(doc["hidden_first4"]), 1e-4, 1e-5)
+            close("c5.probe", m.lm_head.weight.grad[100:110, 100:110], torch.tensor(doc["lm_head_grad_probe"]), 1e-3, 1e-12)
+            close("c5.qkv", m.bloom.blocks[0].self_attention.query_key_value.weight.grad[:6, :6],
+                  torch.tensor(doc["qkv_grad_probe"]), 1e-3, 1e-10)
+            for n, p in m.named_parameters():
+                ref = doc["per_param_grad_norm"][n]
+                assert abs(float(p.grad.double().pow(2).sum().sqrt()) - ref) <= 1e-4 * ref, n
+        opt.step()
+        assert abs(float(loss) - doc["traj"][t][0]) <= 1e-4 * doc["traj"][t][0], (t, float(loss), doc["traj"][t])
+        assert abs(gn - doc["traj"][t][1]) <= 1e-4 * gn, (t, gn, doc["traj"][t])
+
+
+def test_c5_bloom7b1_geometry_bf16_loss_curve_equivalent():
+    doc = json.load(open(os.path.join(G, "c5_bloom.json")))
+    c, ids, am = _c5_inputs(doc)
+    m = build(c["V"], c["H"], c["L"], c["nh"], compute_dtype="bf16")
+    from cleantransformer_amd.optimizer import AdamW
+    opt = AdamW(m.parameters(), lr=1e-5, weight_decay=0.01, decoupled=True)
+    for t in range(2):
+        (loss, _, _), _ = m(input_ids=ids, attention_mask=am, labels=ids.clone())
+        opt.zero_grad()
+        loss.backward()
+        gn = gnorm(m)
+        opt.step()
+        assert abs(float(loss) - doc["traj"][t][0]) <= 3e-3 * doc["traj"][t][0], (t, float(loss), doc["traj"][t])
+        assert abs(gn - doc["traj"][t][1]) <= 3e-2 * gn, (t, gn, doc["traj"][t])
+
+
 def test_oracle_vs_hip_random_config_fp32():
     """A config the goldens do not cover (odd sizes, nh not a power of two, post-LN residual switch)."""
     from cleantransformer_amd.models.modeling_bloom import BloomConfig, BloomForCausalLM
