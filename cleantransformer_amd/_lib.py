@@ -53,6 +53,7 @@ PROTOTYPES = {
     "ctmi_sgd_step": (i32, [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64),
                             i32, f32, f32, f32, f32, i32, vp]),
     "ctmi_cast": (i32, [vp, i32, vp, i32, i64, vp]),
+    "ctmi_transpose_cast": (i32, [vp, vp, i32, i64, i64, vp]),
     "ctmi_sumsq": (i32, [vp, i64, vp, i32, vp]),
     "ctmi_scale": (i32, [vp, i64, f32, vp, vp]),
     "ctmi_scale_copy": (i32, [vp, vp, i64, f32, vp]),

@@ -800,6 +800,33 @@ extern "C" int ctmi_cast(const void* src, int sd, void* dst, int dd, int64_t n, 
     return CTMI_OK;
 }
 
+// dst[c][r] = (TD) src[r][c]   (src fp32 [R,C] row-major -> dst [C,R]): 64x64 tiles through padded LDS, coalesced both ways.
+// GPT-2's Conv1D keeps its weight as [in,out] (modeling_gpt.py:32-46); the GEMM kernels read the [out,in] compute copy.
+template <typename TD>
+__global__ __launch_bounds__(256) void transpose_cast_k(const float* __restrict__ src, TD* __restrict__ dst, int64_t R, int64_t C) {
+    __shared__ float tile[64][65];
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int64_t r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? src[r * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int64_t c = c0 + i, r = r0 + tx;
+        if (c < C && r < R) dst[c * R + r] = Cvt<TD>::from_f(tile[tx][i]);
+    }
+}
+extern "C" int ctmi_transpose_cast(const float* src, void* dst, int dst_dtype, int64_t rows, int64_t cols, void* stream) {
+    CTMI_REQUIRE(src && dst && rows > 0 && cols > 0, "transpose_cast: bad args");
+    const dim3 grid((unsigned)cdiv64(cols, 64), (unsigned)cdiv64(rows, 64));
+    if (dst_dtype == CTMI_F32) hipLaunchKernelGGL((transpose_cast_k<float>), grid, dim3(256), 0, as_stream(stream), src, (float*)dst, rows, cols);
+    else if (dst_dtype == CTMI_BF16) hipLaunchKernelGGL((transpose_cast_k<bf16_t>), grid, dim3(256), 0, as_stream(stream), src, (bf16_t*)dst, rows, cols);
+    else { ctmi_set_error("transpose_cast: unsupported dtype %d", dst_dtype); return CTMI_ERR_UNSUPPORTED; }
+    CTMI_CHECK_LAUNCH("transpose_cast");
+    return CTMI_OK;
+}
+
 __global__ __launch_bounds__(256) void sumsq_k(const float* __restrict__ x, int64_t n, double* __restrict__ out) {
     double s = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) { const double v = x[i]; s += v * v; }

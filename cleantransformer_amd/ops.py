@@ -293,6 +293,29 @@ def cast(src: Tensor, dtype: torch.dtype, out: Optional[Tensor] = None) -> Tenso
     return out
 
 
+def transpose_cast(src: Tensor, dtype: torch.dtype, out: Optional[Tensor] = None) -> Tensor:
+    """src fp32 [R,C] -> out [C,R] in `dtype`."""
+    _need_cuda(src)
+    src = _c(src)
+    R, Cc = src.shape
+    if out is None:
+        out = torch.empty((Cc, R), dtype=dtype, device=src.device)
+    check(_lib.load().ctmi_transpose_cast(_p(src), _p(out), dt_code(dtype), R, Cc, _stream()), "transpose_cast")
+    return out
+
+
+def compute_weight_t(p: Tensor, dtype: torch.dtype) -> Tensor:
+    """The [out,in] compute-dtype copy of a parameter stored as [in,out] (GPT-2 Conv1D).  Cached on the parameter and
+    refreshed when its version counter or storage moved, or when the fused optimizer marked it stale (the fused AdamW
+    updates parameters without moving the counter; see optimizer.py)."""
+    t = getattr(p, "_ct_wt", None)
+    if t is None or t.dtype != dtype or t.device != p.device or getattr(p, "_ct_wt_ver", -1) != p._version \
+            or getattr(p, "_ct_wt_ptr", 0) != p.data_ptr() or getattr(p, "_ct_wt_stale", False):
+        t = transpose_cast(p.detach(), dtype, out=t if (t is not None and t.dtype == dtype and t.device == p.device) else None)
+        p._ct_wt, p._ct_wt_ver, p._ct_wt_ptr, p._ct_wt_stale = t, p._version, p.data_ptr(), False
+    return t
+
+
 def sumsq(x: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
     if out is None:
         out = torch.zeros(1, dtype=torch.float64, device=x.device)

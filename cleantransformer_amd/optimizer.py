@@ -74,6 +74,8 @@ class AdamW():
                            mutate_grad=not self.decoupled, grad_scale=self.grad_scale)
             for i in idx:
                 self.steps[i] += 1
+                if hasattr(self.params[i], "_ct_wt"):
+                    self.params[i]._ct_wt_stale = True         # transposed compute copy (GPT-2 Conv1D) must be rebuilt
 
 
 class SGD():
@@ -112,3 +114,6 @@ class SGD():
             ops.sgd_step(ps, [p.grad for p in ps], [self.momentum_buffer[i] for i in idx] if self.momentum else None, shadows,
                          lr=self.lr, momentum=self.momentum or 0.0, dampening=self.dampening or 0.0,
                          weight_decay=self.weight_decay or 0.0, first_step=is_first)
+            for p in ps:
+                if hasattr(p, "_ct_wt"):
+                    p._ct_wt_stale = True                      # transposed compute copy (GPT-2 Conv1D) must be rebuilt

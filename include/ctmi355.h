@@ -149,6 +149,8 @@ int ctmi_sgd_step(float* const* p, float* const* g, float* const* buf /* momentu
 
 /* ---- small utilities on flat buffers */
 int ctmi_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
+/* dst[c][r] = cast(src[r][c]): the [out,in] compute copy of a GPT-2 Conv1D weight kept as [in,out] (modeling_gpt.py:32-46) */
+int ctmi_transpose_cast(const float* src, void* dst, int dst_dtype, int64_t rows, int64_t cols, void* stream);
 /* out[0] (+)= sum(x^2), fp64 accumulation (device double) — global grad-norm (trainer.py:491-498 clip_grad_norm_) */
 int ctmi_sumsq(const float* x, int64_t n, double* out, int accumulate, void* stream);
 int ctmi_scale(float* x, int64_t n, float s, const float* s_dev /* optional device scalar multiplier */, void* stream);

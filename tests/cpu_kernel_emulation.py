@@ -195,6 +195,14 @@ def cast(src, dtype, out=None):
     return r
 
 
+def transpose_cast(src, dtype, out=None):
+    t = src.detach().t().contiguous().to(dtype)
+    if out is None:
+        return t
+    out.copy_(t)
+    return out
+
+
 def sumsq(x, out=None, accumulate=False):
     s = x.double().pow(2).sum().reshape(1)
     if out is None:
@@ -252,6 +260,6 @@ def install(monkeypatch):
     """Patch cleantransformer_amd.ops in place (pytest's monkeypatch undoes it after the test)."""
     from cleantransformer_amd import ops
     for name in ("layernorm_fwd", "layernorm_bwd", "gemm", "colsum", "MaskInfo", "attn_fwd", "attn_bwd", "embed_fwd", "embed_bwd",
-                 "ce_fwd", "ce_bwd", "cast", "sumsq", "scale_", "argmax_lastdim", "adamw_step", "sgd_step"):
+                 "ce_fwd", "ce_bwd", "cast", "transpose_cast", "sumsq", "scale_", "argmax_lastdim", "adamw_step", "sgd_step"):
         monkeypatch.setattr(ops, name, globals()[name])
     monkeypatch.setattr(ops, "_need_cuda", lambda *a: None)

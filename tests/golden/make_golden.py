@@ -12,6 +12,7 @@ Files written:
                      left-padded variant (uniform-row quirk), greedy tokens
     c1_bloom.json    config-1 shape (V=250880,H=1024,nh=16,L=2,B=2,S=128): scalars + slices
     c5_bloom.json    Bloom-7B1 geometry (V=250880,H=4096,nh=32,hd=128), L=1,B=1,S=512: scalars + slices
+    tiny_gpt.npz     tiny GPT-2 / GPT-1 (modeling_gpt.py): logits, grads, 3-step trajectory, greedy tokens
     ddp_tiny.npz     2- and 4-rank torch-DDP(gloo) averaged grads of the reference tiny model
     known_answers.json   the reference's own printed self-check values (loss.py:76-100 etc.)
 """
@@ -312,6 +313,64 @@ def gen_c5():
     print("c5: sha", sha[:16], "ids", ids_sha[:16], "traj", rec)
 
 
+def gen_gpt():
+    """Tiny GPT-2 (pre-LN) and GPT-1 (post-LN) from the reference's modeling_gpt.py: logits, every gradient of the shifted
+    cross-entropy, a 3-step torch.optim.AdamW trajectory, parameters after it, greedy tokens (KV cache)."""
+    from CleanTransformer.models import modeling_gpt as rg
+    V, H, L, nh, P, B, S = 173, 64, 2, 4, 64, 3, 24
+
+    def build_gpt(version):
+        cfg = rg.GPTConfig(vocab_size=V, n_embd=H, n_positions=P, n_layer=L, n_head=nh, n_ctx=P,
+                           embd_pdrop=0.0, attn_pdrop=0.0, resid_pdrop=0.0)
+        m = rg.GPTLMHeadModel(cfg, version=version)
+        with torch.no_grad():
+            for i, (name, prm) in enumerate(m.named_parameters()):
+                r = torch.randn(prm.shape, generator=torch.Generator().manual_seed(1000 + i))
+                if prm.dim() > 1:
+                    prm.copy_(r * 0.02)
+                elif ("norm" in name or "ln_f" in name) and name.endswith("weight"):
+                    prm.copy_(1 + 0.1 * r)
+                else:
+                    prm.copy_(0.02 * r)
+        for blk in m.gpt.blocks:
+            blk.mlp[3].p = 0.0                              # the reference's trailing torch.nn.Dropout() (p = 0.5) neutralised
+        return cfg, m.train()
+
+    ids = torch.randint(0, V, (B, S), generator=torch.Generator().manual_seed(7))
+    am = torch.ones(B, S, dtype=torch.long)
+    am[1, 18:] = 0                                          # right padding
+    ce = torch.nn.CrossEntropyLoss()
+    out = dict(cfg=np.array([V, H, L, nh, P, B, S]), ids=npy(ids), mask=npy(am))
+    for version in ("gpt2", "gpt"):
+        cfg, m = build_gpt(version)
+        out[f"{version}_names"] = np.array([n for n, _ in m.named_parameters()])
+        opt = torch.optim.AdamW(m.parameters(), lr=1e-5)
+        rec = []
+        for t in range(3):
+            (logits, hidden), _ = m(ids, attention_mask=am)
+            loss = ce(logits[:, :-1, :].reshape(-1, V), ids[:, 1:].reshape(-1))
+            opt.zero_grad()
+            loss.backward()
+            gn = gnorm(m)
+            if t == 0:
+                out[f"{version}_logits0"], out[f"{version}_hidden0"], out[f"{version}_loss0"] = npy(logits), npy(hidden), npy(loss)
+                for n, prm in m.named_parameters():
+                    out[f"{version}_g0_" + n] = npy(prm.grad)
+            opt.step()
+            rec.append((float(loss), gn))
+        out[f"{version}_traj"] = np.array(rec, dtype=np.float64)
+        for n, prm in m.named_parameters():
+            out[f"{version}_p3_" + n] = npy(prm)
+        print("gpt", version, "traj", rec)
+    cfg, m = build_gpt("gpt2")
+    m.eval()
+    p_ids = ids[:2, :7].clone()
+    gen = m.generate(p_ids, attention_mask=torch.ones(2, 7, dtype=torch.long),
+                     generation_configs=dict(beam_size=1, max_gen_len=6, do_sample=False, end_ids=None, pad_id=3))
+    out.update(greedy_prompt=npy(p_ids), greedy_out=npy(gen))
+    np.savez_compressed(os.path.join(HERE, "tiny_gpt.npz"), **out)
+
+
 # ---------------------------------------------------------------------------------------
 def _ddp_worker(rank, world, port, ret):
     import torch.distributed as dist
@@ -372,7 +431,7 @@ def gen_known():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["ops", "tiny", "c1", "c5", "ddp", "known"]
+    which = sys.argv[1:] or ["ops", "tiny", "c1", "c5", "gpt", "ddp", "known"]
     if "ops" in which:
         gen_ops()
     if "tiny" in which:
@@ -381,6 +440,8 @@ if __name__ == "__main__":
         gen_c1()
     if "c5" in which:
         gen_c5()
+    if "gpt" in which:
+        gen_gpt()
     if "ddp" in which:
         gen_ddp()
     if "known" in which:

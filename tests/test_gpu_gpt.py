@@ -1,0 +1,135 @@
+"""GPU: the GPT / GPT-2 path (BASELINE configs[3]) through the C ABI against golden vectors produced by the reference's own
+modeling_gpt.py (tests/golden/tiny_gpt.npz) and against the oracle at a head_dim-64 / seq-2048-style geometry."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle import gpt_ref as GR  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+G = os.path.join(HERE, "golden")
+GPT = np.load(os.path.join(G, "tiny_gpt.npz"))
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def close(name, got, ref, rtol, atol=0.0):
+    got, ref = torch.as_tensor(got).detach().double().cpu(), torch.as_tensor(ref).detach().double().cpu()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    err = (got - ref).abs()
+    bad = err > atol + rtol * ref.abs()
+    assert torch.isfinite(got).all(), name
+    assert not bad.any(), f"{name}: {int(bad.sum())}/{bad.numel()} off, worst {float(err.max()):.3e}, ref scale {float(ref.abs().max()):.3e}"
+
+
+def gnorm(m):
+    return math.sqrt(sum(float(p.grad.double().pow(2).sum()) for p in m.parameters()))
+
+
+def build(shape, cd="fp32", params=None):
+    from cleantransformer_amd.models.modeling_gpt import GPTConfig, GPTLMHeadModel
+    cfg = GPTConfig(vocab_size=shape.vocab_size, n_embd=shape.n_embd, n_positions=shape.n_positions, n_layer=shape.n_layer,
+                    n_head=shape.n_head, n_ctx=shape.n_positions, embd_pdrop=0.0, attn_pdrop=0.0, resid_pdrop=0.0, compute_dtype=cd)
+    m = GPTLMHeadModel(cfg, version=shape.version)
+    sd = dict(params if params is not None else GR.det_init(shape))
+    sd["lm_head.weight"] = sd["gpt.tokens_embed.weight"]
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.endswith("attn.bias") for k in missing)
+    m._tie_weights()
+    for blk in m.gpt.blocks:
+        blk.mlp[3].p = 0.0
+    return m.to(DEV).train()
+
+
+def tiny(version):
+    V, H, L, nh, P, B, S = [int(v) for v in GPT["cfg"]]
+    return GR.GPTShape(V, H, L, nh, P, version=version)
+
+
+def test_transpose_cast_bit_exact():
+    from cleantransformer_amd import ops
+    for R_, C_ in ((64, 64), (100, 37), (1024, 3072), (5, 700)):
+        x = torch.randn(R_, C_, generator=torch.Generator().manual_seed(R_))
+        xd = x.to(DEV)
+        assert torch.equal(ops.transpose_cast(xd, torch.float32).cpu(), x.t().contiguous())
+        assert torch.equal(ops.transpose_cast(xd, torch.bfloat16).cpu(), x.t().contiguous().to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("version", ["gpt2", "gpt"])
+def test_gpt_fp32_matches_reference_golden(version):
+    from cleantransformer_amd.optimizer import AdamW
+    m = build(tiny(version))
+    assert [n for n, _ in m.named_parameters()] == list(GPT[f"{version}_names"])
+    ids, am = T(GPT["ids"]).to(DEV), T(GPT["mask"]).to(DEV)
+    opt = AdamW(m.parameters(), lr=1e-5, weight_decay=0.01, decoupled=True)
+    for t in range(3):
+        (loss, logits, hidden), _ = m(ids, attention_mask=am, labels=ids.clone())
+        opt.zero_grad()
+        loss.backward()
+        gn = gnorm(m)
+        if t == 0:
+            assert torch.equal(logits.argmax(-1).cpu(), T(GPT[f"{version}_logits0"]).argmax(-1))        # token ids bit-exact
+            close("logits0", logits, GPT[f"{version}_logits0"], 1e-4, 2e-6)
+            close("hidden0", hidden, GPT[f"{version}_hidden0"], 1e-4, 2e-6)
+            for n, p in m.named_parameters():
+                close("g0_" + n, p.grad, GPT[f"{version}_g0_" + n], 2e-4, 2e-7)
+        opt.step()
+        assert abs(float(loss) - GPT[f"{version}_traj"][t, 0]) <= 1e-5 * float(loss), (t, float(loss))
+        assert abs(gn - GPT[f"{version}_traj"][t, 1]) <= 1e-4 * gn, (t, gn)
+    for n, p in m.named_parameters():
+        if n.endswith("attn.c_attn.bias"):
+            continue                                        # zero-gradient key slice: see tests/test_gpt_cpu.py::close_params
+        close("p3_" + n, p, GPT[f"{version}_p3_" + n], 1e-5, 2e-7)
+
+
+def test_gpt_greedy_decode_bit_exact():
+    m = build(tiny("gpt2")).eval()
+    out = m.generate(T(GPT["greedy_prompt"]).to(DEV), attention_mask=torch.ones(2, 7, dtype=torch.long, device=DEV),
+                     generation_configs=dict(beam_size=1, max_gen_len=6, do_sample=False, end_ids=None, pad_id=3))
+    assert np.array_equal(out.cpu().numpy(), GPT["greedy_out"])
+
+
+def test_gpt_bf16_mode_tracks_fp32():
+    m = build(tiny("gpt2"), cd="bf16")
+    ids, am = T(GPT["ids"]).to(DEV), T(GPT["mask"]).to(DEV)
+    (loss, logits, _), _ = m(ids, attention_mask=am, labels=ids.clone())
+    assert logits.dtype == torch.bfloat16
+    assert abs(float(loss) - float(GPT["gpt2_loss0"])) <= 5e-3 * float(GPT["gpt2_loss0"])
+    loss.backward()
+    gn = gnorm(m)
+    assert abs(gn - GPT["gpt2_traj"][0, 1]) <= 3e-2 * gn
+    for n, p in m.named_parameters():
+        ref = T(GPT["gpt2_g0_" + n]).double()
+        err = float((p.grad.double().cpu() - ref).norm() / (ref.norm() + 1e-30))
+        assert p.grad.dtype == torch.float32 and p.grad.shape == p.shape and (err < 6e-2 or float(ref.norm()) < 1e-6), (n, err)
+
+
+def test_gpt2_medium_geometry_vs_oracle_fp32():
+    """GPT-2-medium geometry (n_embd=1024, 16 heads -> head_dim 64, V=50257) on a long right-padded sequence, 2 layers:
+    fp32 parity with the oracle (itself pinned to the reference at the tiny size) — loss, logits, gradient norms."""
+    s = GR.GPTShape(50257, 1024, 2, 16, 1024, version="gpt2")
+    p = GR.det_init(s)
+    B, S = 2, 640
+    ids = torch.randint(0, s.vocab_size, (B, S), generator=torch.Generator().manual_seed(11))
+    am = torch.ones(B, S, dtype=torch.long)
+    am[1, 500:] = 0
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    loss_o, logits_o, _, grads_o = GR.loss_and_grads(p, s, ids, am)
+    m = build(s, params=p)
+    (loss, logits, _), _ = m(ids.to(DEV), attention_mask=am.to(DEV), labels=ids.to(DEV).clone())
+    loss.backward()
+    assert abs(float(loss) - float(loss_o)) <= 1e-5 * float(loss_o)
+    assert torch.equal(logits.argmax(-1).cpu(), logits_o.argmax(-1))
+    close("logits", logits[:, ::37, ::501], logits_o[:, ::37, ::501], 1e-4, 1e-5)
+    for n, prm in m.named_parameters():
+        a, b = float(prm.grad.double().norm()), float(grads_o[n].double().norm())
+        assert abs(a - b) <= 1e-4 * b + 1e-9, (n, a, b)
