@@ -276,10 +276,17 @@ class LMHeadFn(torch.autograd.Function):
         B, S, H = hidden.shape
         h2 = hidden.reshape(B * S, H)
         h2 = h2 if h2.is_contiguous() else h2.contiguous()
-        logits = ops.linear_fwd(h2, ops.compute_weight(weight, hidden.dtype), tag="lm_head_fwd")
+        V = weight.shape[0]
+        wc = ops.compute_weight(weight, hidden.dtype)
+        out = None
+        if V % 8 != 0 and hidden.dtype != torch.float32:
+            # odd vocabulary (GPT-2: 50257): logits live in a buffer whose row pitch is padded to a multiple of 32, so rows
+            # stay 16-byte aligned for the loss kernels and the two LM-head backward GEMMs; the caller sees the [.., :V] view
+            out = torch.empty((B * S, ops.pad_rows(V)), dtype=hidden.dtype, device=hidden.device)[:, :V]
+        logits = ops.linear_fwd(h2, wc, tag="lm_head_fwd", out=out)
         ctx.save_for_backward(h2, weight)
         ctx.tie, ctx.shape = tie, (B, S, H)
-        return logits.view(B, S, weight.shape[0])
+        return logits.view(B, S, V)
 
     @staticmethod
     def backward(ctx, dlogits: Tensor):
@@ -287,13 +294,23 @@ class LMHeadFn(torch.autograd.Function):
         B, S, H = ctx.shape
         V = weight.shape[0]
         d2 = dlogits.reshape(B * S, V)
-        d2 = d2 if d2.is_contiguous() else d2.contiguous()
-        dh = ops.linear_dgrad(d2, ops.compute_weight(weight, h2.dtype))
+        wc = ops.compute_weight(weight, h2.dtype)
         tie = ctx.tie
         tied = tie is not None and tie.embed_wants
         sync = getattr(weight, "_ct_tied_sync", None) if tied else None       # set by trainer/ddp.py on the shared [V,H] parameter
         pre = sync.prescale(weight) if sync is not None else None             # 1/world when this step reduces the dense part early
-        dw = ops.linear_wgrad(d2, h2, alpha=1.0 if pre is None else pre)
+        Vp = ops.ZERO_PADDED.pop(d2.data_ptr(), (None, None))[0] if d2.is_cuda else None
+        wpad = getattr(weight, "_ct_shadow_pad", None)
+        if Vp is not None and d2.stride() == (Vp, 1) and wpad is not None and wpad.shape[0] == Vp and wpad.dtype == h2.dtype:
+            # zero-padded dlogits [T, Vp] against the zero-padded table copy [Vp, H]: both GEMMs see aligned, 32-divisible
+            # extents (K = Vp for the dgrad, M = Vp for the wgrad) and the padding contributes exact zeros
+            dp = d2.as_strided((B * S, Vp), (Vp, 1))
+            dh = ops.linear_dgrad(dp, wpad)
+            dw = ops.linear_wgrad(dp, h2, alpha=1.0 if pre is None else pre)[:V]
+        else:
+            d2 = d2 if d2.is_contiguous() else d2.contiguous()
+            dh = ops.linear_dgrad(d2, wc)
+            dw = ops.linear_wgrad(d2, h2, alpha=1.0 if pre is None else pre)
         if tied:
             tie.pending = dw                                   # the embedding backward (always later) finishes and returns it
             if pre is not None:
@@ -311,7 +328,7 @@ class ShiftedCrossEntropyFn(torch.autograd.Function):
     def forward(ctx, logits: Tensor, labels: Tensor):
         B, S, V = logits.shape
         l2 = logits.reshape(B * S, V)
-        l2 = l2 if l2.is_contiguous() else l2.contiguous()
+        l2 = l2 if l2.stride(1) == 1 else l2.contiguous()                  # a padded row pitch is fine: the kernels take ld
         lab = labels.to(torch.int64)
         lab = lab if lab.is_contiguous() else lab.contiguous()
         loss_out, row_lse = ops.ce_fwd(l2, lab, seq=S, shift=1, ignore_index=-100, denom_mode=0)
@@ -325,7 +342,17 @@ class ShiftedCrossEntropyFn(torch.autograd.Function):
         B, S, V = ctx.shape
         g = gout.to(torch.float32).reshape(1)
         g = g if g.is_contiguous() else g.contiguous()
-        d = ops.ce_bwd(l2, lab, row_lse, loss_out, g, seq=S, shift=1, ignore_index=-100)
+        out = None
+        if l2.is_cuda and l2.stride(0) != V and l2.stride(0) == ops.pad_rows(V):
+            # logits came with a padded row pitch (odd vocabulary): give dlogits the same pitch and zero its pad columns, and
+            # tell the LM-head backward so (it then runs both of its GEMMs over the padded extent)
+            Vp = l2.stride(0)
+            buf = torch.empty((B * S, Vp), dtype=l2.dtype, device=l2.device)
+            buf[:, V:].zero_()
+            out = buf[:, :V]
+            ops.ZERO_PADDED.clear()                                       # at most one live entry (it pins its buffer)
+            ops.ZERO_PADDED[out.data_ptr()] = (Vp, buf)
+        d = ops.ce_bwd(l2, lab, row_lse, loss_out, g, seq=S, shift=1, ignore_index=-100, out=out)
         return d.view(B, S, V), None
 
 

@@ -132,7 +132,8 @@ def gemm(A: Tensor, lda: int, a_kmajor: bool, B: Tensor, ldb: int, b_kmajor: boo
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     ws = _splitk_ws(A.device) if (epilogue == _lib.EPI_NONE and bias is None and residual is None) else None
-    check(_lib.load().ctmi_gemm(_p(A), lda, int(a_kmajor), _p(B), ldb, int(b_kmajor), _p(out), N, M, N, K, float(alpha), int(beta),
+    ldc = out.stride(0) if out.dim() == 2 else N                       # a column-padded output buffer keeps its own row pitch
+    check(_lib.load().ctmi_gemm(_p(A), lda, int(a_kmajor), _p(B), ldb, int(b_kmajor), _p(out), ldc, M, N, K, float(alpha), int(beta),
                                 _p(bias), _p(residual), int(epilogue), _p(aux_in), _p(aux_out), int(out_f32), dt_code(dtype),
                                 _p(ws), 0 if ws is None else ws.numel() * 4, _stream()), "gemm")
     if timed:
@@ -142,11 +143,12 @@ def gemm(A: Tensor, lda: int, a_kmajor: bool, B: Tensor, ldb: int, b_kmajor: boo
 
 
 def linear_fwd(x2d: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None,
-               epilogue: int = _lib.EPI_NONE, aux_out: Optional[Tensor] = None, tag: Optional[str] = None) -> Tensor:
+               epilogue: int = _lib.EPI_NONE, aux_out: Optional[Tensor] = None, tag: Optional[str] = None,
+               out: Optional[Tensor] = None) -> Tensor:
     """y[T,out] = epilogue(x[T,in] @ w[out,in]^T + bias) (+ residual).  w in the compute dtype."""
     T, K = x2d.shape
     N = w.shape[0]
-    return gemm(x2d, K, False, w, K, False, T, N, K, bias=bias, residual=residual, epilogue=epilogue, aux_out=aux_out, tag=tag)
+    return gemm(x2d, K, False, w, K, False, T, N, K, bias=bias, residual=residual, epilogue=epilogue, aux_out=aux_out, tag=tag, out=out)
 
 
 def linear_dgrad(dy: Tensor, w: Tensor, epilogue: int = _lib.EPI_NONE, aux_in: Optional[Tensor] = None,
@@ -372,6 +374,17 @@ def sgd_step(params, grads, bufs, shadows, *, lr, momentum, dampening, weight_de
 
 
 # ------------------------------------------------------------------------------------------------ bf16 shadows
+PAD_ROWS = 32
+
+
+def pad_rows(n: int) -> int:
+    return (n + PAD_ROWS - 1) // PAD_ROWS * PAD_ROWS
+
+
+# dlogits buffers whose columns [V, pad) are known to be zero: data_ptr -> (padded column count, the buffer) — set by the loss
+# backward, consumed by the LM-head backward of the same step
+ZERO_PADDED = {}
+
 def compute_weight(p: Tensor, dtype: torch.dtype) -> Tensor:
     """The matrix `p` (an fp32 master parameter) in the compute dtype.  fp32 -> p itself.  bf16 -> a cached shadow,
     refreshed when p's version counter moved (torch optimizers / load_state_dict) and written directly by the fused
@@ -381,6 +394,12 @@ def compute_weight(p: Tensor, dtype: torch.dtype) -> Tensor:
     sh = getattr(p, "_ct_shadow", None)
     if sh is None or sh.device != p.device or sh.shape != p.shape or getattr(p, "_ct_shadow_ver", -1) != p._version \
             or getattr(p, "_ct_shadow_ptr", 0) != p.data_ptr():
+        if (sh is None or sh.shape != p.shape or sh.device != p.device) and p.dim() == 2 and p.shape[0] % PAD_ROWS != 0:
+            # a table whose row count is not a multiple of 32 (GPT-2's V = 50257): the shadow is the head of a zero-padded
+            # buffer, so the LM-head dgrad can run with an aligned, 32-divisible K (see models.modeling_bloom.LMHeadFn)
+            buf = torch.zeros((pad_rows(p.shape[0]), p.shape[1]), dtype=dtype, device=p.device)
+            sh = buf[:p.shape[0]]
+            p._ct_shadow_pad = buf
         sh = cast(p.detach(), dtype, out=sh if (sh is not None and sh.shape == p.shape and sh.device == p.device) else None)
         p._ct_shadow = sh
         p._ct_shadow_ver = p._version

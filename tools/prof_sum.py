@@ -1,5 +1,6 @@
 import csv,glob,sys
-f=glob.glob(sys.argv[1]+'/*/*_kernel_stats.csv')[0]
+import os
+f=max(glob.glob(sys.argv[1]+'/*/*_kernel_stats.csv'), key=os.path.getmtime)
 n=int(sys.argv[2]); top=int(sys.argv[3]) if len(sys.argv)>3 else 14
 rows=list(csv.DictReader(open(f)))
 tot=sum(float(r['TotalDurationNs']) for r in rows)
