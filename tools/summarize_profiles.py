@@ -13,7 +13,7 @@ LM = "gemm_glds_kernel<unsigned short, false, false, 0, 8, 4, true, false>"     
 
 
 def one(pattern):
-    return glob.glob(os.path.join(src, pattern))[0]
+    return max(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)     # newest run if several were merged back
 
 
 def kernel_table(run_dir, steps_traced, title, out_name):
