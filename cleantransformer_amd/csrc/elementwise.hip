@@ -513,7 +513,14 @@ __global__ __launch_bounds__(256) void ce_fwd_k(const T* __restrict__ logits, in
     const T* x = logits + row * ld;
     float m = -INFINITY, s = 0.f;
     if (vec_ok) {
-        for (int64_t c = (int64_t)threadIdx.x * VEC; c < C; c += 256 * VEC) {
+        const int64_t Cv = C - C % VEC;                                 // odd class counts (GPT-2: 50257): vector head + scalar tail
+        for (int64_t c = Cv + threadIdx.x; c < C; c += 256) {
+            const float v = Cvt<T>::to_f(x[c]);
+            const float mn = fmaxf(m, v);
+            s = s * __expf(m - mn) + __expf(v - mn);
+            m = mn;
+        }
+        for (int64_t c = (int64_t)threadIdx.x * VEC; c < Cv; c += 256 * VEC) {
             float v[VEC];
             unpack16<T>(*reinterpret_cast<const uint4*>(x + c), v);
             float vm = v[0];
@@ -599,7 +606,10 @@ __global__ __launch_bounds__(256) void ce_bwd_k(const T* __restrict__ logits, in
     const float coef = live ? (gout ? gout[0] : 1.0f) * loss_out[1] : 0.f;
     const float lse = row_lse[row];
     if (vec_ok) {
-        for (int64_t c = (int64_t)threadIdx.x * VEC; c < C; c += 256 * VEC) {
+        const int64_t Cv = C - C % VEC;
+        for (int64_t c = Cv + threadIdx.x; c < C; c += 256)
+            d[c] = Cvt<T>::from_f(live ? (__expf(Cvt<T>::to_f(x[c]) - lse) - ((c == t) ? 1.0f : 0.0f)) * coef : 0.f);
+        for (int64_t c = (int64_t)threadIdx.x * VEC; c < Cv; c += 256 * VEC) {
             float o[VEC];
             if (live) {
                 float v[VEC];
@@ -625,10 +635,10 @@ extern "C" int ctmi_ce_fwd(const void* logits, int64_t ld, const int64_t* labels
     CTMI_REQUIRE(N > 0 && C > 0 && seq > 0 && N % seq == 0 && shift >= 0 && ld >= C, "ce_fwd: bad shape N=%lld C=%lld seq=%lld", (long long)N, (long long)C, (long long)seq);
     hipStream_t st = as_stream(stream);
     if (dtype == CTMI_F32) {
-        int vec_ok = (C % 4 == 0) && (ld % 4 == 0) && aligned16(logits);
+        int vec_ok = (ld % 4 == 0) && aligned16(logits);
         hipLaunchKernelGGL((ce_fwd_k<float>), dim3((unsigned)N), dim3(256), 0, st, (const float*)logits, ld, labels, row_lse, row_loss, C, seq, shift, ignore_index, vec_ok);
     } else if (dtype == CTMI_BF16) {
-        int vec_ok = (C % 8 == 0) && (ld % 8 == 0) && aligned16(logits);
+        int vec_ok = (ld % 8 == 0) && aligned16(logits);
         hipLaunchKernelGGL((ce_fwd_k<bf16_t>), dim3((unsigned)N), dim3(256), 0, st, (const bf16_t*)logits, ld, labels, row_lse, row_loss, C, seq, shift, ignore_index, vec_ok);
     } else { ctmi_set_error("ce_fwd: unsupported dtype %d", dtype); return CTMI_ERR_UNSUPPORTED; }
     CTMI_CHECK_LAUNCH("ce_fwd");
@@ -644,10 +654,10 @@ extern "C" int ctmi_ce_bwd(const void* logits, int64_t ld, const int64_t* labels
     CTMI_REQUIRE(N > 0 && C > 0 && seq > 0 && N % seq == 0 && ld >= C && ldd >= C, "ce_bwd: bad shape");
     hipStream_t st = as_stream(stream);
     if (dtype == CTMI_F32) {
-        int vec_ok = (C % 4 == 0) && (ld % 4 == 0) && (ldd % 4 == 0) && aligned16(logits) && aligned16(dlogits);
+        int vec_ok = (ld % 4 == 0) && (ldd % 4 == 0) && aligned16(logits) && aligned16(dlogits);
         hipLaunchKernelGGL((ce_bwd_k<float>), dim3((unsigned)N), dim3(256), 0, st, (const float*)logits, ld, labels, row_lse, loss_out, gout, (float*)dlogits, ldd, C, seq, shift, ignore_index, vec_ok);
     } else if (dtype == CTMI_BF16) {
-        int vec_ok = (C % 8 == 0) && (ld % 8 == 0) && (ldd % 8 == 0) && aligned16(logits) && aligned16(dlogits);
+        int vec_ok = (ld % 8 == 0) && (ldd % 8 == 0) && aligned16(logits) && aligned16(dlogits);
         hipLaunchKernelGGL((ce_bwd_k<bf16_t>), dim3((unsigned)N), dim3(256), 0, st, (const bf16_t*)logits, ld, labels, row_lse, loss_out, gout, (bf16_t*)dlogits, ldd, C, seq, shift, ignore_index, vec_ok);
     } else { ctmi_set_error("ce_bwd: unsupported dtype %d", dtype); return CTMI_ERR_UNSUPPORTED; }
     CTMI_CHECK_LAUNCH("ce_bwd");

@@ -362,6 +362,32 @@ def test_cross_entropy_shifted(dtype, rtol, N, C, seq):
         assert float(d.float().cpu()[dead].abs().max()) == 0.0                      # rows without a target carry no gradient
 
 
+@pytest.mark.parametrize("dtype,rtol", [(torch.float32, 2e-6), (torch.bfloat16, 1e-5)])
+def test_cross_entropy_odd_classes_padded_pitch(dtype, rtol):
+    """GPT-2's V = 50257 in a buffer whose row pitch is padded to a multiple of 32 (LMHeadFn): the kernels run their vector
+    body over the 8-divisible head and a scalar tail, on both the logits and the dlogits pitch."""
+    o = ops()
+    N, C, seq, Cp = 8, 50257, 4, 50272
+    logits = rnd(N, C, seed=5) * 2
+    ls = bf(logits) if dtype == torch.bfloat16 else logits
+    labels = torch.randint(0, C, (N,), generator=torch.Generator().manual_seed(6))
+    labels[3] = C - 1                                                       # a target inside the scalar tail
+    rows = torch.tensor([r for r in range(N) if (r % seq) + 1 < seq])
+    lr_ = ls.clone().requires_grad_(True)
+    ref = R.cross_entropy(lr_[rows], labels[rows + 1])
+    ref.backward()
+    buf = torch.full((N, Cp), float("nan"), dtype=dtype, device=DEV)
+    ld = buf[:, :C]
+    ld.copy_(to_dev(logits, dtype))
+    loss_out, row_lse = o.ce_fwd(ld, labels.to(DEV), seq=seq, shift=1)
+    check("ce.loss", loss_out[:1], ref.reshape(1), rtol, 0)
+    check("ce.lse", row_lse, torch.logsumexp(ls.double(), -1), 2e-6, 1e-6)
+    dbuf = torch.zeros((N, Cp), dtype=dtype, device=DEV)
+    d = o.ce_bwd(ld, labels.to(DEV), row_lse, loss_out, None, seq=seq, shift=1, out=dbuf[:, :C])
+    check("ce.dlogits", d.float(), lr_.grad, 1e-2 if dtype == torch.bfloat16 else 1e-5, 1e-9 if dtype == torch.float32 else 1e-6)
+    assert float(dbuf[:, C:].float().abs().max()) == 0.0                  # the pad columns are never written
+
+
 def test_cross_entropy_module_golden_and_known_answers():
     import json
     from cleantransformer_amd.loss import CrossEntropyLoss
