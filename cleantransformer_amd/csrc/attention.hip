@@ -69,6 +69,28 @@ struct AT {
             regs[i] = *reinterpret_cast<const uint4*>(tmp);
         }
     }
+    // Streamed tiles: per-thread row pointers advance by one tile (64 rows) per call, so the steady state issues NCH plain
+    // 16-byte loads and NCH 64-bit adds; the clamped / generic address computation of `load` (64-bit multiplies, min) runs
+    // only for a tile that is not entirely inside the tensor.  (PMC: 43 % of the forward kernel's VALU instructions were
+    // integer ops, most of them this per-tile address arithmetic.)
+    static __device__ __forceinline__ void stream_init(const T* (&ptrs)[NCH], const T* __restrict__ base, int64_t rs, int64_t row0, int tid) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int id = tid + 256 * i;
+            ptrs[i] = base + (row0 + id / CPR) * rs + (id % CPR) * VEC;
+        }
+    }
+    static __device__ __forceinline__ void stream_load(uint4 (&regs)[NCH], const T* (&ptrs)[NCH], const T* __restrict__ base, int64_t rs,
+                                                       int64_t row0, int64_t nrows, int hd, bool fast, int tid) {
+        if (fast && row0 + 64 <= nrows) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) regs[i] = *reinterpret_cast<const uint4*>(ptrs[i]);
+        } else {
+            load(regs, base, rs, row0, nrows, hd, fast, tid);
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) ptrs[i] += 64 * rs;
+    }
     static __device__ __forceinline__ void store_rm(const uint4 (&regs)[NCH], T* __restrict__ tile, int tid) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
@@ -264,6 +286,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
     float rkb = 0.f;
     A::load(rk, kp, p.k_rs, 0, p.Sk, (int)p.hd, fast, tid);
     A::load(rv, vp, p.v_rs, 0, p.Sk, (int)p.hd, fast, tid);
+    const T* pk[A::NCH];
+    const T* pv[A::NCH];
+    A::stream_init(pk, kp, p.k_rs, 64, tid);
+    A::stream_init(pv, vp, p.v_rs, 64, tid);
     if (tid < 64) rkb = key_bias(p, b, tid, slope);
     A::store_rm(rk, KS(0), tid);
     A::store_rm(rv, VS(0), tid);
@@ -274,8 +300,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
 
     for (int t = 0; t < ntiles; ++t) {
         if (t + 1 < ntiles && !(p.dbg & 1)) {
-            A::load(rk, kp, p.k_rs, (int64_t)(t + 1) * 64, p.Sk, (int)p.hd, fast, tid);
-            A::load(rv, vp, p.v_rs, (int64_t)(t + 1) * 64, p.Sk, (int)p.hd, fast, tid);
+            A::stream_load(rk, pk, kp, p.k_rs, (int64_t)(t + 1) * 64, p.Sk, (int)p.hd, fast, tid);
+            A::stream_load(rv, pv, vp, p.v_rs, (int64_t)(t + 1) * 64, p.Sk, (int)p.hd, fast, tid);
             if (tid < 64) rkb = key_bias(p, b, (int64_t)(t + 1) * 64 + tid, slope);
         }
         f32x4 x[4];
@@ -450,9 +476,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
         else if (which == 1) rstat = q < p.Sq ? 1.0f / sl[q] : 0.f;
         else if (which == 2) rstat = q < p.Sq ? sd[q] : 0.f;
     };
+    const T* pq[A::NCH];
+    const T* pg[A::NCH];
     if (qt_begin < qt_end) {
         A::load(rq, qp, p.q_rs, (int64_t)qt_begin * 64, p.Sq, (int)p.hd, fast, tid);
         A::load(rg, gp, p.o_rs, (int64_t)qt_begin * 64, p.Sq, (int)p.hd, fast, tid);
+        A::stream_init(pq, qp, p.q_rs, (int64_t)(qt_begin + 1) * 64, tid);
+        A::stream_init(pg, gp, p.o_rs, (int64_t)(qt_begin + 1) * 64, tid);
         load_stats(qt_begin);
         A::store_rm(rq, QS(0), tid);
         A::store_rm(rg, GS(0), tid);
@@ -462,8 +492,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
 
     for (int t = qt_begin; t < qt_end; ++t) {
         if (t + 1 < qt_end && !(p.dbg & 1)) {
-            A::load(rq, qp, p.q_rs, (int64_t)(t + 1) * 64, p.Sq, (int)p.hd, fast, tid);
-            A::load(rg, gp, p.o_rs, (int64_t)(t + 1) * 64, p.Sq, (int)p.hd, fast, tid);
+            A::stream_load(rq, pq, qp, p.q_rs, (int64_t)(t + 1) * 64, p.Sq, (int)p.hd, fast, tid);
+            A::stream_load(rg, pg, gp, p.o_rs, (int64_t)(t + 1) * 64, p.Sq, (int)p.hd, fast, tid);
             load_stats(t + 1);
         }
         f32x4 x[4], y[4];
@@ -574,6 +604,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
     float rkb = 0.f;
     A::load(rk, kp, p.k_rs, 0, p.Sk, (int)p.hd, fast, tid);
     A::load(rv, vp, p.v_rs, 0, p.Sk, (int)p.hd, fast, tid);
+    const T* pk[A::NCH];
+    const T* pv[A::NCH];
+    A::stream_init(pk, kp, p.k_rs, 64, tid);
+    A::stream_init(pv, vp, p.v_rs, 64, tid);
     if (tid < 64) rkb = key_bias(p, b, tid, slope);
     A::store_rm(rk, KS(0), tid);
     A::store_rm(rv, VS(0), tid);
@@ -582,8 +616,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
 
     for (int t = 0; t < ntiles; ++t) {
         if (t + 1 < ntiles && !(p.dbg & 1)) {
-            A::load(rk, kp, p.k_rs, (int64_t)(t + 1) * 64, p.Sk, (int)p.hd, fast, tid);
-            A::load(rv, vp, p.v_rs, (int64_t)(t + 1) * 64, p.Sk, (int)p.hd, fast, tid);
+            A::stream_load(rk, pk, kp, p.k_rs, (int64_t)(t + 1) * 64, p.Sk, (int)p.hd, fast, tid);
+            A::stream_load(rv, pv, vp, p.v_rs, (int64_t)(t + 1) * 64, p.Sk, (int)p.hd, fast, tid);
             if (tid < 64) rkb = key_bias(p, b, (int64_t)(t + 1) * 64 + tid, slope);
         }
         f32x4 x[4], y[4];
