@@ -206,6 +206,22 @@ __device__ __forceinline__ float key_bias(const AttnP& p, int64_t b, int64_t key
     if (p.kvalid != nullptr && p.kvalid[b * p.Sk + key] == 0) return FINFO_MIN;
     return p.kpos != nullptr ? slope * p.kpos[b * p.Sk + key] : 0.0f;
 }
+// The same, split in two for the streaming loops: `load` issues the (unconditional, index-clamped) loads while the next
+// tile is being requested, `value` turns them into the bias when the tile is published to LDS at the end of the iteration.
+// (key_bias's early returns made dependent loads with a vmcnt(0) each, which also drained the tile prefetch issued just
+// before — in the one wave all the others then wait for at the barrier.)
+struct KeyBiasRaw {
+    int valid; float pos;
+    __device__ __forceinline__ void load(const AttnP& p, int64_t b, int64_t key) {
+        const int64_t kc = b * p.Sk + min(key, p.Sk - 1);
+        valid = p.kvalid != nullptr ? (int)p.kvalid[kc] : 1;
+        pos = p.kpos != nullptr ? p.kpos[kc] : 0.0f;
+    }
+    __device__ __forceinline__ float value(const AttnP& p, int64_t key, float slope) const {
+        const float r = valid != 0 ? slope * pos : FINFO_MIN;
+        return key < p.Sk ? r : -INFINITY;
+    }
+};
 // raw score; AM (additive mask, transformer.py:43-45) is a compile-time switch; am_base points at element (b,h,0,0)
 template <bool AM>
 __device__ __forceinline__ float score_raw(const AttnP& p, float dot, float kb, int q, int key, const float* __restrict__ am_base) {
@@ -284,6 +300,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
 
     uint4 rk[A::NCH], rv[A::NCH];
     float rkb = 0.f;
+    KeyBiasRaw kbr{1, 0.f};
     A::load(rk, kp, p.k_rs, 0, p.Sk, (int)p.hd, fast, tid);
     A::load(rv, vp, p.v_rs, 0, p.Sk, (int)p.hd, fast, tid);
     const T* pk[A::NCH];
@@ -300,9 +317,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
 
     for (int t = 0; t < ntiles; ++t) {
         if (t + 1 < ntiles && !(p.dbg & 1)) {
+            if (tid < 64) kbr.load(p, b, (int64_t)(t + 1) * 64 + tid);
             A::stream_load(rk, pk, kp, p.k_rs, (int64_t)(t + 1) * 64, p.Sk, (int)p.hd, fast, tid);
             A::stream_load(rv, pv, vp, p.v_rs, (int64_t)(t + 1) * 64, p.Sk, (int)p.hd, fast, tid);
-            if (tid < 64) rkb = key_bias(p, b, (int64_t)(t + 1) * 64 + tid, slope);
         }
         f32x4 x[4];
         const float* kbs = KB(cur);
@@ -357,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
             const int nx = NBUF == 2 ? cur ^ 1 : 0;
             A::store_rm(rk, KS(nx), tid);
             A::store_rm(rv, VS(nx), tid);
-            if (tid < 64) KB(nx)[tid] = rkb;
+            if (tid < 64) KB(nx)[tid] = kbr.value(p, (int64_t)(t + 1) * 64 + tid, slope);
             cur = nx;
         }
         if (!(p.dbg & 4)) __syncthreads();
@@ -469,12 +486,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
 
     uint4 rq[A::NCH], rg[A::NCH];
     float rstat = 0.f;
+    // raw load now (index clamped, no arithmetic on the value: nothing forces a wait next to the tile prefetch), the
+    // reciprocal / zeroing when the stats are published to LDS
+    const float* sbase = (tid >> 6) == 0 ? sm : ((tid >> 6) == 1 ? sl : sd);
     auto load_stats = [&](int t) {
         const int64_t q = (int64_t)t * 64 + (tid & 63);
-        const int which = tid >> 6;
-        if (which == 0) rstat = q < p.Sq ? sm[q] : 0.f;
-        else if (which == 1) rstat = q < p.Sq ? 1.0f / sl[q] : 0.f;
-        else if (which == 2) rstat = q < p.Sq ? sd[q] : 0.f;
+        if (tid < 192) rstat = sbase[min(q, p.Sq - 1)];
+    };
+    auto stat_value = [&](int t) {
+        const int64_t q = (int64_t)t * 64 + (tid & 63);
+        const float v = (tid >> 6) == 1 ? 1.0f / rstat : rstat;
+        return q < p.Sq ? v : 0.f;
     };
     const T* pq[A::NCH];
     const T* pg[A::NCH];
@@ -486,15 +508,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
         load_stats(qt_begin);
         A::store_rm(rq, QS(0), tid);
         A::store_rm(rg, GS(0), tid);
-        if (tid < 192) ST(0)[tid] = rstat;
+        if (tid < 192) ST(0)[tid] = stat_value(qt_begin);
     }
     __syncthreads();
 
     for (int t = qt_begin; t < qt_end; ++t) {
         if (t + 1 < qt_end && !(p.dbg & 1)) {
+            load_stats(t + 1);
             A::stream_load(rq, pq, qp, p.q_rs, (int64_t)(t + 1) * 64, p.Sq, (int)p.hd, fast, tid);
             A::stream_load(rg, pg, gp, p.o_rs, (int64_t)(t + 1) * 64, p.Sq, (int)p.hd, fast, tid);
-            load_stats(t + 1);
         }
         f32x4 x[4], y[4];
         const float* st = ST(cur);
@@ -540,7 +562,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
             const int nx = NBUF == 2 ? cur ^ 1 : 0;
             A::store_rm(rq, QS(nx), tid);
             A::store_rm(rg, GS(nx), tid);
-            if (tid < 192) ST(nx)[tid] = rstat;
+            if (tid < 192) ST(nx)[tid] = stat_value(t + 1);
             cur = nx;
         }
         __syncthreads();
@@ -602,6 +624,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
 
     uint4 rk[A::NCH], rv[A::NCH];
     float rkb = 0.f;
+    KeyBiasRaw kbr{1, 0.f};
     A::load(rk, kp, p.k_rs, 0, p.Sk, (int)p.hd, fast, tid);
     A::load(rv, vp, p.v_rs, 0, p.Sk, (int)p.hd, fast, tid);
     const T* pk[A::NCH];
@@ -616,9 +639,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
 
     for (int t = 0; t < ntiles; ++t) {
         if (t + 1 < ntiles && !(p.dbg & 1)) {
+            if (tid < 64) kbr.load(p, b, (int64_t)(t + 1) * 64 + tid);
             A::stream_load(rk, pk, kp, p.k_rs, (int64_t)(t + 1) * 64, p.Sk, (int)p.hd, fast, tid);
             A::stream_load(rv, pv, vp, p.v_rs, (int64_t)(t + 1) * 64, p.Sk, (int)p.hd, fast, tid);
-            if (tid < 64) rkb = key_bias(p, b, (int64_t)(t + 1) * 64 + tid, slope);
         }
         f32x4 x[4], y[4];
         const float* kbs = KB(cur);
@@ -653,7 +676,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
             const int nx = NBUF == 2 ? cur ^ 1 : 0;
             A::store_rm(rk, KS(nx), tid);
             A::store_rm(rv, VS(nx), tid);
-            if (tid < 64) KB(nx)[tid] = rkb;
+            if (tid < 64) KB(nx)[tid] = kbr.value(p, (int64_t)(t + 1) * 64 + tid, slope);
             cur = nx;
         }
         __syncthreads();
