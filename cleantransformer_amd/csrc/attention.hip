@@ -522,23 +522,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
         const float* st = ST(cur);
         dot_tile<T, HDP>(x, QS(cur), kf, lane);                              // x[nt][r] = q[qi] . k[my_k]
         dot_tile<T, HDP>(y, GS(cur), vf, lane);                              // y[nt][r] = dO[qi] . v[my_k]
-        const bool diag = p.causal != 0;      // (a tile-uniform "crosses the diagonal" test here made hipcc unswitch the loop: +29 % time)
+        // (a tile-uniform "crosses the diagonal" test here made hipcc unswitch the loop: +29 % time.)  The per-element masks are
+        // one integer compare each against per-tile, per-lane thresholds on the compile-time offset c = nt*16 + r of the
+        // query inside the tile (query index = qbase + c):
+        //   masked(c) = padding key | (causal & my_k > q + off)   <=>  c < thr_m
+        //   valid(c)  = key row exists & q < Sq                   <=>  c < thr_v
+        const int qbase = t * 64 + g * 4;
+        const int thr_m = key_pad ? 0x7fffffff : (p.causal ? (int)my_k - (int)p.off - qbase : (int)0x80000000);
+        const int thr_v = key_live ? (int)p.Sq - qbase : (int)0x80000000;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const f32x4 mm = *reinterpret_cast<const f32x4*>(st + nt * 16 + g * 4);
             const f32x4 il = *reinterpret_cast<const f32x4*>(st + 64 + nt * 16 + g * 4);
             const f32x4 dl = *reinterpret_cast<const f32x4*>(st + 128 + nt * 16 + g * 4);
-            const int qb0 = t * 64 + nt * 16 + g * 4;
             f32x4 s4 = x[nt] * p.scale + my_kb;                                   // packed fma
             if (AM) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s4[r] = score_raw<true>(p, x[nt][r], my_kb, qb0 + r, (int)my_k, am_base);
+                for (int r = 0; r < 4; ++r) s4[r] = score_raw<true>(p, x[nt][r], my_kb, qbase + nt * 16 + r, (int)my_k, am_base);
             }
-            bool msk[4], valid[4];
+            bool msk[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                msk[r] = key_pad | (diag & ((int)my_k > qb0 + r + p.off));
-                valid[r] = key_live & (qb0 + r < (int)p.Sq);
+                msk[r] = (nt * 16 + r) < thr_m;
                 s4[r] = msk[r] ? FINFO_MIN : s4[r];
             }
             const f32x4 e4 = (s4 - mm) * 1.4426950408889634f;                     // (s - m) first (finfo.min - finfo.min = 0)
@@ -546,12 +551,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) p4[r] = __builtin_amdgcn_exp2f(e4[r]);
             p4 = p4 * il;
-            f32x4 d4 = p4 * (y[nt] - dl);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                p4[r] = valid[r] ? p4[r] : 0.f;
-                d4[r] = (valid[r] & !msk[r]) ? d4[r] : 0.f;
-            }
+            for (int r = 0; r < 4; ++r) p4[r] = ((nt * 16 + r) < thr_v) ? p4[r] : 0.f;
+            f32x4 d4 = p4 * (y[nt] - dl);                                         // already 0 where the row / key does not exist
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d4[r] = msk[r] ? 0.f : d4[r];            // masked entries: P kept (uniform rows), dS = 0
             x[nt] = p4;
             y[nt] = d4;
         }
@@ -648,7 +652,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
         dot_tile<T, HDP>(x, KS(cur), qf, lane);
         dot_tile<T, HDP>(y, VS(cur), gf, lane);
         const int kv0 = t * 64;
-        const bool diag = p.causal != 0;
+        // usable(c) for the key at offset c = nt*16 + r of this lane's 4-key group: row alive & not in the causal future
+        const int thr_u = live ? (p.causal ? q_eff + (int)p.off - kv0 - g * 4 : 0x7fffffff) : (int)0x80000000;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const f32x4 kb4 = *reinterpret_cast<const f32x4*>(kbs + nt * 16 + g * 4);
@@ -665,7 +670,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
             f32x4 d4 = (p4 * il) * (y[nt] - dl);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const bool use = live & (kb4[r] > FINFO_MIN) & !(diag & (k0t + r > q_eff + p.off));   // padding / missing / future keys: dS = 0
+                const bool use = (kb4[r] > FINFO_MIN) & ((nt * 16 + r) <= thr_u);   // padding / missing / future keys, dead rows: dS = 0
                 d4[r] = use ? d4[r] : 0.f;
             }
             y[nt] = d4;
