@@ -397,6 +397,34 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnP p) {
     constexpr int VEC = 16 / sizeof(T);
     const int64_t rows = p.B * p.nh * p.Sq;
     const bool fast = p.vec_ok && (p.hd % VEC == 0) && (64 % (p.hd / VEC) == 0) && (p.hd / VEC) <= 16;
+    if (fast && p.o_hs == p.hd && p.o_rs == p.nh * p.hd && p.o_bs == p.Sq * p.o_rs) {
+        // merged-head layout [B*Sq, nh*hd] (the training path): one wave walks one token row, 64 lanes x 16 B = 1 KiB of
+        // consecutive heads per step — fully coalesced (the per-(b,h,q) row order reads hd-sized pieces nh*hd apart:
+        // measured 0.5 TB/s at H = 4096), and no per-lane 64-bit div/mod
+        const int lpr = (int)p.hd / VEC, hps = 64 / lpr;                      // lanes per head, heads per 1-KiB step
+        const int lane = threadIdx.x & 63, sub = lane % lpr, hin = lane / lpr;
+        const int64_t tokens = p.B * p.Sq, rowlen = p.nh * p.hd;
+        const T* O = reinterpret_cast<const T*>(p.o);
+        const T* G = reinterpret_cast<const T*>(p.d_o);
+        for (int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); tok < tokens; tok += (int64_t)gridDim.x * 4) {
+            const int64_t b = tok / p.Sq, q = tok - b * p.Sq;                 // wave-uniform
+            for (int64_t h0 = 0; h0 < p.nh; h0 += hps) {
+                const int64_t h = h0 + hin;
+                float s = 0.f;
+                if (h < p.nh) {
+                    const int64_t off = tok * rowlen + h * p.hd + sub * VEC;
+                    float a[VEC], c[VEC];
+                    unpack16<T>(*reinterpret_cast<const uint4*>(O + off), a);
+                    unpack16<T>(*reinterpret_cast<const uint4*>(G + off), c);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) s += a[j] * c[j];
+                }
+                for (int o = lpr >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+                if (h < p.nh && sub == 0) p.delta[(b * p.nh + h) * p.Sq + q] = s;
+            }
+        }
+        return;
+    }
     if (fast) {
         // hd/VEC lanes per row (8 for hd = 64 bf16), 16-byte loads, xor-shuffle reduce inside the lane group
         const int lpr = (int)p.hd / VEC, rpw = 64 / lpr;

@@ -128,13 +128,16 @@ extern "C" int ctmi_layernorm_fwd(const void* x, const float* w, const float* b,
 // Backward.  dx = rstd * (g - mean(g) - xhat*mean(g*xhat)),  g = dy*w, xhat = (x-mean)*rstd.
 // Each wave keeps per-lane partial sums of dw = sum dy*xhat and db = sum dy for its rows; a block combines its
 // 4 waves through LDS and writes one partial row to ws[blockIdx][2][cols]; ln_bwd_reduce sums the partial rows.
-static constexpr int LNB_WAVES = 8;                     // waves per workgroup in ln_bwd_vec (512 threads: keeps ~16 waves/CU resident)
+// waves per workgroup in ln_bwd_vec: 8 for rows up to 64*VEC*2 elements, fewer for wider rows so the per-wave dw/db partials
+// ([waves][2][cols] fp32 in LDS) stay within 64 KiB
+static constexpr int lnb_waves(int maxv) { return maxv <= 2 ? 8 : (16 / maxv); }
 template <typename T, int MAXV>
-__global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_vec(const T* __restrict__ dy, const T* __restrict__ x,
+__global__ __launch_bounds__(64 * lnb_waves(MAXV)) void ln_bwd_vec(const T* __restrict__ dy, const T* __restrict__ x,
                                                   const float* __restrict__ w, const float* __restrict__ mean_i,
                                                   const float* __restrict__ rstd_i, const T* __restrict__ dres,
                                                   T* __restrict__ dx, float* __restrict__ ws, int64_t rows, int cols) {
     constexpr int VEC = 16 / sizeof(T);
+    constexpr int LNB_WAVES = lnb_waves(MAXV);
     extern __shared__ __attribute__((aligned(16))) float lds[];      // [LNB_WAVES][2][cols]
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int64_t wave0 = (int64_t)blockIdx.x * LNB_WAVES + wid;
@@ -272,6 +275,88 @@ __global__ __launch_bounds__(256) void ln_bwd_wb_gen(const T* __restrict__ dy, c
     }
 }
 
+// Wide rows (more than 4 x 64 16-byte chunks: hidden sizes above 2048 in bf16): one 4-wave workgroup per row, each wave
+// owning every 4th 1-KiB chunk, so a lane keeps MVW chunks of x / dy / the dw,db partials in registers instead of 8 (the
+// one-wave-per-row kernel needs all 256 VGPRs there and leaves one wave per SIMD).  The two row sums cross the waves through
+// LDS (double-buffered by row parity: one barrier per row).  Partials: ws[block][2][cols], no cross-wave combine.
+template <typename T, int MVW>
+__global__ __launch_bounds__(256) void ln_bwd_wide(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ w,
+                                                   const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                                   const T* __restrict__ dres, T* __restrict__ dx, float* __restrict__ ws,
+                                                   int64_t rows, int cols) {
+    constexpr int VEC = 16 / sizeof(T);
+    __shared__ float sm[2][2][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const float inv_n = 1.0f / (float)cols;
+    float aw[MVW][VEC], ab[MVW][VEC], wvv[MVW][VEC];
+    int col[MVW];
+#pragma unroll
+    for (int i = 0; i < MVW; ++i) {
+        col[i] = ((i * 4 + wv) * 64 + lane) * VEC;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { aw[i][j] = 0.f; ab[i][j] = 0.f; wvv[i][j] = (col[i] < cols) ? w[col[i] + j] : 0.f; }
+    }
+    int par = 0;
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x, par ^= 1) {
+        const float mean = mean_i[row], rstd = rstd_i[row];
+        uint4 xraw[MVW], graw[MVW], rraw[MVW];
+#pragma unroll
+        for (int i = 0; i < MVW; ++i)
+            if (col[i] < cols) {
+                xraw[i] = *reinterpret_cast<const uint4*>(x + row * cols + col[i]);
+                graw[i] = *reinterpret_cast<const uint4*>(dy + row * cols + col[i]);
+                if (dres != nullptr) rraw[i] = *reinterpret_cast<const uint4*>(dres + row * cols + col[i]);
+            }
+        float xh[MVW][VEC], g[MVW][VEC];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MVW; ++i) {
+            if (col[i] < cols) {
+                float xv[VEC], dv[VEC];
+                unpack16<T>(xraw[i], xv);
+                unpack16<T>(graw[i], dv);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    xh[i][j] = (xv[j] - mean) * rstd;
+                    g[i][j] = dv[j] * wvv[i][j];
+                    s1 += g[i][j];
+                    s2 += g[i][j] * xh[i][j];
+                    aw[i][j] += dv[j] * xh[i][j];
+                    ab[i][j] += dv[j];
+                }
+            }
+        }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        if (lane == 0) { sm[par][0][wv] = s1; sm[par][1][wv] = s2; }
+        __syncthreads();
+        s1 = (sm[par][0][0] + sm[par][0][1] + sm[par][0][2] + sm[par][0][3]) * inv_n;
+        s2 = (sm[par][1][0] + sm[par][1][1] + sm[par][1][2] + sm[par][1][3]) * inv_n;
+#pragma unroll
+        for (int i = 0; i < MVW; ++i) {
+            if (col[i] < cols) {
+                float o[VEC];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) o[j] = rstd * (g[i][j] - s1 - xh[i][j] * s2);
+                if (dres != nullptr) {
+                    float r[VEC];
+                    unpack16<T>(rraw[i], r);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) o[j] += r[j];
+                }
+                *reinterpret_cast<uint4*>(dx + row * cols + col[i]) = pack16<T>(o);
+            }
+        }
+    }
+    float* out = ws + (int64_t)blockIdx.x * 2 * cols;
+#pragma unroll
+    for (int i = 0; i < MVW; ++i)
+        if (col[i] < cols) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { out[col[i] + j] = aw[i][j]; out[cols + col[i] + j] = ab[i][j]; }
+        }
+}
+
 __global__ __launch_bounds__(256) void ln_bwd_reduce(const float* __restrict__ ws, float* __restrict__ dw,
                                                      float* __restrict__ db, int nparts, int64_t cols, int accumulate) {
     // 64 columns x 4 row-slices per block; blockIdx.y selects dw / db
@@ -292,6 +377,31 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce(const float* __restrict__ w
         o[c] = accumulate ? o[c] + r : r;
     }
 }
+// the same for wide rows (cols % 256 == 0): a lane sums 4 adjacent columns with 16-byte loads, so a wave reads 1 KiB of each
+// partial row instead of 256 B (the partial rows are 2*cols*4 bytes apart: 256-byte pieces of them ran at ~40 GB/s)
+__global__ __launch_bounds__(256) void ln_bwd_reduce4(const float* __restrict__ ws, float* __restrict__ dw,
+                                                      float* __restrict__ db, int nparts, int64_t cols, int accumulate) {
+    __shared__ float4 sm[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t c = ((int64_t)blockIdx.x * 64 + tx) * 4;
+    const int which = blockIdx.y;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int p = ty; p < nparts; p += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(ws + ((int64_t)p * 2 + which) * cols + c);
+        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    sm[ty][tx] = t;
+    __syncthreads();
+    if (ty == 0) {
+        float4 r = sm[0][tx];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) { r.x += sm[k][tx].x; r.y += sm[k][tx].y; r.z += sm[k][tx].z; r.w += sm[k][tx].w; }
+        float* o = (which ? db : dw) + c;
+        if (accumulate) { r.x += o[0]; r.y += o[1]; r.z += o[2]; r.w += o[3]; }
+        o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = r.w;
+    }
+}
 
 static const int LN_BWD_MAX_BLOCKS = 512;
 extern "C" int64_t ctmi_layernorm_bwd_ws(int64_t rows, int64_t cols) {
@@ -305,17 +415,24 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* w, const fl
                          int64_t rows, int64_t cols, hipStream_t st) {
     constexpr int VEC = 16 / sizeof(T);
     const bool vec_ok = (cols % VEC == 0) && aligned16(x) && aligned16(dy) && aligned16(dx) &&
-                        (dres == nullptr || aligned16(dres)) && cols <= 8LL * 64 * VEC && cols * 2 * LNB_WAVES * 4 <= 64 * 1024;
+                        (dres == nullptr || aligned16(dres)) && cols <= 8LL * 64 * VEC;
     int nparts;
     if (vec_ok) {
-        int grid = (int)std::min<int64_t>(cdiv64(rows, LNB_WAVES), LN_BWD_MAX_BLOCKS);
+        const int mv = cols <= 64 * VEC ? 1 : (cols <= 2 * 64 * VEC ? 2 : (cols <= 4 * 64 * VEC ? 4 : 8));
+        const int nw = lnb_waves(mv);
+        int grid = (int)std::min<int64_t>(cdiv64(rows, nw), LN_BWD_MAX_BLOCKS);
+        if (mv >= 4) {                                                  // wide rows: one workgroup per row, columns split over 4 waves
+            grid = (int)std::min<int64_t>(rows, LN_BWD_MAX_BLOCKS);
+            if (mv == 4) hipLaunchKernelGGL((ln_bwd_wide<T, 1>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, w, mean, rstd, (const T*)dres, (T*)dx, ws, rows, (int)cols);
+            else hipLaunchKernelGGL((ln_bwd_wide<T, 2>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, w, mean, rstd, (const T*)dres, (T*)dx, ws, rows, (int)cols);
+        }
         nparts = grid;
-        size_t lds = (size_t)cols * 2 * LNB_WAVES * sizeof(float);
+        size_t lds = (size_t)cols * 2 * nw * sizeof(float);
 #define LN_BWD_CASE(MV) if (cols <= (int64_t)MV * 64 * VEC) { \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_vec<T, MV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((ln_bwd_vec<T, MV>), dim3(grid), dim3(64 * LNB_WAVES), lds, st, (const T*)dy, (const T*)x, w, mean, rstd, \
+            hipLaunchKernelGGL((ln_bwd_vec<T, MV>), dim3(grid), dim3(64 * lnb_waves(MV)), lds, st, (const T*)dy, (const T*)x, w, mean, rstd, \
                                (const T*)dres, (T*)dx, ws, rows, (int)cols); }
-        LN_BWD_CASE(1) else LN_BWD_CASE(2) else LN_BWD_CASE(4) else LN_BWD_CASE(8)
+        if (mv >= 4) { (void)lds; } else LN_BWD_CASE(1) else LN_BWD_CASE(2)
 #undef LN_BWD_CASE
         CTMI_CHECK_LAUNCH("layernorm_bwd");
     } else {
@@ -329,7 +446,10 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* w, const fl
         hipLaunchKernelGGL((ln_bwd_wb_gen<T>), dim3(nparts), dim3(256), 0, st, (const T*)dy, (const T*)x, mean, rstd, ws, rows, cols, chunk);
         CTMI_CHECK_LAUNCH("layernorm_bwd_wb");
     }
-    hipLaunchKernelGGL(ln_bwd_reduce, dim3((unsigned)cdiv64(cols, 64), 2), dim3(256), 0, st, ws, dw, db, nparts, cols, accumulate);
+    if (cols % 256 == 0 && cols >= 2048 && aligned16(ws))
+        hipLaunchKernelGGL(ln_bwd_reduce4, dim3((unsigned)(cols / 256), 2), dim3(256), 0, st, ws, dw, db, nparts, cols, accumulate);
+    else
+        hipLaunchKernelGGL(ln_bwd_reduce, dim3((unsigned)cdiv64(cols, 64), 2), dim3(256), 0, st, ws, dw, db, nparts, cols, accumulate);
     CTMI_CHECK_LAUNCH("layernorm_bwd_reduce");
     return CTMI_OK;
 }
@@ -364,13 +484,27 @@ __global__ __launch_bounds__(256) void colsum_part(const T* __restrict__ x, int6
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
     if (vec_ok) {
-        if (c0 < N)
-            for (int64_t r = r0 + wid; r < r1; r += 4) {
+        if (c0 < N) {
+            int64_t r = r0 + wid;
+            for (; r + 12 < r1; r += 16) {                                   // 4 independent 16-byte loads in flight per lane
+                uint4 q[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) q[u] = *reinterpret_cast<const uint4*>(x + (r + 4 * u) * ld + c0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float v[VEC];
+                    unpack16<T>(q[u], v);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) acc[j] += v[j];
+                }
+            }
+            for (; r < r1; r += 4) {
                 float v[VEC];
                 unpack16<T>(*reinterpret_cast<const uint4*>(x + r * ld + c0), v);
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) acc[j] += v[j];
             }
+        }
     } else {
         for (int64_t r = r0 + wid; r < r1; r += 4)
 #pragma unroll
@@ -407,7 +541,8 @@ extern "C" int ctmi_colsum(const void* x, int64_t ld, float* out, int accumulate
     CTMI_REQUIRE(x && out && ws && M > 0 && N > 0, "colsum: bad args");
     hipStream_t st = as_stream(stream);
     const int64_t xblocks = cdiv64(N, 64 * (dtype == CTMI_F32 ? 4 : 8));
-    int parts = (int)std::min<int64_t>(std::max<int64_t>(16, std::min<int64_t>(COLSUM_PARTS, cdiv64(512, xblocks))), cdiv64(M, 16));
+    // ~2048 workgroups (8 waves per SIMD) so the row streams cover the HBM latency; >= 16 rows per part
+    int parts = (int)std::min<int64_t>(std::max<int64_t>(16, std::min<int64_t>(COLSUM_PARTS, cdiv64(2048, xblocks))), cdiv64(M, 16));
     int64_t rpp = cdiv64(M, parts);
     parts = (int)cdiv64(M, rpp);
     if (dtype == CTMI_F32) {

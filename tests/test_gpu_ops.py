@@ -120,7 +120,7 @@ def test_probe_lds_transpose_read_dump():
 
 # ------------------------------------------------------------------------------------------------ LayerNorm
 @pytest.mark.parametrize("dtype,rtol,atol", DT)
-@pytest.mark.parametrize("rows,cols", [(7, 48), (33, 64), (5, 211), (300, 1024), (64, 4096), (3, 24)])
+@pytest.mark.parametrize("rows,cols", [(7, 48), (33, 64), (5, 211), (300, 1024), (64, 4096), (3, 24), (40, 2048), (9, 3072), (1030, 1536)])
 def test_layernorm_fwd_bwd(dtype, rtol, atol, rows, cols):
     o = ops()
     x = rnd(rows, cols, seed=1) * 2 + 0.3
