@@ -1,0 +1,31 @@
+#!/bin/bash
+# MFMA-utilisation counters for the LM-head forward GEMM (MB_ONLY=lm_head MB_FWD_ONLY=1 tools/microbench.py gemm); counters only.
+cd /tmp && export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+OUT=gpurun_out/pmc_gemm; rm -rf $OUT; mkdir -p $OUT
+i=0
+for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU" \
+           "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \
+           "GRBM_GUI_ACTIVE GRBM_COUNT SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_CYCLES SQ_WAVES"; do
+  i=$((i+1))
+  MB_ONLY=lm_head MB_FWD_ONLY=1 timeout 200 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/g$i -- python tools/microbench.py gemm > $OUT/g$i.log 2>&1
+done
+python - <<'PY'
+import csv, glob, collections
+acc = collections.defaultdict(list)
+dur = []
+for f in glob.glob("gpurun_out/pmc_gemm/g*/*/*_counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if r["Kernel_Name"].startswith("void gemm_glds_kernel<unsigned short, false, false, 0, 8, 4, true, false>"):
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            dur.append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+a = {k: sum(v) / len(v) for k, v in acc.items()}
+for k in sorted(a):
+    print(f"{k:32s} {a[k]:18.0f}")
+ms = sum(dur) / len(dur) / 1e6
+print(f"average duration under counters: {ms:.3f} ms")
+if "GRBM_GUI_ACTIVE" in a and "SQ_VALU_MFMA_BUSY_CYCLES" in a:
+    print(f"MfmaUtil (gfx94x formula) = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 256 CUs * 4 SIMDs) = {100 * a['SQ_VALU_MFMA_BUSY_CYCLES'] / (a['GRBM_GUI_ACTIVE'] * 256 * 4):.1f} %")
+if "SQ_INSTS_VALU_MFMA_MOPS_BF16" in a:
+    print(f"MFMA bf16 MOPS x 512 FLOP = {a['SQ_INSTS_VALU_MFMA_MOPS_BF16'] * 512 / 1e12:.3f} TFLOP per launch (algorithmic 2*T*H*V = {2 * 8192 * 1024 * 250880 / 1e12:.3f})")
+PY
