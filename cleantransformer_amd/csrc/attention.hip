@@ -329,24 +329,30 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
         // softmax arithmetic on 4-wide vectors so that hipcc emits packed fp32 ops (v_pk_fma/add/mul_f32): this kernel
         // is bound by VALU issue (hd = 64 gives only 16 MFMAs per ~300 VALU instructions per tile), not by the matrix pipe
         float mx = -INFINITY;
+        // three passes over the 4 key groups instead of one: with the (tile-uniform) causal branch inside the group loop every
+        // group was its own basic block, so the four key-bias LDS reads could not be batched and each exposed its latency
+        f32x4 kb4[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) kb4[nt] = *reinterpret_cast<const f32x4*>(kbs + nt * 16 + g * 4);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            const f32x4 kb4 = *reinterpret_cast<const f32x4*>(kbs + nt * 16 + g * 4);
-            f32x4 s4 = x[nt] * p.scale + kb4;                                 // fma(dot, scale, key bias): padding -> finfo.min, no key -> -inf
+            f32x4 s4 = x[nt] * p.scale + kb4[nt];                             // fma(dot, scale, key bias): padding -> finfo.min, no key -> -inf
             if (AM) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s4[r] = score_raw<true>(p, x[nt][r], kb4[r], q_eff, kv0 + nt * 16 + g * 4 + r, am_base);
-            }
-            if (diag) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = kv0 + nt * 16 + g * 4 + r;
-                    s4[r] = (key > q_eff + p.off) ? fminf(s4[r], FINFO_MIN) : s4[r];   // masked_fill; -inf (no such key) stays -inf
-                }
+                for (int r = 0; r < 4; ++r) s4[r] = score_raw<true>(p, x[nt][r], kb4[nt][r], q_eff, kv0 + nt * 16 + g * 4 + r, am_base);
             }
             x[nt] = s4;
-            mx = max3f(max3f(mx, s4[0], s4[1]), s4[2], s4[3]);
         }
+        if (diag) {
+            const int thr = q_eff + (int)p.off - kv0 - g * 4;                 // key offset c = nt*16 + r is in the causal future iff c > thr
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    x[nt][r] = (nt * 16 + r > thr) ? fminf(x[nt][r], FINFO_MIN) : x[nt][r];   // masked_fill; -inf (no such key) stays -inf
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) mx = max3f(max3f(mx, x[nt][0], x[nt][1]), x[nt][2], x[nt][3]);
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m, mx);                                   // finite: every tile holds >= 1 real key
