@@ -63,10 +63,16 @@ struct AT {
             const int row = id / CPR, c = (id % CPR) * VEC;
             const int64_t grow = row0 + row;
             const T* p = base + grow * rs + c;
-            T tmp[VEC];
+            // assembled as packed 32-bit words: gathered element-wise into a T[VEC] array, hipcc kept one 16-bit value per
+            // register for the tile data of BOTH paths and re-packed it with v_perm_b32 before every LDS store
+            uint32_t wd[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) tmp[j] = (grow < nrows && c + j < hd) ? p[j] : (T)0;
-            regs[i] = *reinterpret_cast<const uint4*>(tmp);
+            for (int j = 0; j < VEC; ++j) {
+                const T e = (grow < nrows && c + j < hd) ? p[j] : (T)0;
+                if constexpr (sizeof(T) == 2) wd[j >> 1] |= (uint32_t)__builtin_bit_cast(uint16_t, e) << (16 * (j & 1));
+                else wd[j] = __builtin_bit_cast(uint32_t, e);
+            }
+            regs[i] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
         }
     }
     // Streamed tiles: per-thread row pointers advance by one tile (64 rows) per call, so the steady state issues NCH plain
