@@ -30,6 +30,9 @@ struct AttnP {
 // 64 x HDP tile staging helpers (256 threads).  Thread -> (row = id / CPR, 16-byte chunk = id % CPR): the CPR lanes of
 // one row read one contiguous run of HBM (coalesced: a head row of hd=64 bf16 is exactly one 128-byte line) and write one
 // padded row-major LDS row (pitch HDP + 8 elements: ds_write_b128 / ds_read_b128 / ds_read_b64_tr_b16 all spread over banks).
+// 16 bytes of tile data in flight: a first-class vector, NOT the uint4 struct — struct copies become memcpy intrinsics that
+// SROA left in private memory (scratch stores + vmcnt(0) after every tile load) once the scalar gather path was compiled out
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 template <typename T, int HDP>
 struct AT {
     static constexpr int VEC = 16 / sizeof(T);
@@ -46,14 +49,14 @@ struct AT {
     // `fast` (wave-uniform: 16-byte aligned strides and hd == HDP): unconditional vector loads; rows beyond the
     // tensor are clamped to its last row — they carry finite data whose probabilities / dS are forced to zero by the
     // callers, so no predicate (and no exec-masked load + vmcnt(0) join) is needed in the steady state.
-    static __device__ __forceinline__ void load(uint4 (&regs)[NCH], const T* __restrict__ base, int64_t rs, int64_t row0,
+    static __device__ __forceinline__ void load(u32x4 (&regs)[NCH], const T* __restrict__ base, int64_t rs, int64_t row0,
                                                 int64_t nrows, int hd, bool fast, int tid) {
         if (fast) {
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
                 const int id = tid + 256 * i;
                 const int64_t grow = min(row0 + id / CPR, nrows - 1);
-                regs[i] = *reinterpret_cast<const uint4*>(base + grow * rs + (id % CPR) * VEC);
+                regs[i] = *reinterpret_cast<const u32x4*>(base + grow * rs + (id % CPR) * VEC);
             }
             return;
         }
@@ -72,7 +75,7 @@ struct AT {
                 if constexpr (sizeof(T) == 2) wd[j >> 1] |= (uint32_t)__builtin_bit_cast(uint16_t, e) << (16 * (j & 1));
                 else wd[j] = __builtin_bit_cast(uint32_t, e);
             }
-            regs[i] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+            regs[i] = u32x4{wd[0], wd[1], wd[2], wd[3]};
         }
     }
     // Streamed tiles: per-thread row pointers advance by one tile (64 rows) per call, so the steady state issues NCH plain
@@ -86,22 +89,35 @@ struct AT {
             ptrs[i] = base + (row0 + id / CPR) * rs + (id % CPR) * VEC;
         }
     }
-    static __device__ __forceinline__ void stream_load(uint4 (&regs)[NCH], const T* (&ptrs)[NCH], const T* __restrict__ base, int64_t rs,
+    static __device__ __forceinline__ void stream_load(u32x4 (&regs)[NCH], const T* (&ptrs)[NCH], const T* __restrict__ base, int64_t rs,
                                                        int64_t row0, int64_t nrows, int hd, bool fast, int tid) {
-        if (fast && row0 + 64 <= nrows) {
+        if (fast) {
+            // only the ADDRESSES differ between an interior tile and one that crosses the end of the tensor (rows clamped to
+            // the last one): the loads themselves stay outside the branch.  (With the loads inside both arms hipcc merged
+            // the arms through a private-memory copy of `regs` — scratch stores with a vmcnt(0) after every load.)
+            const T* src[NCH];
 #pragma unroll
-            for (int i = 0; i < NCH; ++i) regs[i] = *reinterpret_cast<const uint4*>(ptrs[i]);
+            for (int i = 0; i < NCH; ++i) src[i] = ptrs[i];
+            if (row0 + 64 > nrows) {
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) {
+                    const int id = tid + 256 * i;
+                    src[i] = base + min(row0 + id / CPR, nrows - 1) * rs + (id % CPR) * VEC;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) regs[i] = *reinterpret_cast<const u32x4*>(src[i]);
         } else {
-            load(regs, base, rs, row0, nrows, hd, fast, tid);
+            load(regs, base, rs, row0, nrows, hd, false, tid);
         }
 #pragma unroll
         for (int i = 0; i < NCH; ++i) ptrs[i] += 64 * rs;
     }
-    static __device__ __forceinline__ void store_rm(const uint4 (&regs)[NCH], T* __restrict__ tile, int tid) {
+    static __device__ __forceinline__ void store_rm(const u32x4 (&regs)[NCH], T* __restrict__ tile, int tid) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int id = tid + 256 * i;
-            *reinterpret_cast<uint4*>(tile + (id / CPR) * PRM + (id % CPR) * VEC) = regs[i];
+            *reinterpret_cast<u32x4*>(tile + (id / CPR) * PRM + (id % CPR) * VEC) = regs[i];
         }
     }
 };
@@ -116,8 +132,14 @@ template <> __device__ __forceinline__ float frag_rm<float, 64>(const float* __r
 template <> __device__ __forceinline__ float frag_rm<float, 128>(const float* __restrict__ t, int row, int kofs) { return t[row * AT<float, 128>::PRM + kofs]; }
 
 // fragment straight from HBM: KL consecutive elements of one row (row == nullptr -> zeros)
-template <typename T> __device__ __forceinline__ typename Mma<T>::Frag frag_global(const T* row, int kofs, int hd, bool vec_ok);
-template <> __device__ __forceinline__ short8 frag_global<bf16_t>(const bf16_t* row, int kofs, int hd, bool vec_ok) {
+// FAST: hd == HDP and 16-byte aligned rows (known at compile time) — only the vector load exists
+template <typename T, bool FAST = false> __device__ __forceinline__ typename Mma<T>::Frag frag_global(const T* row, int kofs, int hd, bool vec_ok);
+template <> __device__ __forceinline__ short8 frag_global<bf16_t, true>(const bf16_t* row, int kofs, int, bool) {
+    short8 f = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (row != nullptr) f = *reinterpret_cast<const short8*>(row + kofs);
+    return f;
+}
+template <> __device__ __forceinline__ short8 frag_global<bf16_t, false>(const bf16_t* row, int kofs, int hd, bool vec_ok) {
     short8 f = {0, 0, 0, 0, 0, 0, 0, 0};
     if (row == nullptr) return f;
     if (kofs + 8 <= hd && vec_ok) return *reinterpret_cast<const short8*>(row + kofs);
@@ -125,8 +147,11 @@ template <> __device__ __forceinline__ short8 frag_global<bf16_t>(const bf16_t* 
     for (int j = 0; j < 8; ++j) f[j] = (kofs + j < hd) ? (short)row[kofs + j] : (short)0;
     return f;
 }
-template <> __device__ __forceinline__ float frag_global<float>(const float* row, int kofs, int hd, bool) {
+template <> __device__ __forceinline__ float frag_global<float, false>(const float* row, int kofs, int hd, bool) {
     return (row != nullptr && kofs < hd) ? row[kofs] : 0.f;
+}
+template <> __device__ __forceinline__ float frag_global<float, true>(const float* row, int kofs, int, bool) {
+    return row != nullptr ? row[kofs] : 0.f;
 }
 
 // x[nt][r] = sum_d tile[nt*16 + (g*4+r)][d] * own[d]   (tile rows stream, lane's own row from registers)
@@ -239,14 +264,14 @@ __device__ __forceinline__ float score_raw(const AttnP& p, float dot, float kb, 
     return s;
 }
 
-template <typename T, int HDP>
+template <typename T, int HDP, bool FAST = false>
 __device__ __forceinline__ void store_own_row(T* rowp, const f32x4 (&acc)[HDP / 16], float mul, int hd, int g, bool vec_ok) {
 #pragma unroll
     for (int dt = 0; dt < HDP / 16; ++dt) {
         const int d = dt * 16 + g * 4;
-        if (d >= hd) continue;
+        if (!FAST && d >= hd) continue;
         float v[4] = {acc[dt][0] * mul, acc[dt][1] * mul, acc[dt][2] * mul, acc[dt][3] * mul};
-        if (d + 4 <= hd && vec_ok) {
+        if (FAST || (d + 4 <= hd && vec_ok)) {
             if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2*>(rowp + d) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
             else *reinterpret_cast<float4*>(rowp + d) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
@@ -263,7 +288,7 @@ template <typename T, int HDP> struct DkdvStage { static constexpr int BYTES = 2
 template <typename T, int HDP> struct DqStage { static constexpr int BYTES = 2 * AT<T, HDP>::RM_ELEMS * (int)sizeof(T) + 256; };
 constexpr int nbuf_for(int stage_bytes) { return 2 * stage_bytes <= 80 * 1024 ? 2 : 1; }
 
-template <typename T, int HDP, bool AM>
+template <typename T, int HDP, bool AM, bool FAST>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
     using A = AT<T, HDP>;
     constexpr int MK = Mma<T>::K, KL = Mma<T>::KL, NKK = HDP / MK, NDT = HDP / 16;
@@ -274,7 +299,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
     auto VS = [&](int s_) { return KS(s_) + A::RM_ELEMS; };
     auto KB = [&](int s_) { return reinterpret_cast<float*>(VS(s_) + A::RM_ELEMS); };   // [64] per-key digest of the staged tile
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, li = lane & 15;
-    const bool fast = p.vec_ok && p.hd == HDP;
+    // FAST (compile time): 16-byte aligned strides and hd == HDP — the element-wise gather / guarded store paths are not even
+    // compiled into the kernel the training shapes use (their mere presence cost registers, see AT::load)
+    const bool fast = FAST || (p.vec_ok && p.hd == HDP);
+    const int hd_ = FAST ? HDP : (int)p.hd;
+    const bool vok = FAST || p.vec_ok;
     const int nqb = (int)((p.Sq + 63) / 64);
     const int vid = xcd_remap(blockIdx.x, gridDim.x);
     const int qb = nqb - 1 - (vid % nqb);                                   // longest (latest) query blocks first
@@ -288,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
     typename Mma<T>::Frag qf[NKK];
 #pragma unroll
     for (int kk = 0; kk < NKK; ++kk)
-        qf[kk] = frag_global<T>(my_q < p.Sq ? qp + my_q * p.q_rs : nullptr, kk * MK + g * KL, (int)p.hd, p.vec_ok);
+        qf[kk] = frag_global<T, FAST>(my_q < p.Sq ? qp + my_q * p.q_rs : nullptr, kk * MK + g * KL, hd_, vok);
 
     int64_t kv_end = p.Sk;
     if (p.causal) {
@@ -304,11 +333,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    uint4 rk[A::NCH], rv[A::NCH];
+    u32x4 rk[A::NCH], rv[A::NCH];
     float rkb = 0.f;
     KeyBiasRaw kbr{1, 0.f};
-    A::load(rk, kp, p.k_rs, 0, p.Sk, (int)p.hd, fast, tid);
-    A::load(rv, vp, p.v_rs, 0, p.Sk, (int)p.hd, fast, tid);
+    A::load(rk, kp, p.k_rs, 0, p.Sk, hd_, fast, tid);
+    A::load(rv, vp, p.v_rs, 0, p.Sk, hd_, fast, tid);
     const T* pk[A::NCH];
     const T* pv[A::NCH];
     A::stream_init(pk, kp, p.k_rs, 64, tid);
@@ -324,8 +353,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
     for (int t = 0; t < ntiles; ++t) {
         if (t + 1 < ntiles && !(p.dbg & 1)) {
             if (tid < 64) kbr.load(p, b, (int64_t)(t + 1) * 64 + tid);
-            A::stream_load(rk, pk, kp, p.k_rs, (int64_t)(t + 1) * 64, p.Sk, (int)p.hd, fast, tid);
-            A::stream_load(rv, pv, vp, p.v_rs, (int64_t)(t + 1) * 64, p.Sk, (int)p.hd, fast, tid);
+            A::stream_load(rk, pk, kp, p.k_rs, (int64_t)(t + 1) * 64, p.Sk, hd_, fast, tid);
+            A::stream_load(rv, pv, vp, p.v_rs, (int64_t)(t + 1) * 64, p.Sk, hd_, fast, tid);
         }
         f32x4 x[4];
         const float* kbs = KB(cur);
@@ -395,7 +424,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
     lsum += __shfl_xor(lsum, 32, 64);
     if (my_q < p.Sq) {
         T* op = reinterpret_cast<T*>(p.out) + b * p.o_bs + h * p.o_hs + my_q * p.o_rs;
-        store_own_row<T, HDP>(op, acc, 1.0f / lsum, (int)p.hd, g, p.vec_ok);
+        store_own_row<T, HDP, FAST>(op, acc, 1.0f / lsum, hd_, g, vok);
         if (g == 0) {
             p.stat_m[(b * p.nh + h) * p.Sq + my_q] = m;
             p.stat_l[(b * p.nh + h) * p.Sq + my_q] = lsum;
@@ -475,7 +504,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnP p) {
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
 // own rows = keys.  Per query tile: S = Q K^T and dP = dO V^T (own key in the accumulator column), P = exp(S-m)/l,
 // dS = P (dP - delta); dV^T += dO^T P, dK^T += Q^T dS  (Q, dO staged both row-major and transposed).
-template <typename T, int HDP, bool AM>
+template <typename T, int HDP, bool AM, bool FAST>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
     using A = AT<T, HDP>;
     constexpr int MK = Mma<T>::K, KL = Mma<T>::KL, NKK = HDP / MK, NDT = HDP / 16;
@@ -486,7 +515,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
     auto GS = [&](int s_) { return QS(s_) + A::RM_ELEMS; };
     auto ST = [&](int s_) { return reinterpret_cast<float*>(GS(s_) + A::RM_ELEMS); };   // [3][64]: m, 1/l, delta
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, li = lane & 15;
-    const bool fast = p.vec_ok && p.hd == HDP;
+    // FAST (compile time): 16-byte aligned strides and hd == HDP — the element-wise gather / guarded store paths are not even
+    // compiled into the kernel the training shapes use (their mere presence cost registers, see AT::load)
+    const bool fast = FAST || (p.vec_ok && p.hd == HDP);
+    const int hd_ = FAST ? HDP : (int)p.hd;
+    const bool vok = FAST || p.vec_ok;
     const int nkb = (int)((p.Sk + 63) / 64);
     const int vid = xcd_remap(blockIdx.x, gridDim.x);
     const int kb = vid % nkb;                                                // early key blocks (most work) first
@@ -501,8 +534,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
     typename Mma<T>::Frag kf[NKK], vf[NKK];
 #pragma unroll
     for (int kk = 0; kk < NKK; ++kk) {
-        kf[kk] = frag_global<T>(my_k < p.Sk ? kp + my_k * p.k_rs : nullptr, kk * MK + g * KL, (int)p.hd, p.vec_ok);
-        vf[kk] = frag_global<T>(my_k < p.Sk ? vp + my_k * p.v_rs : nullptr, kk * MK + g * KL, (int)p.hd, p.vec_ok);
+        kf[kk] = frag_global<T, FAST>(my_k < p.Sk ? kp + my_k * p.k_rs : nullptr, kk * MK + g * KL, hd_, vok);
+        vf[kk] = frag_global<T, FAST>(my_k < p.Sk ? vp + my_k * p.v_rs : nullptr, kk * MK + g * KL, hd_, vok);
     }
     f32x4 dk[NDT], dv[NDT];
 #pragma unroll
@@ -524,7 +557,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
     const float* sl = p.stat_l + (b * p.nh + h) * p.Sq;
     const float* sd = p.delta + (b * p.nh + h) * p.Sq;
 
-    uint4 rq[A::NCH], rg[A::NCH];
+    u32x4 rq[A::NCH], rg[A::NCH];
     float rstat = 0.f;
     // raw load now (index clamped, no arithmetic on the value: nothing forces a wait next to the tile prefetch), the
     // reciprocal / zeroing when the stats are published to LDS
@@ -541,8 +574,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
     const T* pq[A::NCH];
     const T* pg[A::NCH];
     if (qt_begin < qt_end) {
-        A::load(rq, qp, p.q_rs, (int64_t)qt_begin * 64, p.Sq, (int)p.hd, fast, tid);
-        A::load(rg, gp, p.o_rs, (int64_t)qt_begin * 64, p.Sq, (int)p.hd, fast, tid);
+        A::load(rq, qp, p.q_rs, (int64_t)qt_begin * 64, p.Sq, hd_, fast, tid);
+        A::load(rg, gp, p.o_rs, (int64_t)qt_begin * 64, p.Sq, hd_, fast, tid);
         A::stream_init(pq, qp, p.q_rs, (int64_t)(qt_begin + 1) * 64, tid);
         A::stream_init(pg, gp, p.o_rs, (int64_t)(qt_begin + 1) * 64, tid);
         load_stats(qt_begin);
@@ -555,8 +588,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
     for (int t = qt_begin; t < qt_end; ++t) {
         if (t + 1 < qt_end && !(p.dbg & 1)) {
             load_stats(t + 1);
-            A::stream_load(rq, pq, qp, p.q_rs, (int64_t)(t + 1) * 64, p.Sq, (int)p.hd, fast, tid);
-            A::stream_load(rg, pg, gp, p.o_rs, (int64_t)(t + 1) * 64, p.Sq, (int)p.hd, fast, tid);
+            A::stream_load(rq, pq, qp, p.q_rs, (int64_t)(t + 1) * 64, p.Sq, hd_, fast, tid);
+            A::stream_load(rg, pg, gp, p.o_rs, (int64_t)(t + 1) * 64, p.Sq, hd_, fast, tid);
         }
         f32x4 x[4], y[4];
         const float* st = ST(cur);
@@ -614,14 +647,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
     if (my_k < p.Sk) {
         T* dkp = reinterpret_cast<T*>(p.dk) + b * p.k_bs + h * p.k_hs + my_k * p.k_rs;
         T* dvp = reinterpret_cast<T*>(p.dv) + b * p.v_bs + h * p.v_hs + my_k * p.v_rs;
-        store_own_row<T, HDP>(dkp, dk, p.scale, (int)p.hd, g, p.vec_ok);
-        store_own_row<T, HDP>(dvp, dv, 1.0f, (int)p.hd, g, p.vec_ok);
+        store_own_row<T, HDP, FAST>(dkp, dk, p.scale, hd_, g, vok);
+        store_own_row<T, HDP, FAST>(dvp, dv, 1.0f, hd_, g, vok);
     }
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ
 // own rows = queries.  Per key tile: S^T = K Q^T, dP^T = V dO^T, dS^T = P^T (dP^T - delta); dQ^T += K^T dS^T.
-template <typename T, int HDP, bool AM>
+template <typename T, int HDP, bool AM, bool FAST>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
     using A = AT<T, HDP>;
     constexpr int MK = Mma<T>::K, KL = Mma<T>::KL, NKK = HDP / MK, NDT = HDP / 16;
@@ -632,7 +665,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
     auto VS = [&](int s_) { return KS(s_) + A::RM_ELEMS; };
     auto KB = [&](int s_) { return reinterpret_cast<float*>(VS(s_) + A::RM_ELEMS); };
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, li = lane & 15;
-    const bool fast = p.vec_ok && p.hd == HDP;
+    // FAST (compile time): 16-byte aligned strides and hd == HDP — the element-wise gather / guarded store paths are not even
+    // compiled into the kernel the training shapes use (their mere presence cost registers, see AT::load)
+    const bool fast = FAST || (p.vec_ok && p.hd == HDP);
+    const int hd_ = FAST ? HDP : (int)p.hd;
+    const bool vok = FAST || p.vec_ok;
     const int nqb = (int)((p.Sq + 63) / 64);
     const int vid = xcd_remap(blockIdx.x, gridDim.x);
     const int qb = nqb - 1 - (vid % nqb);
@@ -648,8 +685,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
     typename Mma<T>::Frag qf[NKK], gf[NKK];
 #pragma unroll
     for (int kk = 0; kk < NKK; ++kk) {
-        qf[kk] = frag_global<T>(live ? qp + my_q * p.q_rs : nullptr, kk * MK + g * KL, (int)p.hd, p.vec_ok);
-        gf[kk] = frag_global<T>(live ? gp + my_q * p.o_rs : nullptr, kk * MK + g * KL, (int)p.hd, p.vec_ok);
+        qf[kk] = frag_global<T, FAST>(live ? qp + my_q * p.q_rs : nullptr, kk * MK + g * KL, hd_, vok);
+        gf[kk] = frag_global<T, FAST>(live ? gp + my_q * p.o_rs : nullptr, kk * MK + g * KL, hd_, vok);
     }
     const int64_t srow = (b * p.nh + h) * p.Sq + my_q;
     const float m = live ? p.stat_m[srow] : 0.f;
@@ -666,11 +703,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    uint4 rk[A::NCH], rv[A::NCH];
+    u32x4 rk[A::NCH], rv[A::NCH];
     float rkb = 0.f;
     KeyBiasRaw kbr{1, 0.f};
-    A::load(rk, kp, p.k_rs, 0, p.Sk, (int)p.hd, fast, tid);
-    A::load(rv, vp, p.v_rs, 0, p.Sk, (int)p.hd, fast, tid);
+    A::load(rk, kp, p.k_rs, 0, p.Sk, hd_, fast, tid);
+    A::load(rv, vp, p.v_rs, 0, p.Sk, hd_, fast, tid);
     const T* pk[A::NCH];
     const T* pv[A::NCH];
     A::stream_init(pk, kp, p.k_rs, 64, tid);
@@ -684,8 +721,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
     for (int t = 0; t < ntiles; ++t) {
         if (t + 1 < ntiles && !(p.dbg & 1)) {
             if (tid < 64) kbr.load(p, b, (int64_t)(t + 1) * 64 + tid);
-            A::stream_load(rk, pk, kp, p.k_rs, (int64_t)(t + 1) * 64, p.Sk, (int)p.hd, fast, tid);
-            A::stream_load(rv, pv, vp, p.v_rs, (int64_t)(t + 1) * 64, p.Sk, (int)p.hd, fast, tid);
+            A::stream_load(rk, pk, kp, p.k_rs, (int64_t)(t + 1) * 64, p.Sk, hd_, fast, tid);
+            A::stream_load(rv, pv, vp, p.v_rs, (int64_t)(t + 1) * 64, p.Sk, hd_, fast, tid);
         }
         f32x4 x[4], y[4];
         const float* kbs = KB(cur);
@@ -728,7 +765,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
     }
     if (live) {
         T* dqp = reinterpret_cast<T*>(p.dq) + b * p.q_bs + h * p.q_hs + my_q * p.q_rs;
-        store_own_row<T, HDP>(dqp, dq, p.scale, (int)p.hd, g, p.vec_ok);
+        store_own_row<T, HDP, FAST>(dqp, dq, p.scale, hd_, g, vok);
     }
 }
 
@@ -764,8 +801,9 @@ static int fwd_launch(AttnP& p, hipStream_t st) {
     using A = AT<T, HDP>;
     const size_t lds = (size_t)FwdStage<T, HDP>::BYTES * nbuf_for(FwdStage<T, HDP>::BYTES);
     const int64_t grid = ((p.Sq + 63) / 64) * p.B * p.nh;
-    if (p.add_mask) launch_k(&attn_fwd_kernel<T, HDP, true>, grid, lds, st, p);
-    else launch_k(&attn_fwd_kernel<T, HDP, false>, grid, lds, st, p);
+    if (p.add_mask) launch_k(&attn_fwd_kernel<T, HDP, true, false>, grid, lds, st, p);
+    else if (p.vec_ok && p.hd == HDP) launch_k(&attn_fwd_kernel<T, HDP, false, true>, grid, lds, st, p);
+    else launch_k(&attn_fwd_kernel<T, HDP, false, false>, grid, lds, st, p);
     CTMI_CHECK_LAUNCH("attn_fwd");
     return CTMI_OK;
 }
@@ -780,15 +818,17 @@ static int bwd_launch(AttnP& p, hipStream_t st) {
     {
         const size_t lds = (size_t)DkdvStage<T, HDP>::BYTES * nbuf_for(DkdvStage<T, HDP>::BYTES);
         const int64_t grid = ((p.Sk + 63) / 64) * p.B * p.nh;
-        if (p.add_mask) launch_k(&attn_bwd_dkdv_kernel<T, HDP, true>, grid, lds, st, p);
-        else launch_k(&attn_bwd_dkdv_kernel<T, HDP, false>, grid, lds, st, p);
+        if (p.add_mask) launch_k(&attn_bwd_dkdv_kernel<T, HDP, true, false>, grid, lds, st, p);
+        else if (p.vec_ok && p.hd == HDP) launch_k(&attn_bwd_dkdv_kernel<T, HDP, false, true>, grid, lds, st, p);
+        else launch_k(&attn_bwd_dkdv_kernel<T, HDP, false, false>, grid, lds, st, p);
         CTMI_CHECK_LAUNCH("attn_bwd_dkdv");
     }
     {
         const size_t lds = (size_t)DqStage<T, HDP>::BYTES * nbuf_for(DqStage<T, HDP>::BYTES);
         const int64_t grid = ((p.Sq + 63) / 64) * p.B * p.nh;
-        if (p.add_mask) launch_k(&attn_bwd_dq_kernel<T, HDP, true>, grid, lds, st, p);
-        else launch_k(&attn_bwd_dq_kernel<T, HDP, false>, grid, lds, st, p);
+        if (p.add_mask) launch_k(&attn_bwd_dq_kernel<T, HDP, true, false>, grid, lds, st, p);
+        else if (p.vec_ok && p.hd == HDP) launch_k(&attn_bwd_dq_kernel<T, HDP, false, true>, grid, lds, st, p);
+        else launch_k(&attn_bwd_dq_kernel<T, HDP, false, false>, grid, lds, st, p);
         CTMI_CHECK_LAUNCH("attn_bwd_dq");
     }
     return CTMI_OK;
