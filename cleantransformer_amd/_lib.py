@@ -58,6 +58,9 @@ PROTOTYPES = {
     "ctmi_scale": (i32, [vp, i64, f32, vp, vp]),
     "ctmi_scale_copy": (i32, [vp, vp, i64, f32, vp]),
     "ctmi_argmax": (i32, [vp, i64, vp, i64, i64, i32, vp]),
+    "ctmi_row_lse": (i32, [vp, i64, vp, i64, i64, i32, vp]),
+    "ctmi_group_topk": (i32, [vp, i64, vp, vp, f32, vp, vp, i64, i32, i64, i32, i32, vp]),
+    "ctmi_scores_filter": (i32, [vp, i64, f32, vp, i64, f32, vp, i64, i64, i64, vp]),
     "ctmi_probe": (i32, [i32, vp, vp, vp]),
 }
 

@@ -1050,6 +1050,120 @@ extern "C" int ctmi_argmax(const void* x, int64_t ld, int64_t* out, int64_t rows
     return CTMI_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ decode (beam search, samplers)
+// Row statistics of log_softmax (generation_util.py:200): stats[row] = {max, log(sum exp(x - max))}, so that the consumer
+// forms (x - max) - logsum exactly as torch.log_softmax does.  One workgroup per row; decode is latency-, not HBM-bound.
+template <typename T>
+__global__ __launch_bounds__(256) void row_lse_k(const T* __restrict__ x, int64_t ld, float* __restrict__ stats, int64_t cols) {
+    const T* r = x + (int64_t)blockIdx.x * ld;
+    __shared__ float red[4];
+    float m = -INFINITY;
+    for (int64_t c = threadIdx.x; c < cols; c += 256) m = fmaxf(m, Cvt<T>::to_f(r[c]));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int64_t c = threadIdx.x; c < cols; c += 256) sum += expf(Cvt<T>::to_f(r[c]) - m);
+    sum = wave_sum(sum);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        stats[2 * blockIdx.x] = m;
+        stats[2 * blockIdx.x + 1] = logf((red[0] + red[1]) + (red[2] + red[3]));
+    }
+}
+extern "C" int ctmi_row_lse(const void* x, int64_t ld, float* stats, int64_t rows, int64_t cols, int dtype, void* stream) {
+    CTMI_REQUIRE(x && stats && rows > 0 && cols > 0 && ld >= cols, "row_lse: bad args");
+    if (dtype == CTMI_F32) hipLaunchKernelGGL((row_lse_k<float>), dim3((unsigned)rows), dim3(256), 0, as_stream(stream), (const float*)x, ld, stats, cols);
+    else if (dtype == CTMI_BF16) hipLaunchKernelGGL((row_lse_k<bf16_t>), dim3((unsigned)rows), dim3(256), 0, as_stream(stream), (const bf16_t*)x, ld, stats, cols);
+    else { ctmi_set_error("row_lse: unsupported dtype %d", dtype); return CTMI_ERR_UNSUPPORTED; }
+    CTMI_CHECK_LAUNCH("row_lse");
+    return CTMI_OK;
+}
+
+// Top-k over the `group` x cols candidates of one batch element (generation_util.py:199-224: scores.view(bsz, -1).topk(2*beam)):
+//     score(i, v) = ((x[g*group + i][v] - max_i) - logsum_i) + add[g*group + i] * add_mul       (stats / add optional)
+// Output k (value, flat index i*cols + v) pairs in descending value order, equal values by ascending flat index.
+// Selection by k rounds of a lexicographic arg-max over the candidates that come after the previous pick: no per-thread
+// candidate lists (dynamic register arrays would live in scratch), exact for -inf entries and duplicates; the candidate set
+// (group * cols * 4 B <= a few MiB) stays in L2 between rounds.
+template <typename T>
+__global__ __launch_bounds__(1024) void group_topk_k(const T* __restrict__ x, int64_t ld, const float* __restrict__ stats,
+                                                     const float* __restrict__ add, float add_mul, float* __restrict__ out_val,
+                                                     int64_t* __restrict__ out_idx, int group, int64_t cols, int k) {
+    const int64_t g = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float sv[16]; __shared__ int64_t si[16];
+    __shared__ float pick_v; __shared__ int64_t pick_i;
+    float pv = INFINITY; int64_t pi = -1;                         // previous pick: everything is "after" it
+    for (int r = 0; r < k; ++r) {
+        float bv = -INFINITY; int64_t bi = INT64_MAX;
+        for (int i = 0; i < group; ++i) {
+            const int64_t row = g * group + i;
+            const T* xr = x + row * ld;
+            const float mx = stats ? stats[2 * row] : 0.f, ls = stats ? stats[2 * row + 1] : 0.f;
+            const float a = add ? add[row] * add_mul : 0.f;
+            for (int64_t c = tid; c < cols; c += 1024) {
+                float v = Cvt<T>::to_f(xr[c]);
+                if (stats) v = (v - mx) - ls;
+                if (add) v = v + a;
+                const int64_t f = (int64_t)i * cols + c;
+                const bool after = (v < pv) || (v == pv && f > pi);
+                if (after && (v > bv || (v == bv && f < bi))) { bv = v; bi = f; }
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float v2 = __shfl_xor(bv, o, 64); const int64_t i2 = __shfl_xor(bi, o, 64);
+            if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
+        }
+        if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 16; ++w) if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+            pick_v = bv; pick_i = bi;
+            out_val[g * k + r] = bv; out_idx[g * k + r] = bi;
+        }
+        __syncthreads();
+        pv = pick_v; pi = pick_i;
+    }
+}
+extern "C" int ctmi_group_topk(const void* x, int64_t ld, const float* stats, const float* add, float add_mul, float* out_val,
+                               int64_t* out_idx, int64_t groups, int group, int64_t cols, int k, int dtype, void* stream) {
+    CTMI_REQUIRE(x && out_val && out_idx && groups > 0 && group > 0 && cols > 0 && ld >= cols, "group_topk: bad args");
+    CTMI_REQUIRE(k > 0 && (int64_t)k <= (int64_t)group * cols, "group_topk: k must be in [1, group*cols]");
+    if (dtype == CTMI_F32) hipLaunchKernelGGL((group_topk_k<float>), dim3((unsigned)groups), dim3(1024), 0, as_stream(stream),
+                                              (const float*)x, ld, stats, add, add_mul, out_val, out_idx, group, cols, k);
+    else if (dtype == CTMI_BF16) hipLaunchKernelGGL((group_topk_k<bf16_t>), dim3((unsigned)groups), dim3(1024), 0, as_stream(stream),
+                                                    (const bf16_t*)x, ld, stats, add, add_mul, out_val, out_idx, group, cols, k);
+    else { ctmi_set_error("group_topk: unsupported dtype %d", dtype); return CTMI_ERR_UNSUPPORTED; }
+    CTMI_CHECK_LAUNCH("group_topk");
+    return CTMI_OK;
+}
+
+// Sampler filters on fp32 scores (logits_processor.py:35-56): out = x / divisor, then entries strictly below the row's
+// threshold (thr[row * thr_stride], optional) are replaced by `fill`.  A true division, as the reference performs.
+__global__ __launch_bounds__(256) void scores_filter_k(const float* __restrict__ x, int64_t ld, float divisor, const float* __restrict__ thr,
+                                                       int64_t thr_stride, float fill, float* __restrict__ out, int64_t ldo, int64_t cols) {
+    const int64_t row = blockIdx.y;
+    const float t = thr ? thr[row * thr_stride] : -INFINITY;
+    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < cols; c += (int64_t)gridDim.x * 256) {
+        float v = x[row * ld + c];
+        if (divisor != 1.0f) v = __fdiv_rn(v, divisor);
+        out[row * ldo + c] = (thr && v < t) ? fill : v;
+    }
+}
+extern "C" int ctmi_scores_filter(const float* x, int64_t ld, float divisor, const float* thr, int64_t thr_stride, float fill,
+                                  float* out, int64_t ldo, int64_t rows, int64_t cols, void* stream) {
+    CTMI_REQUIRE(x && out && rows > 0 && rows < 65536 && cols > 0 && ld >= cols && ldo >= cols, "scores_filter: bad args");
+    const unsigned gx = (unsigned)std::min<int64_t>(cdiv64(cols, 256), 1024);
+    hipLaunchKernelGGL(scores_filter_k, dim3(gx, (unsigned)rows), dim3(256), 0, as_stream(stream), x, ld, divisor, thr, thr_stride, fill,
+                       out, ldo, cols);
+    CTMI_CHECK_LAUNCH("scores_filter");
+    return CTMI_OK;
+}
+
 // attention_mask [B,S] -> ALiBi key positions (cumsum(mask)-1)*mask as fp32, validity as int32 (modeling_bloom.py:328,178)
 __global__ __launch_bounds__(64) void mask_prep_k(const int64_t* __restrict__ am, float* __restrict__ kpos,
                                                   int32_t* __restrict__ kvalid, int32_t* __restrict__ first_valid, int64_t S) {

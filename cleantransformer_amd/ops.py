@@ -344,6 +344,51 @@ def argmax_lastdim(x2d: Tensor) -> Tensor:
     return out
 
 
+def row_lse(x2d: Tensor) -> Tensor:
+    """[rows, 2] fp32 = (max, log sum exp(x - max)) per row: the two terms torch.log_softmax subtracts (generation_util.py:200)."""
+    _need_cuda(x2d)
+    assert x2d.dim() == 2 and x2d.stride(1) == 1
+    rows, cols = x2d.shape
+    stats = torch.empty(rows, 2, dtype=torch.float32, device=x2d.device)
+    check(_lib.load().ctmi_row_lse(_p(x2d), x2d.stride(0), _p(stats), rows, cols, dt_code(x2d.dtype), _stream()), "row_lse")
+    return stats
+
+
+def group_topk(x2d: Tensor, group: int, k: int, stats: Optional[Tensor] = None, add: Optional[Tensor] = None,
+               add_mul: float = 1.0) -> Tuple[Tensor, Tensor]:
+    """Best k of the group*cols candidates of every `group` consecutive rows; score = ((x - max) - logsum) + add*add_mul when
+    stats/add are given.  Returns (values [G,k] fp32 descending, flat indices [G,k] int64; ties by ascending index)."""
+    _need_cuda(x2d)
+    assert x2d.dim() == 2 and x2d.stride(1) == 1 and x2d.shape[0] % group == 0
+    rows, cols = x2d.shape
+    G = rows // group
+    val = torch.empty(G, k, dtype=torch.float32, device=x2d.device)
+    idx = torch.empty(G, k, dtype=torch.int64, device=x2d.device)
+    if stats is not None:
+        assert stats.dtype == torch.float32 and stats.is_contiguous() and stats.shape == (rows, 2)
+    if add is not None:
+        add = add.to(torch.float32).contiguous().view(-1)
+        assert add.numel() == rows
+    check(_lib.load().ctmi_group_topk(_p(x2d), x2d.stride(0), _p(stats), _p(add), float(add_mul), _p(val), _p(idx), G, group, cols, k,
+                                      dt_code(x2d.dtype), _stream()), "group_topk")
+    return val, idx
+
+
+def scores_filter(x2d: Tensor, divisor: float = 1.0, thr: Optional[Tensor] = None, fill: float = float("-inf")) -> Tensor:
+    """x / divisor, entries below the per-row threshold replaced by `fill` (fp32 scores; logits_processor.py:35-56)."""
+    _need_cuda(x2d)
+    assert x2d.dtype == torch.float32 and x2d.dim() == 2 and x2d.stride(1) == 1
+    rows, cols = x2d.shape
+    out = torch.empty(rows, cols, dtype=torch.float32, device=x2d.device)
+    ts = 0
+    if thr is not None:
+        assert thr.dtype == torch.float32 and thr.dim() == 1 and thr.numel() == rows
+        ts = thr.stride(0)
+    check(_lib.load().ctmi_scores_filter(_p(x2d), x2d.stride(0), float(divisor), _p(thr), ts, float(fill), _p(out), cols, rows, cols,
+                                         _stream()), "scores_filter")
+    return out
+
+
 def _ptr_array(ts):
     arr = (C.c_void_p * len(ts))()
     for i, t in enumerate(ts):

@@ -159,6 +159,20 @@ int ctmi_scale_copy(const float* src, float* dst, int64_t n, float s, void* stre
 /* argmax over the last dim of x[rows, cols] -> int64 (first maximal index, as torch.argmax; generation_util.py:86) */
 int ctmi_argmax(const void* x, int64_t ld, int64_t* out, int64_t rows, int64_t cols, int dtype, void* stream);
 
+/* ---- decode beyond argmax: beam search and samplers (generation_util.py:121-290, logits_processor.py) */
+/* stats[row] = {max, log(sum exp(x - max))} over x[rows, cols]: the two terms of torch.log_softmax (generation_util.py:200) */
+int ctmi_row_lse(const void* x, int64_t ld, float* stats /* [rows,2] */, int64_t rows, int64_t cols, int dtype, void* stream);
+/* per group g of `group` consecutive rows: the k best of score(i,v) = ((x[g*group+i][v] - max) - logsum) + add[g*group+i]*add_mul
+   (stats, add optional) as (value, flat index i*cols+v), descending, equal values by ascending index — replaces
+   scores.view(bsz,-1).topk(2*beam) (generation_util.py:199-217) and the k-th-value threshold of TopKLogitsWrapper
+   (logits_processor.py:48-50). */
+int ctmi_group_topk(const void* x, int64_t ld, const float* stats, const float* add, float add_mul, float* out_val /* [groups,k] */,
+                    int64_t* out_idx /* [groups,k] */, int64_t groups, int group, int64_t cols, int k, int dtype, void* stream);
+/* out = x / divisor, then entries < thr[row*thr_stride] (thr optional) become `fill` — TemperatureLogitsWrapper and the
+   masked_fill of TopKLogitsWrapper (logits_processor.py:35-56); fp32, out may alias x */
+int ctmi_scores_filter(const float* x, int64_t ld, float divisor, const float* thr, int64_t thr_stride, float fill, float* out,
+                       int64_t ldo, int64_t rows, int64_t cols, void* stream);
+
 /* ---- hardware probe (diagnostics: dumps MFMA / LDS-transpose lane layouts into out[]; used by tests only) */
 int ctmi_probe(int which, const float* in /* device */, float* out /* device, 256 floats */, void* stream);
 

@@ -220,6 +220,39 @@ def argmax_lastdim(x2d):
     return x2d.float().argmax(-1)
 
 
+def row_lse(x2d):
+    x = x2d.float()
+    m = x.max(dim=-1).values
+    return torch.stack([m, (x - m[:, None]).exp().sum(-1).log()], dim=1)
+
+
+def group_topk(x2d, group, k, stats=None, add=None, add_mul=1.0):
+    """(value desc, flat index asc) selection, as ctmi_group_topk documents its tie order."""
+    s = x2d.float()
+    if stats is not None:
+        s = (s - stats[:, 0:1]) - stats[:, 1:2]
+    if add is not None:
+        s = s + add.float().reshape(-1, 1) * add_mul
+    s = s.reshape(x2d.shape[0] // group, -1)
+    vals, idxs = [], []
+    for row in s:
+        order = sorted(range(row.numel()), key=lambda j: (-float(row[j]), j)) if row.numel() <= 4096 else None
+        if order is None:                                  # large rows: torch.topk, then a stable re-sort of equal values
+            v, i = row.topk(k)
+            order = sorted(i.tolist(), key=lambda j: (-float(row[j]), j))
+        order = order[:k]
+        idxs.append(order)
+        vals.append([float(row[j]) for j in order])
+    return torch.tensor(vals, dtype=torch.float32), torch.tensor(idxs, dtype=torch.int64)
+
+
+def scores_filter(x2d, divisor=1.0, thr=None, fill=float("-inf")):
+    v = x2d / divisor if divisor != 1.0 else x2d.clone()
+    if thr is not None:
+        v = v.masked_fill(v < thr[:, None], fill)
+    return v
+
+
 def adamw_step(params, grads, exp_avg, exp_avg_sq, shadows, *, lr, beta1, beta2, eps, weight_decay, step, decoupled,
                mutate_grad=False, grad_scale=1.0):
     bc1, bc2 = 1.0 - beta1 ** step, 1.0 - beta2 ** step
@@ -260,6 +293,7 @@ def install(monkeypatch):
     """Patch cleantransformer_amd.ops in place (pytest's monkeypatch undoes it after the test)."""
     from cleantransformer_amd import ops
     for name in ("layernorm_fwd", "layernorm_bwd", "gemm", "colsum", "MaskInfo", "attn_fwd", "attn_bwd", "embed_fwd", "embed_bwd",
-                 "ce_fwd", "ce_bwd", "cast", "transpose_cast", "sumsq", "scale_", "argmax_lastdim", "adamw_step", "sgd_step"):
+                 "ce_fwd", "ce_bwd", "cast", "transpose_cast", "sumsq", "scale_", "argmax_lastdim", "row_lse", "group_topk",
+                 "scores_filter", "adamw_step", "sgd_step"):
         monkeypatch.setattr(ops, name, globals()[name])
     monkeypatch.setattr(ops, "_need_cuda", lambda *a: None)

@@ -372,6 +372,87 @@ def gen_gpt():
 
 
 # ---------------------------------------------------------------------------------------
+def gen_decode():
+    """SURVEY §8(f)3 — the rest of the decode path: beam search (generation_util.py:121-290, do_sample=False so that token ids
+    are deterministic), greedy with the n-gram ban, and the four logits processors (logits_processor.py) on seeded scores."""
+    from CleanTransformer.generation import logits_processor as lp
+    from CleanTransformer.models import modeling_gpt as rg
+    out = {}
+    # --- logits processors: data in / data out
+    g = torch.Generator().manual_seed(31)
+    sc = torch.randn(5, 97, generator=g) * 3.0
+    sc[1, 10] = sc[1, 20]                                   # an exact tie inside the row
+    hist = torch.randint(0, 9, (5, 14), generator=g)
+    out["lp_scores"], out["lp_hist"] = npy(sc), npy(hist)
+    for n in (2, 3):
+        out[f"lp_ngram{n}"] = npy(lp.NoRepeatNGramLogitsProcessor(n)(hist, sc.clone()))
+    out["lp_temp"] = npy(lp.TemperatureLogitsWrapper(0.7)(hist, sc.clone()))
+    out["lp_temp_floor"] = npy(lp.TemperatureLogitsWrapper(0.0)(hist, sc.clone()))
+    for k in (1, 10, 500):
+        out[f"lp_topk{k}"] = npy(lp.TopKLogitsWrapper(k)(hist, sc.clone()))
+    for pp in (0.3, 0.8, 1.0, 0.0):
+        out[f"lp_topp{pp}"] = npy(lp.TopPLogitsWrapper(pp)(hist, sc.clone()))
+    # --- Bloom beam search / n-gram greedy
+    V, H, L, nh = 211, 64, 2, 8
+    ids = torch.randint(0, V, (4, 16), generator=torch.Generator().manual_seed(7))
+    cfg, m = build(V, H, L, nh)
+    m.eval()
+    p_ids = ids[:3, :6].clone()
+    p_am = torch.ones(3, 6, dtype=torch.long)
+    p_am[1, :2] = 0
+    out["bloom_prompt"], out["bloom_mask"] = npy(p_ids), npy(p_am)
+    free = m.generate(p_ids, attention_mask=p_am,
+                      generation_configs=dict(beam_size=3, max_gen_len=6, do_sample=False, end_ids=[V + 5], pad_id=3))
+    out["bloom_beam3_free"] = npy(free)                      # an end id that can never be produced: pure beam expansion
+    # end ids taken from what the free run generated, so candidates do finish (both early_stop settings)
+    ends = sorted(set(int(t) for t in free[:, 0, 7:9].reshape(-1)))
+    out["bloom_ends"] = np.array(ends)
+    for es in (True, False):
+        r = m.generate(p_ids, attention_mask=p_am,
+                       generation_configs=dict(beam_size=3, max_gen_len=6, do_sample=False, end_ids=ends, pad_id=3, early_stop=es))
+        out[f"bloom_beam3_ends_es{int(es)}"] = npy(r)
+    r = m.generate(p_ids, attention_mask=p_am,
+                   generation_configs=dict(beam_size=2, max_gen_len=8, do_sample=False, end_ids=[V + 5], pad_id=3, no_repeat_ngram_size=2))
+    out["bloom_beam2_ngram2"] = npy(r)
+    rep = torch.tensor([[5, 9, 5, 9, 5, 9], [7, 7, 7, 7, 7, 7]])
+    out["bloom_rep_prompt"] = npy(rep)
+    for n in (0, 2):
+        r = m.generate(rep, attention_mask=torch.ones_like(rep),
+                       generation_configs=dict(beam_size=1, max_gen_len=8, do_sample=False, end_ids=None, pad_id=3, no_repeat_ngram_size=n))
+        out[f"bloom_greedy_ngram{n}"] = npy(r)
+    # --- GPT-2 beam search
+    Vg, Hg, Lg, nhg, P = 173, 64, 2, 4, 64
+    cfgg = rg.GPTConfig(vocab_size=Vg, n_embd=Hg, n_positions=P, n_layer=Lg, n_head=nhg, n_ctx=P, embd_pdrop=0.0, attn_pdrop=0.0,
+                        resid_pdrop=0.0)
+    mg = rg.GPTLMHeadModel(cfgg, version="gpt2")
+    with torch.no_grad():
+        for i, (name, prm) in enumerate(mg.named_parameters()):
+            r = torch.randn(prm.shape, generator=torch.Generator().manual_seed(1000 + i))
+            if prm.dim() > 1:
+                prm.copy_(r * 0.02)
+            elif ("norm" in name or "ln_f" in name) and name.endswith("weight"):
+                prm.copy_(1 + 0.1 * r)
+            else:
+                prm.copy_(0.02 * r)
+    mg.eval()
+    gids = torch.randint(0, Vg, (3, 24), generator=torch.Generator().manual_seed(7))[:2, :7].clone()
+    out["gpt_prompt"] = npy(gids)
+    free = mg.generate(gids, attention_mask=torch.ones(2, 7, dtype=torch.long),
+                       generation_configs=dict(beam_size=4, max_gen_len=6, do_sample=False, end_ids=[Vg + 1], pad_id=3))
+    out["gpt_beam4_free"] = npy(free)
+    ends = sorted(set(int(t) for t in free[:, 0, 8:10].reshape(-1)))
+    out["gpt_ends"] = np.array(ends)
+    for es in (True, False):
+        r = mg.generate(gids, attention_mask=torch.ones(2, 7, dtype=torch.long),
+                        generation_configs=dict(beam_size=4, max_gen_len=6, do_sample=False, end_ids=ends, pad_id=3, early_stop=es))
+        out[f"gpt_beam4_ends_es{int(es)}"] = npy(r)
+    np.savez_compressed(os.path.join(HERE, "decode.npz"), **out)
+    for k in ("bloom_beam3_free", "bloom_ends", "bloom_beam3_ends_es1", "bloom_beam3_ends_es0", "bloom_greedy_ngram0", "bloom_greedy_ngram2",
+              "gpt_beam4_free", "gpt_ends", "gpt_beam4_ends_es1"):
+        print(k, out[k].tolist())
+
+
+# ---------------------------------------------------------------------------------------
 def _ddp_worker(rank, world, port, ret):
     import torch.distributed as dist
     from torch.nn.parallel import DistributedDataParallel as DDP
@@ -431,7 +512,7 @@ def gen_known():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["ops", "tiny", "c1", "c5", "gpt", "ddp", "known"]
+    which = sys.argv[1:] or ["ops", "tiny", "c1", "c5", "gpt", "decode", "ddp", "known"]
     if "ops" in which:
         gen_ops()
     if "tiny" in which:
@@ -442,6 +523,8 @@ if __name__ == "__main__":
         gen_c5()
     if "gpt" in which:
         gen_gpt()
+    if "decode" in which:
+        gen_decode()
     if "ddp" in which:
         gen_ddp()
     if "known" in which:

@@ -114,8 +114,6 @@ def test_greedy_decode_loop_bit_exact(monkeypatch):
     out = m.generate(T(TINY["greedy_prompt"]), attention_mask=T(TINY["greedy_mask"]),
                      generation_configs=dict(beam_size=1, max_gen_len=6, do_sample=False, end_ids=None, pad_id=3))
     assert np.array_equal(out.numpy(), TINY["greedy_out"])
-    with pytest.raises(NotImplementedError):
-        m.generate(T(TINY["greedy_prompt"]), generation_configs=dict(beam_size=3))
 
 
 def test_generic_modules_vs_reference_golden(monkeypatch):
