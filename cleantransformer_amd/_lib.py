@@ -57,6 +57,8 @@ PROTOTYPES = {
     "ctmi_sumsq": (i32, [vp, i64, vp, i32, vp]),
     "ctmi_scale": (i32, [vp, i64, f32, vp, vp]),
     "ctmi_scale_copy": (i32, [vp, vp, i64, f32, vp]),
+    "ctmi_amp_unscale": (i32, [C.POINTER(vp), C.POINTER(i64), i32, vp, vp]),
+    "ctmi_amp_update": (i32, [vp, f32, f32, i32, vp]),
     "ctmi_argmax": (i32, [vp, i64, vp, i64, i64, i32, vp]),
     "ctmi_row_lse": (i32, [vp, i64, vp, i64, i64, i32, vp]),
     "ctmi_group_topk": (i32, [vp, i64, vp, vp, f32, vp, vp, i64, i32, i64, i32, i32, vp]),

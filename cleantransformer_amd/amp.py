@@ -1,0 +1,133 @@
+"""Loss scaling for the mixed-precision SFT loop — ``GradScaler`` with the surface of ``torch.cuda.amp.GradScaler`` as the
+reference's DDP script drives it (examples/ft_bloom_DDP.py:107-128):
+
+    scaler = GradScaler()
+    scaler.scale(loss).backward(); scaler.step(optimizer); scaler.update()
+
+MI355X-first: the record {scale, growth tracker, found_inf} lives in ONE device tensor; ``scale()`` multiplies by it on the
+device, ``unscale_`` is a multi-tensor in-place kernel (``ctmi_amp_unscale``: one launch per <= 24 gradients, writes
+``found_inf``), ``update()`` a one-thread kernel (``ctmi_amp_update``) — the scale itself is never read on the host.  The only
+host round-trip is the 4-byte ``found_inf`` read in ``step()``, the same one torch's scaler makes before deciding to call
+``optimizer.step()`` (so that a skipped step does not advance Adam's bias-correction count).
+
+With the bf16 compute policy of this package (fp32 master weights and gradients, bf16 operands) scaling is not needed for range;
+it is kept because the reference's loop uses it, and with a power-of-two scale in fp32/bf16 it is exact (scaled gradients are
+bit-identical after unscaling unless something overflowed).  ``autocast`` is accepted as a no-op context: the compute dtype is
+fixed by ``config.compute_dtype`` and the fused kernels do not dispatch through torch's autocast.
+"""
+from __future__ import annotations
+
+import contextlib
+
+import torch
+
+from . import ops
+
+
+@contextlib.contextmanager
+def autocast(*args, **kwargs):
+    """``torch.cuda.amp.autocast()`` stand-in for the reference's loop (ft_bloom_DDP.py:122): precision is a model property here."""
+    yield
+
+
+class GradScaler():
+    def __init__(self, init_scale=2.0 ** 16, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, enabled=True):
+        if enabled:
+            assert growth_factor > 1.0 and backoff_factor < 1.0
+        self._enabled = enabled
+        self._init_scale, self._growth, self._backoff, self._interval = float(init_scale), growth_factor, backoff_factor, int(growth_interval)
+        self._state = None                                   # device float[3]: scale, growth tracker, found_inf (lazily placed)
+        self._unscaled = set()                                # ids of optimizers already unscaled this step
+
+    # ------------------------------------------------------------------------------------------------ state
+    def _ensure(self, device):
+        if self._state is None:
+            self._state = torch.tensor([self._init_scale, 0.0, 0.0], dtype=torch.float32, device=device)
+        return self._state
+
+    def is_enabled(self):
+        return self._enabled
+
+    def get_scale(self):
+        if not self._enabled:
+            return 1.0
+        return self._init_scale if self._state is None else float(self._state[0])
+
+    def get_growth_factor(self):
+        return self._growth
+
+    def get_backoff_factor(self):
+        return self._backoff
+
+    def get_growth_interval(self):
+        return self._interval
+
+    def state_dict(self):
+        if not self._enabled:
+            return {}
+        tracker = 0 if self._state is None else int(self._state[1])
+        return {"scale": self.get_scale(), "growth_factor": self._growth, "backoff_factor": self._backoff,
+                "growth_interval": self._interval, "_growth_tracker": tracker}
+
+    def load_state_dict(self, sd):
+        if not self._enabled:
+            return
+        if len(sd) == 0:
+            raise RuntimeError("The source state dict is empty, possibly because it was saved from a disabled instance of GradScaler.")
+        self._init_scale, self._growth, self._backoff = float(sd["scale"]), sd["growth_factor"], sd["backoff_factor"]
+        self._interval = int(sd["growth_interval"])
+        if self._state is not None:
+            self._state.copy_(torch.tensor([self._init_scale, float(sd["_growth_tracker"]), 0.0]))
+        else:
+            self._pending_tracker = float(sd["_growth_tracker"])
+
+    # ------------------------------------------------------------------------------------------------ the three calls
+    def scale(self, outputs):
+        if not self._enabled:
+            return outputs
+        if isinstance(outputs, (list, tuple)):
+            return type(outputs)(self.scale(o) for o in outputs)
+        st = self._ensure(outputs.device)
+        if getattr(self, "_pending_tracker", None) is not None:
+            st[1] = self._pending_tracker
+            self._pending_tracker = None
+        return outputs * st[0].to(outputs.dtype)
+
+    @staticmethod
+    def _grads(optimizer):
+        if hasattr(optimizer, "param_groups"):
+            ps = [p for g in optimizer.param_groups for p in g["params"]]
+        else:
+            ps = list(optimizer.params)
+        return [p.grad for p in ps if p.grad is not None]
+
+    def unscale_(self, optimizer):
+        if not self._enabled:
+            return
+        if id(optimizer) in self._unscaled:
+            raise RuntimeError("unscale_() has already been called on this optimizer since the last update().")
+        grads = self._grads(optimizer)
+        if grads:
+            ops.amp_unscale(grads, self._ensure(grads[0].device))
+        self._unscaled.add(id(optimizer))
+
+    def step(self, optimizer, *args, **kwargs):
+        if not self._enabled:
+            return optimizer.step(*args, **kwargs)
+        if id(optimizer) not in self._unscaled:
+            self.unscale_(optimizer)
+        if self._state is not None and float(self._state[2]) != 0.0:      # the one host read of the step
+            return None                                                     # skipped: overflow in this step's gradients
+        return optimizer.step(*args, **kwargs)
+
+    def update(self, new_scale=None):
+        if not self._enabled:
+            return
+        self._unscaled.clear()
+        if self._state is None:
+            return
+        if new_scale is not None:
+            self._state[0] = float(new_scale)
+            self._state[2] = 0.0
+            return
+        ops.amp_update(self._state, self._growth, self._backoff, self._interval)

@@ -878,6 +878,66 @@ extern "C" int ctmi_adamw_step(float* const* p, float* const* g, float* const* m
     return CTMI_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ loss scaling (GradScaler)
+// torch.cuda.amp.GradScaler semantics (ft_bloom_DDP.py:107-128: scaler.scale(loss).backward(); scaler.step(opt); scaler.update()).
+// state[0] = scale, state[1] = growth tracker, state[2] = found_inf (0/1) — one device-resident record, so scale() / unscale /
+// update never read the scale on the host.  Unscale is in place (the caller can inspect true gradients after step(), as with
+// torch) and multi-tensor: one launch per <= 24 gradients instead of one per parameter.
+__global__ __launch_bounds__(256) void amp_unscale_k(MTPack pk, float* __restrict__ state) {
+    const int ti = blockIdx.y;
+    const int64_t n = pk.n[ti];
+    float* __restrict__ g = pk.g[ti];
+    const float inv = 1.0f / state[0];
+    bool bad = false;
+    const bool vec = (((uintptr_t)g) & 15) == 0;
+    const int64_t n4 = vec ? n / 4 : 0;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        float4 G = reinterpret_cast<float4*>(g)[i];
+        G.x *= inv; G.y *= inv; G.z *= inv; G.w *= inv;
+        bad |= !(isfinite(G.x) && isfinite(G.y) && isfinite(G.z) && isfinite(G.w));
+        reinterpret_cast<float4*>(g)[i] = G;
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float G = g[i] * inv;
+        bad |= !isfinite(G);
+        g[i] = G;
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) state[2] = 1.0f;          // benign race: every writer stores the same value
+}
+extern "C" int ctmi_amp_unscale(float* const* g, const int64_t* n, int count, float* state, void* stream) {
+    CTMI_REQUIRE(g && n && state && count >= 0, "amp_unscale: bad args");
+    for (int base = 0; base < count; base += CTMI_MT_MAX) {
+        const int c = std::min(CTMI_MT_MAX, count - base);
+        MTPack pk;
+        for (int i = 0; i < c; ++i) {
+            CTMI_REQUIRE(g[base + i] && n[base + i] >= 0, "amp_unscale: null tensor %d", base + i);
+            pk.p[i] = nullptr; pk.g[i] = g[base + i]; pk.m[i] = nullptr; pk.v[i] = nullptr; pk.shadow[i] = nullptr; pk.n[i] = n[base + i];
+        }
+        hipLaunchKernelGGL(amp_unscale_k, dim3(mt_grid_x(n + base, c), c), dim3(256), 0, as_stream(stream), pk, state);
+        CTMI_CHECK_LAUNCH("amp_unscale");
+    }
+    return CTMI_OK;
+}
+// torch's _amp_update_scale_: found_inf -> scale *= backoff, tracker = 0; else ++tracker, and at growth_interval scale *= growth
+// (only if the grown scale is finite), tracker = 0.  Clears found_inf for the next step.
+__global__ void amp_update_k(float* __restrict__ state, float growth, float backoff, int interval) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (state[2] != 0.0f) { state[0] *= backoff; state[1] = 0.0f; }
+    else {
+        const float t = state[1] + 1.0f;
+        if ((int)t == interval) { const float ns = state[0] * growth; if (isfinite(ns)) state[0] = ns; state[1] = 0.0f; }
+        else state[1] = t;
+    }
+    state[2] = 0.0f;
+}
+extern "C" int ctmi_amp_update(float* state, float growth, float backoff, int interval, void* stream) {
+    CTMI_REQUIRE(state && interval >= 1, "amp_update: bad args");
+    hipLaunchKernelGGL(amp_update_k, dim3(1), dim3(64), 0, as_stream(stream), state, growth, backoff, interval);
+    CTMI_CHECK_LAUNCH("amp_update");
+    return CTMI_OK;
+}
+
 struct SgdHyper { float lr, momentum, dampening, wd; int first; };
 __global__ __launch_bounds__(256) void sgd_mt_k(MTPack pk, SgdHyper h) {
     const int ti = blockIdx.y;

@@ -408,6 +408,22 @@ def adamw_step(params, grads, exp_avg, exp_avg_sq, shadows, *, lr, beta1, beta2,
                                       int(decoupled), int(mutate_grad), float(grad_scale), _stream()), "adamw_step")
 
 
+def amp_unscale(grads, state: Tensor) -> None:
+    """grads[i] *= 1/state[0] in place; state[2] = 1 if anything is not finite (GradScaler.unscale_)."""
+    n = len(grads)
+    if n == 0:
+        return
+    _need_cuda(state, *grads)
+    assert state.dtype == torch.float32 and state.numel() >= 3 and all(g.dtype == torch.float32 and g.is_contiguous() for g in grads)
+    sizes = (C.c_int64 * n)(*[g.numel() for g in grads])
+    check(_lib.load().ctmi_amp_unscale(_ptr_array(grads), sizes, n, _p(state), _stream()), "amp_unscale")
+
+
+def amp_update(state: Tensor, growth: float, backoff: float, interval: int) -> None:
+    _need_cuda(state)
+    check(_lib.load().ctmi_amp_update(_p(state), float(growth), float(backoff), int(interval), _stream()), "amp_update")
+
+
 def sgd_step(params, grads, bufs, shadows, *, lr, momentum, dampening, weight_decay, first_step) -> None:
     n = len(params)
     if n == 0:

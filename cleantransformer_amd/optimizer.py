@@ -38,6 +38,7 @@ class AdamW():
         self.weight_decay = weight_decay
         self.decoupled = decoupled
         self.grad_scale = grad_scale
+        self.param_groups = [{"params": self.params}]          # what torch.cuda.amp.GradScaler / clip utilities iterate
 
     def zero_grad(self):
         for param in self.params:
@@ -86,6 +87,7 @@ class SGD():
         self.dampening = dampening
         self.momentum_buffer = [None for _ in self.params]
         self.weight_decay = weight_decay
+        self.param_groups = [{"params": self.params}]
 
     def zero_grad(self):
         for param in self.params:

@@ -147,6 +147,13 @@ int ctmi_sgd_step(float* const* p, float* const* g, float* const* buf /* momentu
                   void* const* shadow, const int64_t* n, int count, float lr, float momentum, float dampening,
                   float weight_decay, int first_step, void* stream);
 
+/* ---- loss scaling: the kernels under cleantransformer_amd.amp.GradScaler (torch.cuda.amp.GradScaler as ft_bloom_DDP.py:107-128
+ *      drives it).  state = device float[3] {scale, growth tracker, found_inf}. */
+/* g[i] *= 1/scale in place (multi-tensor); found_inf = 1 if any result is not finite */
+int ctmi_amp_unscale(float* const* g /*host*/, const int64_t* n /*host*/, int count, float* state /*device*/, void* stream);
+/* scale/tracker update after a step (backoff on found_inf, growth every `interval` clean steps); clears found_inf */
+int ctmi_amp_update(float* state /*device*/, float growth, float backoff, int interval, void* stream);
+
 /* ---- small utilities on flat buffers */
 int ctmi_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
 /* dst[c][r] = cast(src[r][c]): the [out,in] compute copy of a GPT-2 Conv1D weight kept as [in,out] (modeling_gpt.py:32-46) */

@@ -275,6 +275,30 @@ def adamw_step(params, grads, exp_avg, exp_avg_sq, shadows, *, lr, beta1, beta2,
             shadows[i].copy_(p.to(shadows[i].dtype))
 
 
+def amp_unscale(grads, state):
+    inv = 1.0 / state[0]
+    for g in grads:
+        g.mul_(inv)
+        if not torch.isfinite(g).all():
+            state[2] = 1.0
+
+
+def amp_update(state, growth, backoff, interval):
+    if float(state[2]) != 0.0:
+        state[0] *= backoff
+        state[1] = 0.0
+    else:
+        t = float(state[1]) + 1.0
+        if int(t) == interval:
+            ns = state[0] * growth
+            if torch.isfinite(ns):
+                state[0] = ns
+            state[1] = 0.0
+        else:
+            state[1] = t
+    state[2] = 0.0
+
+
 def sgd_step(params, grads, bufs, shadows, *, lr, momentum, dampening, weight_decay, first_step):
     for i, (p, g) in enumerate(zip(params, grads)):
         p = p.data
@@ -294,6 +318,6 @@ def install(monkeypatch):
     from cleantransformer_amd import ops
     for name in ("layernorm_fwd", "layernorm_bwd", "gemm", "colsum", "MaskInfo", "attn_fwd", "attn_bwd", "embed_fwd", "embed_bwd",
                  "ce_fwd", "ce_bwd", "cast", "transpose_cast", "sumsq", "scale_", "argmax_lastdim", "row_lse", "group_topk",
-                 "scores_filter", "adamw_step", "sgd_step"):
+                 "scores_filter", "amp_unscale", "amp_update", "adamw_step", "sgd_step"):
         monkeypatch.setattr(ops, name, globals()[name])
     monkeypatch.setattr(ops, "_need_cuda", lambda *a: None)

@@ -1,0 +1,113 @@
+"""GPU: loss scaling through the C ABI (ctmi_amp_unscale / ctmi_amp_update) — SURVEY §8(f)2, ft_bloom_DDP.py:107-128."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TINY = np.load(os.path.join(HERE, "golden", "tiny_bloom.npz"))
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_unscale_kernel_multi_tensor_and_found_inf():
+    from cleantransformer_amd import ops
+    g = torch.Generator().manual_seed(2)
+    sizes = [1, 3, 4, 5, 1023, 4096, 70001] + [17] * 30                   # > 24 tensors: several launches; odd tails
+    grads = [torch.randn(n, generator=g).to(DEV) for n in sizes]
+    base = torch.randn(sum(sizes) + 1, generator=g).to(DEV)
+    grads.append(base[1:1 + 4097])                                          # a 4-byte-aligned (not 16-byte) view: scalar path
+    ref = [x.clone() for x in grads]
+    state = torch.tensor([8.0, 5.0, 0.0], device=DEV)
+    ops.amp_unscale(grads, state)
+    for x, r in zip(grads, ref):
+        assert torch.equal(x, r / 8.0)
+    assert state.tolist() == [8.0, 5.0, 0.0]
+    for bad in (float("inf"), float("-inf"), float("nan")):
+        state[2] = 0.0
+        grads[6][70000] = bad                                               # last element of a large tensor
+        ops.amp_unscale(grads, state)
+        assert float(state[2]) == 1.0
+        grads[6][70000] = 0.0
+    # overflow produced BY the unscale (tiny scale) is caught as well
+    state = torch.tensor([1e-30, 0.0, 0.0], device=DEV)
+    big = [torch.full((100,), 1e20, device=DEV)]
+    ops.amp_unscale(big, state)
+    assert float(state[2]) == 1.0
+
+
+def test_update_kernel_matches_torch_semantics():
+    from cleantransformer_amd import ops
+    st = torch.tensor([1024.0, 0.0, 1.0], device=DEV)
+    ops.amp_update(st, 2.0, 0.5, 3)
+    assert st.tolist() == [512.0, 0.0, 0.0]
+    for expect in ([512.0, 1.0, 0.0], [512.0, 2.0, 0.0], [1024.0, 0.0, 0.0]):
+        ops.amp_update(st, 2.0, 0.5, 3)
+        assert st.tolist() == expect
+    st = torch.tensor([3e38, 0.0, 0.0], device=DEV)                         # growth that would overflow keeps the scale
+    ops.amp_update(st, 2.0, 0.5, 1)
+    assert st.tolist()[0] == pytest.approx(3e38) and st.tolist()[1:] == [0.0, 0.0]
+
+
+@pytest.mark.parametrize("cd", ["fp32", "bf16"])
+def test_scaled_loop_equals_unscaled_loop(cd):
+    """Power-of-two scaling is exact in fp32 and in bf16 operands: the scaled run reproduces the unscaled run bit for bit
+    (fp32: and therefore the reference's golden trajectory)."""
+    from test_gpu_bloom import build
+    from cleantransformer_amd.amp import GradScaler
+    from cleantransformer_amd.examples.ft_bloom import train_step, train_step_amp
+    from cleantransformer_amd.optimizer import AdamW
+    V, H, L, nh, B, S = [int(v) for v in TINY["cfg"]]
+    batch = {"input_ids": T(TINY["ids"]).to(DEV), "attention_mask": T(TINY["mask"]).to(DEV), "labels": T(TINY["ids"]).clone().to(DEV)}
+    ma, mb = build(V, H, L, nh, cd), build(V, H, L, nh, cd)
+    oa = AdamW(ma.parameters(), lr=1e-5, weight_decay=0.01, decoupled=True)
+    ob = AdamW(mb.parameters(), lr=1e-5, weight_decay=0.01, decoupled=True)
+    scaler = GradScaler()
+    for t in range(4):
+        la = train_step(ma, batch, oa)
+        ob.zero_grad()
+        lb = train_step_amp(mb, batch, ob, scaler)
+        assert float(la) == float(lb), (t, float(la), float(lb))
+        if cd == "fp32":
+            assert abs(float(lb) - TINY["traj"][t, 0]) <= 1e-5 * TINY["traj"][t, 0]
+    for (n, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert torch.equal(pa, pb), n
+    assert scaler.get_scale() == 65536.0
+
+
+def test_overflow_skips_and_torch_scaler_interop():
+    from test_gpu_bloom import build
+    from cleantransformer_amd.amp import GradScaler
+    from cleantransformer_amd.optimizer import AdamW
+    V, H, L, nh, B, S = [int(v) for v in TINY["cfg"]]
+    batch = {"input_ids": T(TINY["ids"]).to(DEV), "attention_mask": T(TINY["mask"]).to(DEV), "labels": T(TINY["ids"]).clone().to(DEV)}
+    m = build(V, H, L, nh)
+    opt = AdamW(m.parameters(), lr=1e-5, weight_decay=0.01, decoupled=True)
+    scaler = GradScaler(init_scale=1024.0, growth_interval=2)
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    (loss, _, _), _ = m(**batch)
+    scaler.scale(loss).backward()
+    m.bloom.ln_f.bias.grad[3] = float("inf")
+    assert scaler.step(opt) is None
+    scaler.update()
+    assert scaler.get_scale() == 512.0 and opt.steps[0] == 1
+    for n, p in m.named_parameters():
+        assert torch.equal(p.detach(), before[n]), n
+    # the caller's own torch.cuda.amp.GradScaler() (ft_bloom_DDP.py:109) drives the fused optimizer too
+    ts = torch.amp.GradScaler("cuda", init_scale=256.0)
+    for t in range(2):
+        opt.zero_grad()
+        (loss, _, _), _ = m(**batch)
+        ts.scale(loss).backward()
+        ts.step(opt)
+        ts.update()
+        assert abs(float(loss) - TINY["traj"][t, 0]) <= 1e-5 * TINY["traj"][t, 0]
+    assert opt.steps[0] == 3
