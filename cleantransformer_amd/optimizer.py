@@ -45,6 +45,27 @@ class AdamW():
             if param.grad is not None:
                 param.grad = None
 
+    def state_dict(self):
+        """torch.optim-style layout (what the trainer writes to ``optimizer.pt``, trainer.py:1440): per-parameter step count
+        and the two moment buffers, keyed by the parameter's position."""
+        state = {i: {"step": self.steps[i], "exp_avg": self.momentum_buffer[i], "exp_avg_sq": self.rmsp_buffer[i]}
+                 for i in range(len(self.params)) if torch.is_tensor(self.momentum_buffer[i])}
+        group = {"lr": self.lr, "betas": (self.beta1, self.beta2), "eps": self.eps, "weight_decay": self.weight_decay,
+                 "decoupled": self.decoupled, "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        g = sd["param_groups"][0]
+        if len(g["params"]) != len(self.params):
+            raise ValueError("loaded state dict has a different number of parameters")
+        self.lr, (self.beta1, self.beta2), self.eps = g["lr"], g["betas"], g["eps"]
+        self.weight_decay, self.decoupled = g["weight_decay"], g.get("decoupled", self.decoupled)
+        for i, st in sd["state"].items():
+            p = self.params[int(i)]
+            self.steps[int(i)] = int(st["step"])
+            self.momentum_buffer[int(i)] = st["exp_avg"].to(device=p.device, dtype=torch.float32).clone()
+            self.rmsp_buffer[int(i)] = st["exp_avg_sq"].to(device=p.device, dtype=torch.float32).clone()
+
     def _lazy_state(self, i, p):
         if not torch.is_tensor(self.momentum_buffer[i]):
             self.momentum_buffer[i] = torch.zeros_like(p, dtype=torch.float32)
@@ -93,6 +114,19 @@ class SGD():
         for param in self.params:
             if param.grad is not None:
                 param.grad = None
+
+    def state_dict(self):
+        state = {i: {"momentum_buffer": b} for i, b in enumerate(self.momentum_buffer) if b is not None}
+        group = {"lr": self.lr, "momentum": self.momentum, "dampening": self.dampening, "weight_decay": self.weight_decay,
+                 "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        g = sd["param_groups"][0]
+        self.lr, self.momentum, self.dampening, self.weight_decay = g["lr"], g["momentum"], g["dampening"], g["weight_decay"]
+        for i, st in sd["state"].items():
+            p = self.params[int(i)]
+            self.momentum_buffer[int(i)] = st["momentum_buffer"].to(device=p.device, dtype=torch.float32).clone()
 
     @torch.no_grad()
     def step(self):

@@ -127,3 +127,65 @@ def test_ddp_matches_torch_ddp_on_reference_model(world, bucket_mb):
     # the tied embedding / LM-head gradient went through the early dense all-reduce + row exchange in every plain synced
     # backward (3 of them), and through its bucket in the accumulation step
     assert ret["early_steps"] == 2 and ret["early_in_accum"] == 0, (ret["early_steps"], ret["early_in_accum"])
+
+
+def _trainer_worker(rank, world, port, out_dir, ret):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cpu_kernel_emulation as emu
+    emu.install(_Patch())
+    from test_host_logic_cpu import TINY, T, build
+    from cleantransformer_amd.trainer import Trainer, TrainingArguments
+    V, H, L, nh, B, S = [int(v) for v in TINY["cfg"]]
+    ids, am = T(TINY["ids"]), T(TINY["mask"])
+    rows = slice(rank * 2, rank * 2 + 2)                         # each rank: half of the golden batch, as TWO micro-batches of one row
+
+    class Data:
+        def __iter__(self):
+            for r in range(rows.start, rows.stop):
+                yield {"input_ids": ids[r:r + 1], "attention_mask": am[r:r + 1], "labels": ids[r:r + 1].clone()}
+
+        def __len__(self):
+            return 2
+    args = TrainingArguments(output_dir=out_dir, device="cpu", max_steps=1, gradient_accumulation_steps=2, per_device_train_batch_size=1,
+                             learning_rate=1e-5, weight_decay=0.01, lr_scheduler_type="constant", max_grad_norm=1e9, logging_steps=1, save_steps=1)
+    tr = Trainer(model=build(V, H, L, nh), args=args, train_dataset=Data())
+    tr.train()
+    if rank == 0:
+        ret["log"] = dict(tr.state.log_history[0])
+        ret["files"] = sorted(os.listdir(os.path.join(out_dir, "checkpoint-1")))
+        ret["wrapped"] = type(tr.model_wrapped).__name__
+        for n, p in tr.model.named_parameters():
+            ret["p_" + n] = p.detach().numpy().copy()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_trainer_under_ddp_accumulation_equals_the_golden_full_batch_step(tmp_path):
+    """world 2 x gradient_accumulation 2 x micro-batch 1 = the golden batch of 4 rows: one all-reduce per optimizer step
+    (micro-step 1 runs under no_sync), averaged loss / grad-norm in the log, rank-0-only checkpoint, parameters after the step
+    equal to the single-process full-batch step."""
+    from test_host_logic_cpu import TINY
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_trainer_worker, args=(2, _free_port(), str(tmp_path), ret), nprocs=2, join=True)
+    assert ret["wrapped"] == "DistributedDataParallel"
+    assert abs(ret["log"]["loss"] - float(TINY["traj"][0, 0])) <= 1.01e-4
+    assert abs(ret["log"]["grad_norm"] - float(TINY["traj"][0, 1])) <= 1e-4 * float(TINY["traj"][0, 1])
+    assert ret["files"] == sorted(["pytorch_model.bin", "optimizer.pt", "scheduler.pt", "trainer_state.json", "rng_state_0.pth",
+                                   "training_args.bin"])
+    import cpu_kernel_emulation as emu
+    from test_host_logic_cpu import T, build
+    from cleantransformer_amd.examples.ft_bloom import train_step
+    from cleantransformer_amd.optimizer import AdamW
+    emu.install(_Patch())                                          # (process-wide; this module's other tests spawn their own workers)
+    V, H, L, nh, B, S = [int(v) for v in TINY["cfg"]]
+    m = build(V, H, L, nh)
+    train_step(m, {"input_ids": T(TINY["ids"]), "attention_mask": T(TINY["mask"]), "labels": T(TINY["ids"]).clone()},
+               AdamW(m.parameters(), lr=1e-5, weight_decay=0.01, decoupled=True))
+    for n, p in m.named_parameters():
+        assert np.allclose(ret["p_" + n], p.detach().numpy(), rtol=1e-6, atol=5e-8), n
