@@ -17,6 +17,14 @@
 #include <type_traits>
 #include "mma.h"
 
+// Ping-pong epilogue re-layout.  0 (default): 128-row tiles (WM = 4) re-layout across lanes with v_permlane16_swap, 256-row tiles
+// through the per-wave LDS patches; 1: LDS patches everywhere (A/B builds).  Same-box A/B (bf16, T = 8192): 128x256 tiles
+// +9 % with the cross-lane form (4hh dgrad 935 -> 1020 TF/s); 256x256 tiles are neutral on [T,4H] outputs and 8 % SLOWER on the
+// logits-sized output (64-byte instead of 128-byte row segments per store instruction), so they keep the LDS form.
+#ifndef CTMI_EPI_SHUFFLE
+#define CTMI_EPI_SHUFFLE 0
+#endif
+
 template <typename T> struct Tile;
 template <> struct Tile<bf16_t> { static constexpr int BM = 128, BN = 128, BK = 64, PADK = 8, PADR = 8; };
 template <> struct Tile<float>  { static constexpr int BM = 128, BN = 128, BK = 16, PADK = 4, PADR = 4; };
@@ -656,11 +664,117 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
                     __builtin_amdgcn_sched_barrier(0);                         // one pass at a time: keeps the live set at acc + one pass
                 }
             };
+            // Cross-lane variant of the same re-layout: v_permlane16_swap exchanges the odd 16-lane rows of one register
+            // with the even rows of another, so swapping the accumulators of column tiles j and j+1 element by element
+            // leaves every lane with 8 consecutive columns of its row (lane group q: columns 32*jp + 16*(q&1) + 8*(q>>1))
+            // — 16-byte bf16 stores / side-input loads, 64 contiguous bytes per row and instruction, with no LDS round
+            // trip (4 swaps per 8 values instead of 2 ds_write_b128 + 2 ds_read_b128 and their waits).
+            auto direct = [&](auto plain_c, auto nt_flag) {
+                constexpr bool PLAIN = decltype(plain_c)::value;
+                constexpr bool NT = decltype(nt_flag)::value;
+                const int q = lane >> 4;
+                const int64_t offL = (mw + (lane & 15)) * g.ldc + nw + 16 * (q & 1) + 8 * (q >> 1);
+                const int64_t row16 = 16 * g.ldc;
+                uint4 pre[2][PRE ? 4 : 1];
+                auto prefetch = [&](int p, int slot) {
+                    if constexpr (PRE) {
+#pragma unroll
+                        for (int it = 0; it < 4; ++it) pre[slot][it] = *reinterpret_cast<const uint4*>(side + offL + (p * 2 + (it >> 1)) * row16 + 32 * (it & 1));
+                    }
+                };
+                prefetch(0, 0);
+#pragma unroll
+                for (int p = 0; p < WM / 2; ++p) {
+                    if (p + 1 < WM / 2) prefetch(p + 1, (p + 1) & 1);
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int i = p * 2 + (it >> 1), jp = it & 1;
+                        f32x4 a = acc[i][2 * jp] * g.alpha, b = acc[i][2 * jp + 1] * g.alpha;
+                        if (g.bias != nullptr) { a += bias4[2 * jp]; b += bias4[2 * jp + 1]; }
+                        // (inline asm, not __builtin_amdgcn_permlane16_swap: in the 256-row instantiations hipcc merged the four
+                        // swaps of a register quad into one and replicated its result — caught by the forced-tile parity test.
+                        // One statement per quad; the leading s_nop 1 is the "VALU write -> v_permlane read" hazard pad.)
+                        float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
+                        asm volatile("s_nop 1\n\t"
+                                     "v_permlane16_swap_b32 %0, %4\n\t"
+                                     "v_permlane16_swap_b32 %1, %5\n\t"
+                                     "v_permlane16_swap_b32 %2, %6\n\t"
+                                     "v_permlane16_swap_b32 %3, %7"
+                                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+                        float v[8] = {a0, a1, a2, a3, b0, b1, b2, b3};
+                        const int64_t off = offL + i * row16 + 32 * jp;
+                        if (EPI == CTMI_EPI_GELU) {
+                            const uint4 tb = pack16<T>(v);
+                            *reinterpret_cast<uint4*>(AUXO + off) = tb;
+                            unpack16<T>(tb, v);
+#pragma unroll
+                            for (int r = 0; r < 8; r += 2) { const f32x2 y = gelu_tanh_pk(f32x2{v[r], v[r + 1]}); v[r] = y[0]; v[r + 1] = y[1]; }
+                        } else if (EPI == CTMI_EPI_RELU) {
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+                        } else if (EPI == CTMI_EPI_DGELU || EPI == CTMI_EPI_DRELU) {
+                            float u[8];
+                            if constexpr (PRE_AUX) unpack16<T>(pre[p & 1][it], u);
+                            else unpack16<T>(*reinterpret_cast<const uint4*>(AUXI + off), u);
+                            if (EPI == CTMI_EPI_DGELU) {
+#pragma unroll
+                                for (int r = 0; r < 8; r += 2) { const f32x2 y = f32x2{v[r], v[r + 1]} * gelu_tanh_grad_pk(f32x2{u[r], u[r + 1]}); v[r] = y[0]; v[r + 1] = y[1]; }
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 8; ++r) v[r] = u[r] > 0.f ? v[r] : 0.f;
+                            }
+                        }
+                        if constexpr (PRE_RES) {
+                            float u[8];
+                            unpack16<T>(pre[p & 1][it], u);
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) v[r] += u[r];
+                        } else if constexpr (!PLAIN) {
+                            if (R != nullptr) {
+                                float u[8];
+                                unpack16<T>(*reinterpret_cast<const uint4*>(R + off), u);
+#pragma unroll
+                                for (int r = 0; r < 8; ++r) v[r] += u[r];
+                            }
+                        }
+                        if constexpr (sizeof(TO) == 4) {
+                            float* Cf = reinterpret_cast<float*>(C) + off;
+                            if constexpr (!PLAIN) {
+                                if (g.beta) {
+                                    const f32x4 c0v = *reinterpret_cast<const f32x4*>(Cf), c1v = *reinterpret_cast<const f32x4*>(Cf + 4);
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) { v[r] += c0v[r]; v[4 + r] += c1v[r]; }
+                                }
+                            }
+                            *reinterpret_cast<f32x4*>(Cf) = f32x4{v[0], v[1], v[2], v[3]};
+                            *reinterpret_cast<f32x4*>(Cf + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                        } else {
+                            if constexpr (!PLAIN) {
+                                if (g.beta) {
+                                    float u[8];
+                                    unpack16<T>(*reinterpret_cast<const uint4*>(C + off), u);
+#pragma unroll
+                                    for (int r = 0; r < 8; ++r) v[r] += u[r];
+                                }
+                            }
+                            const uint4 pk = pack16<T>(v);
+                            if (NT && g.nt_c) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(C + off), "v"(__builtin_bit_cast(u32x4, pk)) : "memory");
+                            else *reinterpret_cast<uint4*>(C + off) = pk;
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);                         // one pass at a time: keeps the live set at acc + one pass
+                }
+            };
             const bool plain = (PRE_RES || R == nullptr) && !g.beta;
             constexpr bool CAN_NT = sizeof(TO) == 2 && EPI == CTMI_EPI_NONE && !RES;
-            if (plain) shuffle(std::true_type{}, std::integral_constant<bool, CAN_NT>{});
-            else shuffle(std::false_type{}, std::false_type{});
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // patch reads retired before the other row group may write it
+            if constexpr (!CTMI_EPI_SHUFFLE && WM == 4) {
+                if (plain) direct(std::true_type{}, std::integral_constant<bool, CAN_NT>{});
+                else direct(std::false_type{}, std::false_type{});
+            } else {
+                if (plain) shuffle(std::true_type{}, std::integral_constant<bool, CAN_NT>{});
+                else shuffle(std::false_type{}, std::false_type{});
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // patch reads retired before the other row group may write it
+            }
             return;
         }
     }
