@@ -24,6 +24,16 @@
 #ifndef CTMI_EPI_SHUFFLE
 #define CTMI_EPI_SHUFFLE 0
 #endif
+// LDS-DMA ring depth.  Free-running tiles: 3 stages.  Ping-pong: 4 stages + 4 x 8 KiB epilogue patches; the 128-row tile's
+// cross-lane epilogue needs no patches (96 KiB).  Its 24 KiB stages would fit six times into 160 KiB (five K-steps of prefetch
+// instead of three): measured same-box, that is neutral per kernel and 0.3 ms/step WORSE in the training step — the 64 KiB it
+// leaves free is what lets a weight-gradient workgroup of the side stream share the CU.  CTMI_PP128_RING keeps the knob.
+#ifndef CTMI_PP128_RING
+#define CTMI_PP128_RING 4
+#endif
+constexpr int glds_ring(bool pp, int wm) { return !pp ? 3 : ((wm == 4 && !CTMI_EPI_SHUFFLE) ? CTMI_PP128_RING : 4); }
+constexpr int glds_patch_bytes(bool pp, int wm) { return (pp && !(wm == 4 && !CTMI_EPI_SHUFFLE)) ? 4 * 8192 : 0; }
+
 
 template <typename T> struct Tile;
 template <> struct Tile<bf16_t> { static constexpr int BM = 128, BN = 128, BK = 64, PADK = 8, PADR = 8; };
@@ -400,7 +410,7 @@ template <typename TO, bool AK, bool BKM, int EPI, int WM, int WGN, bool PP = fa
 __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
     using T = bf16_t;
     constexpr int NW = 2 * WGN;                                             // waves: 2 along M x WGN along N
-    constexpr int BM = WM * 32, BN = WGN * 64, BK = 32, NST = PP ? 4 : 3;
+    constexpr int BM = WM * 32, BN = WGN * 64, BK = 32, NST = glds_ring(PP, WM);
     using TA = GTile<AK, BM>;
     using TB = GTile<BKM, BN>;
     constexpr int STAGE = TA::BYTES + TB::BYTES;
@@ -873,18 +883,22 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
         // ---- ping-pong schedule (8 waves, one workgroup per CU).  Every SIMD holds one wave of row-group wr = 0 and one
         // of wr = 1; group 1 runs one barrier behind group 0, so while one group's 32 MFMAs own the matrix pipe the
         // other group reads its fragments from LDS and issues its LDS-DMA pieces.  Two barriers per K-step:
-        //   phase A: ds_read fragments of stage c | DMA-issue stage c+3 | wait own pieces of stage c+1 | lgkmcnt(0)
+        //   phase A: ds_read fragments of stage c | DMA-issue stage c+NST-1 | wait own pieces of stage c+1 | lgkmcnt(0)
         //   phase B: MFMA
         // RAW: a stage is read one full K-step after every wave's counted wait for it (the lagging group's wait
-        // precedes the barrier the leading group passes before reading).  WAR: stage c+3 reuses the slot of stage c-1,
+        // precedes the barrier the leading group passes before reading).  WAR: stage c+NST-1 reuses the slot of stage c-1,
         // whose last reads (lagging group, phase A of c-1) were retired by lgkmcnt(0) before the barrier in between.
         auto wait_stages = [&](int n) {                                       // allow n younger stages to stay in flight
-            if (n >= 2) { if (LOADS == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+            static_assert(LOADS == 3 || LOADS == 4, "counted waits are spelled out for 3 or 4 DMA instructions per stage");
+            static_assert(NST <= 6, "wait_stages covers rings of up to 6 stages");
+            if (n >= 4 && NST >= 6) { if (LOADS == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
+            else if (n >= 3 && NST >= 5) { if (LOADS == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); }
+            else if (n >= 2) { if (LOADS == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
             else if (n == 1) { if (LOADS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         };
 #pragma unroll 1
-        for (int s = 0; s < 3 && wi < nwork; ++s) {
+        for (int s = 0; s < NST - 1 && wi < nwork; ++s) {
             issue_stage(wrb);
             stage_issued(); ++inflight; wrb = wrb == NST - 1 ? 0 : wrb + 1;
         }
@@ -1021,7 +1035,7 @@ static bool shared_mode();
 template <typename TO, bool AK, bool BKM, int EPI, int WM, int WGN, bool PP = false, bool RES = false>
 static void glds_launch(GemmArgs& g, hipStream_t st) {
     constexpr int BM = WM * 32, BN = WGN * 64;
-    const size_t lds = (PP ? 4 : 3) * (size_t)(GTile<AK, BM>::BYTES + GTile<BKM, BN>::BYTES) + (PP ? 4 * 8192 : 0);   // PP: + epilogue patches
+    const size_t lds = glds_ring(PP, WM) * (size_t)(GTile<AK, BM>::BYTES + GTile<BKM, BN>::BYTES) + glds_patch_bytes(PP, WM);
     const int64_t nwork = cdiv64(g.M, BM) * cdiv64(g.N, BN) * g.splits;
     // persistent launch: one resident workgroup per occupancy slot (256 CUs x workgroups that fit a CU's 160 KiB LDS),
     // each walking work items bid, bid+G, ... with its DMA stream prefetching across item boundaries
