@@ -18,9 +18,12 @@
 #include "mma.h"
 
 // Ping-pong epilogue re-layout.  0 (default): 128-row tiles (WM = 4) re-layout across lanes with v_permlane16_swap, 256-row tiles
-// through the per-wave LDS patches; 1: LDS patches everywhere (A/B builds).  Same-box A/B (bf16, T = 8192): 128x256 tiles
-// +9 % with the cross-lane form (4hh dgrad 935 -> 1020 TF/s); 256x256 tiles are neutral on [T,4H] outputs and 8 % SLOWER on the
-// logits-sized output (64-byte instead of 128-byte row segments per store instruction), so they keep the LDS form.
+// through the per-wave LDS patches; 1: LDS patches everywhere (A/B builds).  Same-box A/B of "cross-lane everywhere" against
+// "patches everywhere" (bf16, T = 8192): 256x256 tiles — row-major-B [T,4H] output +9 % (939 -> 1019 TF/s), K-major-B [T,4H]
+// output neutral, logits-sized output 8 % SLOWER (64-byte instead of 128-byte row segments per store instruction; 3.80 ->
+// 4.13 ms, which decides it for this tile); 128x256 tiles — +2 % per kernel (inside the noise), 189 -> 159 VGPRs, and no
+// patches: 96 instead of 128 KiB of LDS, which is what a side-stream weight-gradient workgroup needs to share the CU (the
+// side stream's gain in the step went from 0.6 to 1.2 ms).
 #ifndef CTMI_EPI_SHUFFLE
 #define CTMI_EPI_SHUFFLE 0
 #endif
