@@ -639,6 +639,26 @@ __device__ __forceinline__ void lse_merge(float& m, float& s, float m2, float s2
     m = mn;
 }
 
+// Streaming (non-temporal) 16-byte accesses for single-pass kernels whose data is far larger than the 256 MiB Infinity Cache
+// (the optimizer walks 16.8 GB per step, the loss backward 8.2 GB): no line is ever reused, so none should be kept.
+typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ldg_stream(const float* p) {
+    const f32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void stg_stream(float* p, const float4& v) {
+    __builtin_nontemporal_store(f32x4_nt{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4_nt*>(p));
+}
+
+__device__ __forceinline__ uint4 ldg_stream16(const void* p) {
+    const u32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt*>(p));
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void stg_stream16(void* p, const uint4& v) {
+    __builtin_nontemporal_store(u32x4_nt{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4_nt*>(p));
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void ce_fwd_k(const T* __restrict__ logits, int64_t ld, const int64_t* __restrict__ labels,
                                                 float* __restrict__ row_lse, float* __restrict__ row_loss,
@@ -748,14 +768,14 @@ __global__ __launch_bounds__(256) void ce_bwd_k(const T* __restrict__ logits, in
             float o[VEC];
             if (live) {
                 float v[VEC];
-                unpack16<T>(*reinterpret_cast<const uint4*>(x + c), v);
+                unpack16<T>(ldg_stream16(x + c), v);                      // logits: last use
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) o[j] = (__expf(v[j] - lse) - ((c + j == t) ? 1.0f : 0.0f)) * coef;
             } else {
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) o[j] = 0.f;
             }
-            *reinterpret_cast<uint4*>(d + c) = pack16<T>(o);
+            stg_stream16(d + c, pack16<T>(o));                            // 4.1 GB of dlogits: far beyond any cache
         }
     } else {
         for (int64_t c = threadIdx.x; c < C; c += 256)
@@ -832,12 +852,12 @@ __global__ __launch_bounds__(256) void adamw_mt_k(MTPack pk, AdamHyper h) {
     const int64_t n4 = vec ? (n / 4) : 0;
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-        float4 P = reinterpret_cast<float4*>(p)[i], G = reinterpret_cast<const float4*>(g)[i];
-        float4 M = reinterpret_cast<float4*>(m)[i], V = reinterpret_cast<float4*>(v)[i];
+        float4 P = ldg_stream(p + 4 * i), G = ldg_stream(g + 4 * i);
+        float4 M = ldg_stream(m + 4 * i), V = ldg_stream(v + 4 * i);
         adam_one(P.x, G.x, M.x, V.x, h); adam_one(P.y, G.y, M.y, V.y, h);
         adam_one(P.z, G.z, M.z, V.z, h); adam_one(P.w, G.w, M.w, V.w, h);
-        reinterpret_cast<float4*>(p)[i] = P; reinterpret_cast<float4*>(m)[i] = M; reinterpret_cast<float4*>(v)[i] = V;
-        if (h.mutate_grad) reinterpret_cast<float4*>(g)[i] = G;
+        stg_stream(p + 4 * i, P); stg_stream(m + 4 * i, M); stg_stream(v + 4 * i, V);
+        if (h.mutate_grad) stg_stream(g + 4 * i, G);
         if (sh) reinterpret_cast<uint2*>(sh)[i] = make_uint2(pack_bf2(P.x, P.y), pack_bf2(P.z, P.w));
     }
     for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
