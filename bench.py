@@ -156,7 +156,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ops.set_timer(None)
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
