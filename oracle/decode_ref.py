@@ -6,8 +6,8 @@ TEST INFRASTRUCTURE — the oracle for ``cleantransformer_amd/generation``; neve
 Parity status: PINNED by ``tests/test_decode_cpu.py::test_oracle_*`` against ``tests/golden/decode.npz``, produced in the build
 container by the reference's own ``generate`` / processor classes (``tests/golden/make_golden.py decode``).
 
-The model is abstracted as ``step_fn(ids_new, attention_mask, pasts) -> (logits [rows, S_new, V], pasts)`` so that the same
-search runs over ``oracle.bloom_ref`` and ``oracle.gpt_ref``.  Only the deterministic configuration (``do_sample=False``) is
+The model is abstracted as ``step_fn(ids_new, attention_mask, pasts[, position_ids=, segment_ids=]) -> (logits [rows, S_new, V],
+pasts)`` so that the same search runs over ``oracle.bloom_ref`` and ``oracle.gpt_ref``.  Only the deterministic configuration (``do_sample=False``) is
 restated: sampled ids depend on the RNG stream.
 """
 from __future__ import annotations
@@ -55,20 +55,31 @@ def top_p(scores: Tensor, p: float, fill: float = -float("inf"), min_keep: int =
 
 
 # ------------------------------------------------------------------------------------------------ generation_util.py:121-290
+def _extra(position_ids, segment_ids, step):
+    kw = {}
+    if position_ids is not None:
+        kw["position_ids"] = position_ids[:, step:]
+    if segment_ids is not None:
+        kw["segment_ids"] = segment_ids[:, step:]
+    return kw
+
+
 def beam_search(step_fn: Callable, n_layer: int, input_ids: Tensor, attention_mask: Tensor, beam: int, max_gen_len: int,
                 end_ids: Sequence[int], pad_id: int = 0, early_stop: bool = True, no_repeat_ngram_size: int = 0,
-                length_penalty: float = 1.0) -> Tensor:
+                length_penalty: float = 1.0, position_ids: Optional[Tensor] = None, segment_ids: Optional[Tensor] = None) -> Tensor:
     bsz = input_ids.shape[0]
     max_len = max_gen_len + input_ids.shape[-1]
     ids = input_ids.repeat_interleave(beam, dim=0)
     mask = attention_mask.repeat_interleave(beam, dim=0)
+    pos = None if position_ids is None else position_ids.repeat_interleave(beam, dim=0)
+    seg = None if segment_ids is None else segment_ids.repeat_interleave(beam, dim=0)
     probs = torch.zeros(bsz, beam)
     probs[:, 1:] = -1e9                                                          # :238-239
     infos = [dict(done=False, worst=1e9, cands=[]) for _ in range(bsz)]         # :242
     pasts, step = None, 0
     while True:
         with torch.no_grad():
-            logits, pasts = step_fn(ids[:, step:], mask, pasts)
+            logits, pasts = step_fn(ids[:, step:], mask, pasts, **_extra(pos, seg, step))
         last = logits[:, -1, :]
         if no_repeat_ngram_size > 1:
             last = no_repeat_ngram(ids, last, no_repeat_ngram_size)             # :253-256
@@ -109,6 +120,12 @@ def beam_search(step_fn: Callable, n_layer: int, input_ids: Tensor, attention_ma
         ids = torch.cat([ids[rows], ntok.view(-1, 1)], dim=-1)
         mask = mask[rows]
         mask = torch.cat([mask, mask[:, -1:]], dim=-1)
+        if pos is not None:                                                       # :268-269
+            pos = pos[rows]
+            pos = torch.cat([pos, pos[:, -1:] + 1], dim=-1)
+        if seg is not None:                                                       # :270-271
+            seg = seg[rows]
+            seg = torch.cat([seg, seg[:, -1:]], dim=-1)
         pasts = [tuple(s.index_select(0, rows) for s in layer) for layer in pasts]   # :278-282
         probs = nval
         step = ids.shape[1] - 1
@@ -117,18 +134,24 @@ def beam_search(step_fn: Callable, n_layer: int, input_ids: Tensor, attention_ma
     return ids.view(bsz, beam, -1)
 
 
-def greedy_ngram(step_fn: Callable, input_ids: Tensor, attention_mask: Tensor, max_gen_len: int, n: int) -> Tensor:
+def greedy_ngram(step_fn: Callable, input_ids: Tensor, attention_mask: Tensor, max_gen_len: int, n: int,
+                 position_ids: Optional[Tensor] = None, segment_ids: Optional[Tensor] = None) -> Tensor:
     """generation_util.py:57-119 with do_sample=False, end_ids=None and the n-gram ban (:71-74)."""
     ids, mask = input_ids.clone(), attention_mask.clone()
+    pos, seg = position_ids, segment_ids
     max_len = max_gen_len + ids.shape[-1]
     pasts, step = None, 0
     while True:
         with torch.no_grad():
-            logits, pasts = step_fn(ids[:, step:], mask, pasts)
+            logits, pasts = step_fn(ids[:, step:], mask, pasts, **_extra(pos, seg, step))
         last = logits[:, -1, :]
         if n > 1:
             last = no_repeat_ngram(ids, last, n)
         ids = torch.cat([ids, torch.argmax(last, dim=-1)[:, None]], dim=-1)
+        if pos is not None:
+            pos = torch.cat([pos, (pos.max(dim=-1).values + 1).view(-1, 1)], dim=-1)     # :98
+        if seg is not None:
+            seg = torch.cat([seg, seg[:, -1:]], dim=-1)                                  # :99
         mask = torch.cat([mask, mask[:, -1:]], dim=-1)
         step = ids.shape[1] - 1
         if step > max_len:

@@ -117,14 +117,19 @@ def block(p: Dict[str, Tensor], i: int, x: Tensor, add_mask, s: GPTShape, past=N
 
 
 def gpt_forward(p: Dict[str, Tensor], s: GPTShape, input_ids: Tensor, attention_mask: Tensor, labels: Optional[Tensor] = None,
-                pasts=None):
+                pasts=None, position_ids: Optional[Tensor] = None, segment_ids: Optional[Tensor] = None):
     """modeling_gpt.py:164-193 + 206-214; returns (loss|None, logits, hidden, presents)."""
     S = input_ids.shape[1]
-    pos = attention_mask.long().cumsum(-1) - 1                                              # :166-169
-    pos = pos.masked_fill(attention_mask == 0, 1)[:, -S:]
+    if position_ids is None:
+        pos = attention_mask.long().cumsum(-1) - 1                                          # :166-169
+        pos = pos.masked_fill(attention_mask == 0, 1)[:, -S:]
+    else:
+        pos = position_ids
     am = attention_mask[:, None, None, :].to(torch.float32)
     am = (1.0 - am) * torch.finfo(torch.float32).min                                        # :171-175
     h = p["gpt.tokens_embed.weight"][input_ids] + p["gpt.position_embed.weight"][pos]
+    if segment_ids is not None:
+        h = h + p["gpt.tokens_embed.weight"][segment_ids.view(-1, segment_ids.size(-1))]    # :184 (segments share the token table)
     presents = []
     for i in range(s.n_layer):
         h, pr = block(p, i, h, am, s, None if pasts is None else pasts[i])

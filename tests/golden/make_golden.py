@@ -446,8 +446,18 @@ def gen_decode():
         r = mg.generate(gids, attention_mask=torch.ones(2, 7, dtype=torch.long),
                         generation_configs=dict(beam_size=4, max_gen_len=6, do_sample=False, end_ids=ends, pad_id=3, early_stop=es))
         out[f"gpt_beam4_ends_es{int(es)}"] = npy(r)
+    # explicit position_ids / segment_ids (GPT only: modeling_gpt.py:164,184): both searches carry and extend them (:98-99, :268-271)
+    gpos = torch.tensor([[3, 4, 5, 6, 7, 8, 9], [0, 1, 2, 3, 4, 5, 6]])
+    gseg = torch.tensor([[1, 1, 1, 2, 2, 2, 2], [5, 5, 5, 5, 5, 5, 5]])
+    out["gpt_pos"], out["gpt_seg"] = npy(gpos), npy(gseg)
+    r = mg.generate(gids, attention_mask=torch.ones(2, 7, dtype=torch.long), position_ids=gpos, segment_ids=gseg,
+                    generation_configs=dict(beam_size=1, max_gen_len=6, do_sample=False, end_ids=None, pad_id=3))
+    out["gpt_greedy_posseg"] = npy(r)
+    r = mg.generate(gids, attention_mask=torch.ones(2, 7, dtype=torch.long), position_ids=gpos, segment_ids=gseg,
+                    generation_configs=dict(beam_size=3, max_gen_len=6, do_sample=False, end_ids=[Vg + 1], pad_id=3))
+    out["gpt_beam3_posseg"] = npy(r)
     np.savez_compressed(os.path.join(HERE, "decode.npz"), **out)
-    for k in ("bloom_beam3_free", "bloom_ends", "bloom_beam3_ends_es1", "bloom_beam3_ends_es0", "bloom_greedy_ngram0", "bloom_greedy_ngram2",
+    for k in ("gpt_greedy_posseg", "gpt_beam3_posseg", "bloom_beam3_free", "bloom_ends", "bloom_beam3_ends_es1", "bloom_beam3_ends_es0", "bloom_greedy_ngram0", "bloom_greedy_ngram2",
               "gpt_beam4_free", "gpt_ends", "gpt_beam4_ends_es1"):
         print(k, out[k].tolist())
 

@@ -61,8 +61,8 @@ def _gpt_step():
     s = GR.GPTShape(*GPTS, version="gpt2")
     p = GR.det_init(s)
 
-    def step(ids, mask, pasts):
-        _, logits, _, pasts = GR.gpt_forward(p, s, ids, mask, None, pasts)
+    def step(ids, mask, pasts, position_ids=None, segment_ids=None):
+        _, logits, _, pasts = GR.gpt_forward(p, s, ids, mask, None, pasts, position_ids=position_ids, segment_ids=segment_ids)
         return logits, pasts
     return step
 
@@ -88,6 +88,11 @@ def test_oracle_gpt_beam_search_matches_reference():
     ends = [int(e) for e in DEC["gpt_ends"]]
     for es in (True, False):
         same(D.beam_search(step, 2, ids, am, 4, 6, ends, pad_id=3, early_stop=es), DEC[f"gpt_beam4_ends_es{int(es)}"])
+    # explicit position / segment ids are carried and extended by both searches (generation_util.py:98-99, :268-271)
+    pos, seg = T(DEC["gpt_pos"]), T(DEC["gpt_seg"])
+    same(D.greedy_ngram(step, ids, am, 6, 0, position_ids=pos, segment_ids=seg), DEC["gpt_greedy_posseg"])
+    same(D.beam_search(step, 2, ids, am, 3, 6, [GPTS[0] + 1], pad_id=3, position_ids=pos, segment_ids=seg), DEC["gpt_beam3_posseg"])
+    assert not np.array_equal(DEC["gpt_greedy_posseg"], np.load(os.path.join(G, "tiny_gpt.npz"))["greedy_out"])   # the ids do matter
 
 
 # ------------------------------------------------------------------------------------------------ 2. product host logic
@@ -153,6 +158,13 @@ def test_gpt_beam_search_host_logic_bit_exact(monkeypatch):
     ends = [int(e) for e in DEC["gpt_ends"]]
     for es in (True, False):
         same(gen(end_ids=ends, early_stop=es), DEC[f"gpt_beam4_ends_es{int(es)}"])
+    pos, seg = T(DEC["gpt_pos"]), T(DEC["gpt_seg"])
+    out = m.generate(ids, attention_mask=am, position_ids=pos, segment_ids=seg,
+                     generation_configs=dict(beam_size=1, max_gen_len=6, do_sample=False, end_ids=None, pad_id=3))
+    same(out.numpy(), DEC["gpt_greedy_posseg"])
+    out = m.generate(ids, attention_mask=am, position_ids=pos, segment_ids=seg,
+                     generation_configs=dict(beam_size=3, max_gen_len=6, do_sample=False, end_ids=[GPTS[0] + 1], pad_id=3))
+    same(out.numpy(), DEC["gpt_beam3_posseg"])
 
 
 def test_sampling_paths_host_logic(monkeypatch):

@@ -151,6 +151,13 @@ def test_gpt_beam_search_bit_exact_vs_reference_golden():
     ends = [int(e) for e in DEC["gpt_ends"]]
     for es in (True, False):
         same(gen(end_ids=ends, early_stop=es), DEC[f"gpt_beam4_ends_es{int(es)}"])
+    pos, seg = T(DEC["gpt_pos"]).to(DEV), T(DEC["gpt_seg"]).to(DEV)            # explicit position / segment ids (GPT only)
+    out = m.generate(ids, attention_mask=am, position_ids=pos, segment_ids=seg,
+                     generation_configs=dict(beam_size=1, max_gen_len=6, do_sample=False, end_ids=None, pad_id=3))
+    same(out.cpu().numpy(), DEC["gpt_greedy_posseg"])
+    out = m.generate(ids, attention_mask=am, position_ids=pos, segment_ids=seg,
+                     generation_configs=dict(beam_size=3, max_gen_len=6, do_sample=False, end_ids=[GPTS[0] + 1], pad_id=3))
+    same(out.cpu().numpy(), DEC["gpt_beam3_posseg"])
 
 
 def test_bloom_beam_search_vs_oracle_larger_vocab():
