@@ -48,6 +48,8 @@ PROTOTYPES = {
     "ctmi_embed_bwd": (i32, [vp, vp, vp, i64, i64, i64, i32, f32, vp]),
     "ctmi_ce_fwd": (i32, [vp, i64, vp, vp, vp, vp, i64, i64, i64, i64, i64, i32, i64, i32, vp]),
     "ctmi_ce_bwd": (i32, [vp, i64, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i32, vp]),
+    "ctmi_ce_soft_fwd": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, i64, i32, i64, i32, vp]),
+    "ctmi_ce_soft_bwd": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, vp, i64, i64, i64, i32, vp]),
     "ctmi_adamw_step": (i32, [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64),
                               i32, f32, f32, f32, f32, f32, i32, i32, i32, f32, vp]),
     "ctmi_sgd_step": (i32, [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64),

@@ -819,6 +819,92 @@ extern "C" int ctmi_ce_bwd(const void* logits, int64_t ld, const int64_t* labels
     return CTMI_OK;
 }
 
+// ---- probability targets (the second branch of loss.py:43-46): loss = -sum_{n,c} t[n,c] * log_softmax(x)[n,c]
+//      = sum_n ( lse_n * sum_c t[n,c] - sum_c t[n,c] x[n,c] );   dx[n,c] = (softmax[n,c] * sum_c t[n,c] - t[n,c]) * g / denom.
+// One workgroup per row, fp32 statistics; the row sums of t are kept for the backward.  Not on the SFT path (general widths,
+// scalar loads): the kernels exist so that the module is complete, not to be fast.
+template <typename T>
+__global__ __launch_bounds__(256) void ce_soft_fwd_k(const T* __restrict__ logits, int64_t ld, const float* __restrict__ target, int64_t ldt,
+                                                     float* __restrict__ row_lse, float* __restrict__ row_tsum,
+                                                     float* __restrict__ row_loss, int64_t C) {
+    const int64_t row = blockIdx.x;
+    const T* x = logits + row * ld;
+    const float* t = target + row * ldt;
+    float m = -INFINITY;
+    for (int64_t c = threadIdx.x; c < C; c += 256) m = fmaxf(m, Cvt<T>::to_f(x[c]));
+    __shared__ float red[3][4];
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    __syncthreads();
+    float s = 0.f, ts = 0.f, tx = 0.f;
+    for (int64_t c = threadIdx.x; c < C; c += 256) {
+        const float v = Cvt<T>::to_f(x[c]), tv = t[c];
+        s += expf(v - m); ts += tv; tx += tv * v;
+    }
+    s = wave_sum(s); ts = wave_sum(ts); tx = wave_sum(tx);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = ts; red[2][threadIdx.x >> 6] = tx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float S = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        const float TS = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        const float TX = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+        const float lse = m + logf(S);
+        row_lse[row] = lse; row_tsum[row] = TS; row_loss[row] = lse * TS - TX;
+    }
+}
+// single block: loss_out[0] = sum(row_loss)/denom over ALL rows (a soft-target row loss may be negative), loss_out[1] = 1/denom
+__global__ __launch_bounds__(1024) void ce_soft_finalize_k(const float* __restrict__ row_loss, float* __restrict__ loss_out, int64_t N, double denom) {
+    __shared__ double sm_s[16];
+    double s = 0.0;
+    for (int64_t r = threadIdx.x; r < N; r += 1024) s += (double)row_loss[r];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) sm_s[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double S = 0.0;
+        for (int k = 0; k < 16; ++k) S += sm_s[k];
+        loss_out[0] = (float)(S / denom); loss_out[1] = (float)(1.0 / denom);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void ce_soft_bwd_k(const T* __restrict__ logits, int64_t ld, const float* __restrict__ target, int64_t ldt,
+                                                     const float* __restrict__ row_lse, const float* __restrict__ row_tsum,
+                                                     const float* __restrict__ loss_out, const float* __restrict__ gout,
+                                                     T* __restrict__ dlogits, int64_t ldd, int64_t C) {
+    const int64_t row = blockIdx.x;
+    const float coef = (gout ? gout[0] : 1.0f) * loss_out[1], lse = row_lse[row], ts = row_tsum[row];
+    for (int64_t c = threadIdx.x; c < C; c += 256)
+        dlogits[row * ldd + c] = Cvt<T>::from_f((expf(Cvt<T>::to_f(logits[row * ld + c]) - lse) * ts - target[row * ldt + c]) * coef);
+}
+extern "C" int ctmi_ce_soft_fwd(const void* logits, int64_t ld, const float* target, int64_t ldt, float* row_lse, float* row_tsum,
+                                float* row_loss, float* loss_out, int64_t N, int64_t C, int denom_mode, int64_t denom_rows, int dtype,
+                                void* stream) {
+    CTMI_REQUIRE(logits && target && row_lse && row_tsum && row_loss && loss_out, "ce_soft_fwd: null pointer");
+    CTMI_REQUIRE(N > 0 && C > 0 && ld >= C && ldt >= C && (denom_mode == 1 || denom_mode == 2), "ce_soft_fwd: bad args");
+    hipStream_t st = as_stream(stream);
+    if (dtype == CTMI_F32) hipLaunchKernelGGL((ce_soft_fwd_k<float>), dim3((unsigned)N), dim3(256), 0, st, (const float*)logits, ld, target, ldt, row_lse, row_tsum, row_loss, C);
+    else if (dtype == CTMI_BF16) hipLaunchKernelGGL((ce_soft_fwd_k<bf16_t>), dim3((unsigned)N), dim3(256), 0, st, (const bf16_t*)logits, ld, target, ldt, row_lse, row_tsum, row_loss, C);
+    else { ctmi_set_error("ce_soft_fwd: unsupported dtype %d", dtype); return CTMI_ERR_UNSUPPORTED; }
+    CTMI_CHECK_LAUNCH("ce_soft_fwd");
+    hipLaunchKernelGGL(ce_soft_finalize_k, dim3(1), dim3(1024), 0, st, row_loss, loss_out, N, denom_mode == 1 ? (double)denom_rows : 1.0);
+    CTMI_CHECK_LAUNCH("ce_soft_finalize");
+    return CTMI_OK;
+}
+extern "C" int ctmi_ce_soft_bwd(const void* logits, int64_t ld, const float* target, int64_t ldt, const float* row_lse,
+                                const float* row_tsum, const float* loss_out, const float* gout, void* dlogits, int64_t ldd,
+                                int64_t N, int64_t C, int dtype, void* stream) {
+    CTMI_REQUIRE(logits && target && row_lse && row_tsum && loss_out && dlogits, "ce_soft_bwd: null pointer");
+    CTMI_REQUIRE(N > 0 && C > 0 && ld >= C && ldt >= C && ldd >= C, "ce_soft_bwd: bad shape");
+    hipStream_t st = as_stream(stream);
+    if (dtype == CTMI_F32) hipLaunchKernelGGL((ce_soft_bwd_k<float>), dim3((unsigned)N), dim3(256), 0, st, (const float*)logits, ld, target, ldt, row_lse, row_tsum, loss_out, gout, (float*)dlogits, ldd, C);
+    else if (dtype == CTMI_BF16) hipLaunchKernelGGL((ce_soft_bwd_k<bf16_t>), dim3((unsigned)N), dim3(256), 0, st, (const bf16_t*)logits, ld, target, ldt, row_lse, row_tsum, loss_out, gout, (bf16_t*)dlogits, ldd, C);
+    else { ctmi_set_error("ce_soft_bwd: unsupported dtype %d", dtype); return CTMI_ERR_UNSUPPORTED; }
+    CTMI_CHECK_LAUNCH("ce_soft_bwd");
+    return CTMI_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // fused multi-tensor AdamW / SGD   (optimizer.py:53-97, 12-50; torch.optim.AdamW semantics at ft_bloom.py:70)
 // 28 B/param of HBM traffic (+2 B when the bf16 shadow is written, +4 B when the L2 form writes the grad back).

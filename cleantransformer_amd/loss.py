@@ -37,9 +37,29 @@ class CrossEntropyFn(torch.autograd.Function):
         return d, None, None, None
 
 
+class SoftTargetCrossEntropyFn(torch.autograd.Function):
+    """loss.py:43-46: probability targets [N, C]:  -sum t * log_softmax(x)  (÷ N for 'mean').  The gradient flows to the logits
+    only (targets are data in every caller; the reference's autograd would also produce d/dt = -log_softmax)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, reduction):
+        n, c = logits.shape
+        lg = logits if logits.is_contiguous() else logits.contiguous()
+        tg = target.to(torch.float32)
+        tg = tg if tg.is_contiguous() else tg.contiguous()
+        loss_out, row_lse, row_tsum = ops.ce_soft_fwd(lg, tg, denom_mode=1 if reduction == 'mean' else 2, denom_rows=n)
+        ctx.save_for_backward(lg, tg, row_lse, row_tsum, loss_out)
+        return loss_out[0].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        lg, tg, row_lse, row_tsum, loss_out = ctx.saved_tensors
+        g = gout.to(torch.float32).reshape(1).contiguous()
+        return ops.ce_soft_bwd(lg, tg, row_lse, row_tsum, loss_out, g), None, None
+
+
 class CrossEntropyLoss(torch.nn.Module):
-    """loss.py:29-49.  input [N, C]; target [N] class indices.  (Probability targets [N, C] — the second branch of the
-    reference — are not on the SFT path and are not built; they raise.)"""
+    """loss.py:29-49.  input [N, C]; target [N] class indices, or [N, C] probabilities (the reference's second branch)."""
 
     def __init__(self, reduction='mean', ignore_index=None):
         super().__init__()
@@ -49,6 +69,10 @@ class CrossEntropyLoss(torch.nn.Module):
     def forward(self, input, target):
         if input.dim() != 2:
             raise ValueError("CrossEntropyLoss expects input [N, C] (loss.py:41 gathers along dim 1)")
-        if target.dim() != input.dim() - 1:
-            raise NotImplementedError("probability targets (loss.py:43-46) are not built on the MI355X path")
+        if target.dim() != input.dim() - 1:                  # loss.py:39: anything that is not [N] is taken as probabilities
+            if target.shape != input.shape:
+                raise ValueError("probability targets must have the shape of the input (loss.py:45 multiplies them element-wise)")
+            if self.ignore_index is not None:
+                raise ValueError("ignore_index applies to class-index targets only")
+            return SoftTargetCrossEntropyFn.apply(input, target, self.reduction)
         return CrossEntropyFn.apply(input, target, self.reduction, self.ignore_index)

@@ -285,6 +285,31 @@ def ce_bwd(logits2d: Tensor, labels: Tensor, row_lse: Tensor, loss_out: Tensor, 
     return out
 
 
+def ce_soft_fwd(logits2d: Tensor, target: Tensor, denom_mode: int, denom_rows: int):
+    """probability targets (loss.py:43-46) -> loss_out fp32[2], row_lse fp32[N], row_tsum fp32[N]."""
+    _need_cuda(logits2d, target)
+    N, Cn = logits2d.shape
+    assert target.shape == (N, Cn) and target.dtype == torch.float32 and target.stride(1) == 1 and logits2d.stride(1) == 1
+    dev = logits2d.device
+    row_lse = torch.empty(N, dtype=torch.float32, device=dev)
+    row_tsum = torch.empty(N, dtype=torch.float32, device=dev)
+    row_loss = torch.empty(N, dtype=torch.float32, device=dev)
+    loss_out = torch.empty(2, dtype=torch.float32, device=dev)
+    check(_lib.load().ctmi_ce_soft_fwd(_p(logits2d), logits2d.stride(0), _p(target), target.stride(0), _p(row_lse), _p(row_tsum),
+                                       _p(row_loss), _p(loss_out), N, Cn, denom_mode, denom_rows, dt_code(logits2d.dtype), _stream()),
+          "ce_soft_fwd")
+    return loss_out, row_lse, row_tsum
+
+
+def ce_soft_bwd(logits2d: Tensor, target: Tensor, row_lse: Tensor, row_tsum: Tensor, loss_out: Tensor, gout: Optional[Tensor]) -> Tensor:
+    N, Cn = logits2d.shape
+    out = torch.empty((N, Cn), dtype=logits2d.dtype, device=logits2d.device)
+    check(_lib.load().ctmi_ce_soft_bwd(_p(logits2d), logits2d.stride(0), _p(target), target.stride(0), _p(row_lse), _p(row_tsum),
+                                       _p(loss_out), _p(gout), _p(out), out.stride(0), N, Cn, dt_code(logits2d.dtype), _stream()),
+          "ce_soft_bwd")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ utilities
 def cast(src: Tensor, dtype: torch.dtype, out: Optional[Tensor] = None) -> Tensor:
     _need_cuda(src)

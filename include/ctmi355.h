@@ -130,6 +130,14 @@ int ctmi_ce_bwd(const void* logits, int64_t ld, const int64_t* labels, const flo
                 const float* gout /* device scalar or NULL = 1 */, void* dlogits, int64_t ldd,
                 int64_t N, int64_t C, int64_t seq, int64_t shift, int64_t ignore_index, int dtype, void* stream);
 
+/* probability targets, the second branch of loss.py:43-46: loss = -sum t * log_softmax(x) (÷ denom_rows for 'mean': denom_mode 1;
+ * 'sum': denom_mode 2).  target fp32 [N, C] (ldt).  row_tsum keeps sum_c t[n,c] for the backward:
+ * dlogits = (softmax * row_tsum - target) * gout[0] * loss_out[1]. */
+int ctmi_ce_soft_fwd(const void* logits, int64_t ld, const float* target, int64_t ldt, float* row_lse, float* row_tsum,
+                     float* row_loss, float* loss_out, int64_t N, int64_t C, int denom_mode, int64_t denom_rows, int dtype, void* stream);
+int ctmi_ce_soft_bwd(const void* logits, int64_t ld, const float* target, int64_t ldt, const float* row_lse, const float* row_tsum,
+                     const float* loss_out, const float* gout, void* dlogits, int64_t ldd, int64_t N, int64_t C, int dtype, void* stream);
+
 /* ---- optimizers  (optimizer.py:53-97 AdamW [L2 form]; torch.optim.AdamW as called at ft_bloom.py:70 [decoupled];
  *                   optimizer.py:12-50 SGD)
  * Multi-tensor: `count` tensors described by host arrays of device pointers; one launch per <=CTMI_MT_MAX tensors.

@@ -220,6 +220,20 @@ def argmax_lastdim(x2d):
     return x2d.float().argmax(-1)
 
 
+def ce_soft_fwd(logits2d, target, denom_mode, denom_rows):
+    x = logits2d.float()
+    lse = torch.logsumexp(x, dim=-1)
+    tsum = target.sum(-1)
+    row = lse * tsum - (target * x).sum(-1)
+    denom = float(denom_rows) if denom_mode == 1 else 1.0
+    return torch.stack([row.double().sum() / denom, torch.tensor(1.0 / denom, dtype=torch.float64)]).float(), lse, tsum
+
+
+def ce_soft_bwd(logits2d, target, row_lse, row_tsum, loss_out, gout):
+    coef = (gout[0] if gout is not None else 1.0) * loss_out[1]
+    return ((torch.exp(logits2d.float() - row_lse[:, None]) * row_tsum[:, None] - target) * coef).to(logits2d.dtype)
+
+
 def row_lse(x2d):
     x = x2d.float()
     m = x.max(dim=-1).values
@@ -317,7 +331,7 @@ def install(monkeypatch):
     """Patch cleantransformer_amd.ops in place (pytest's monkeypatch undoes it after the test)."""
     from cleantransformer_amd import ops
     for name in ("layernorm_fwd", "layernorm_bwd", "gemm", "colsum", "MaskInfo", "attn_fwd", "attn_bwd", "embed_fwd", "embed_bwd",
-                 "ce_fwd", "ce_bwd", "cast", "transpose_cast", "sumsq", "scale_", "argmax_lastdim", "row_lse", "group_topk",
+                 "ce_fwd", "ce_bwd", "ce_soft_fwd", "ce_soft_bwd", "cast", "transpose_cast", "sumsq", "scale_", "argmax_lastdim", "row_lse", "group_topk",
                  "scores_filter", "amp_unscale", "amp_update", "adamw_step", "sgd_step"):
         monkeypatch.setattr(ops, name, globals()[name])
     monkeypatch.setattr(ops, "_need_cuda", lambda *a: None)

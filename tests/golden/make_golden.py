@@ -372,6 +372,30 @@ def gen_gpt():
 
 
 # ---------------------------------------------------------------------------------------
+def gen_soft_ce():
+    """Probability-target branch of the reference's CrossEntropyLoss (loss.py:43-46): losses and input gradients for normalised and
+    un-normalised targets, both reductions, plus the inputs of the reference's own printed self-check (seed 999, loss.py:76-91)."""
+    g = torch.Generator().manual_seed(41)
+    out = {}
+    x = torch.randn(7, 37, generator=g) * 2
+    tn = torch.softmax(torch.randn(7, 37, generator=g), dim=-1)
+    tu = torch.rand(7, 37, generator=g)
+    out.update(x=npy(x), t_norm=npy(tn), t_raw=npy(tu))
+    for name, t in (("norm", tn), ("raw", tu)):
+        for red in ("mean", "sum"):
+            xi = x.clone().requires_grad_(True)
+            loss = ref_loss.CrossEntropyLoss(red)(xi, t)
+            loss.backward()
+            out[f"loss_{name}_{red}"] = npy(loss)
+            out[f"dx_{name}_{red}"] = npy(xi.grad)
+    torch.manual_seed(999)
+    pred, gtp = torch.rand(3, 4), torch.rand(3, 4)
+    out.update(known_pred=npy(pred), known_t=npy(gtp), known_loss=npy(ref_loss.CrossEntropyLoss('mean')(pred, gtp)))
+    np.savez_compressed(os.path.join(HERE, "soft_ce.npz"), **out)
+    print("soft_ce:", {k: float(v) for k, v in out.items() if k.startswith("loss") or k == "known_loss"})
+
+
+# ---------------------------------------------------------------------------------------
 def gen_decode():
     """SURVEY §8(f)3 — the rest of the decode path: beam search (generation_util.py:121-290, do_sample=False so that token ids
     are deterministic), greedy with the n-gram ban, and the four logits processors (logits_processor.py) on seeded scores."""
@@ -522,7 +546,7 @@ def gen_known():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["ops", "tiny", "c1", "c5", "gpt", "decode", "ddp", "known"]
+    which = sys.argv[1:] or ["ops", "tiny", "c1", "c5", "gpt", "soft_ce", "decode", "ddp", "known"]
     if "ops" in which:
         gen_ops()
     if "tiny" in which:
@@ -533,6 +557,8 @@ if __name__ == "__main__":
         gen_c5()
     if "gpt" in which:
         gen_gpt()
+    if "soft_ce" in which:
+        gen_soft_ce()
     if "decode" in which:
         gen_decode()
     if "ddp" in which:

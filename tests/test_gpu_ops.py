@@ -543,3 +543,42 @@ def test_gemm_every_tile_schedule_and_policy(env):
                        env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.parametrize("dtype,rtol,atol", [(torch.float32, 1e-5, 1e-6), (torch.bfloat16, 2e-2, 2e-3)])
+def test_soft_target_cross_entropy_vs_reference_golden(dtype, rtol, atol):
+    """Probability-target branch of CrossEntropyLoss (loss.py:43-46) through ctmi_ce_soft_fwd/bwd: the reference's own losses and
+    input gradients (tests/golden/soft_ce.npz), both reductions, normalised and raw targets, its printed self-check value, and a
+    wide row (C = 50257) against the oracle."""
+    from cleantransformer_amd.loss import CrossEntropyLoss
+    from oracle import bloom_ref as R
+    SC = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "soft_ce.npz"))
+    x = torch.from_numpy(SC["x"])
+    for name in ("norm", "raw"):
+        t = torch.from_numpy(SC[f"t_{name}"]).to(DEV)
+        for red in ("mean", "sum"):
+            xi = x.to(dtype).to(DEV).requires_grad_(True)
+            loss = CrossEntropyLoss(red)(xi, t)
+            (loss * 3.0).backward()
+            ref_l, ref_g = float(SC[f"loss_{name}_{red}"]), torch.from_numpy(SC[f"dx_{name}_{red}"])
+            if dtype == torch.bfloat16:                                    # the kernel sees bf16-rounded logits: compare with the oracle on those
+                xr = x.to(dtype).float().requires_grad_(True)
+                lr = R.cross_entropy_repo(xr, t.cpu(), red)
+                lr.backward()
+                ref_l, ref_g = float(lr), xr.grad
+            assert abs(float(loss) - ref_l) <= 1e-5 * abs(ref_l) + 1e-6, (name, red, float(loss), ref_l)
+            check(f"soft_ce.dx[{name},{red}]", xi.grad.float() / 3.0, ref_g, rtol, atol)
+    if dtype == torch.float32:
+        k = CrossEntropyLoss('mean')(torch.from_numpy(SC["known_pred"]).to(DEV), torch.from_numpy(SC["known_t"]).to(DEV))
+        assert abs(float(k) - 3.14231014) < 1e-6
+    g = torch.Generator().manual_seed(8)
+    xw = (torch.randn(5, 50257, generator=g) * 3).to(dtype)
+    tw = torch.softmax(torch.randn(5, 50257, generator=g) * 2, dim=-1)
+    xi = xw.to(DEV).requires_grad_(True)
+    loss = CrossEntropyLoss('mean')(xi, tw.to(DEV))
+    loss.backward()
+    xr = xw.double().requires_grad_(True)
+    lr = -(tw.double() * torch.log_softmax(xr, -1)).sum() / 5
+    lr.backward()
+    assert abs(float(loss) - float(lr)) <= 2e-6 * float(lr)
+    check("soft_ce.wide.dx", xi.grad.float(), xr.grad.float(), rtol, max(atol * 1e-3, 1e-9) if dtype == torch.float32 else 1e-6)
