@@ -569,12 +569,78 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
             // per-lane element offset of (row lane>>3, column chunk lane&7) of the wave tile; rows advance by 8 * ldc
             const int64_t off0 = (mw + (lane >> 3)) * g.ldc + nw + (lane & 7) * 8;
             const int64_t row8 = 8 * g.ldc;
+            // One 16-byte row piece (8 consecutive columns in v[]) through the epilogue proper: activation (+ pre-activation out) or
+            // activation derivative, residual, beta, conversion and the store.  Shared by both re-layouts below; always inlined
+            // (v[] lives in registers).
+            auto finish = [&](auto plain_c, auto nt_flag, float (&v)[8], const int64_t off, const uint4& pre_it) __attribute__((always_inline)) {
+                constexpr bool PLAIN = decltype(plain_c)::value;            // no inline residual load, no beta
+                constexpr bool NT = decltype(nt_flag)::value;
+                if (EPI == CTMI_EPI_GELU) {
+                    const uint4 tb = pack16<T>(v);
+                    *reinterpret_cast<uint4*>(AUXO + off) = tb;
+                    unpack16<T>(tb, v);
+#pragma unroll
+                    for (int r = 0; r < 8; r += 2) { const f32x2 y = gelu_tanh_pk(f32x2{v[r], v[r + 1]}); v[r] = y[0]; v[r + 1] = y[1]; }
+                } else if (EPI == CTMI_EPI_RELU) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+                } else if (EPI == CTMI_EPI_DGELU || EPI == CTMI_EPI_DRELU) {
+                    float u[8];
+                    if constexpr (PRE_AUX) unpack16<T>(pre_it, u);
+                    else unpack16<T>(*reinterpret_cast<const uint4*>(AUXI + off), u);
+                    if (EPI == CTMI_EPI_DGELU) {
+#pragma unroll
+                        for (int r = 0; r < 8; r += 2) { const f32x2 y = f32x2{v[r], v[r + 1]} * gelu_tanh_grad_pk(f32x2{u[r], u[r + 1]}); v[r] = y[0]; v[r + 1] = y[1]; }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] = u[r] > 0.f ? v[r] : 0.f;
+                    }
+                }
+                if constexpr (PRE_RES) {
+                    float u[8];
+                    unpack16<T>(pre_it, u);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] += u[r];
+                } else if constexpr (!PLAIN) {
+                    if (R != nullptr) {
+                        float u[8];
+                        unpack16<T>(*reinterpret_cast<const uint4*>(R + off), u);
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] += u[r];
+                    }
+                }
+                if constexpr (sizeof(TO) == 4) {
+                    float* Cf = reinterpret_cast<float*>(C) + off;
+                    if constexpr (!PLAIN) {
+                        if (g.beta) {
+                            const f32x4 c0v = *reinterpret_cast<const f32x4*>(Cf), c1v = *reinterpret_cast<const f32x4*>(Cf + 4);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { v[r] += c0v[r]; v[4 + r] += c1v[r]; }
+                        }
+                    }
+                    *reinterpret_cast<f32x4*>(Cf) = f32x4{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(Cf + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                } else {
+                    if constexpr (!PLAIN) {
+                        if (g.beta) {
+                            float u[8];
+                            unpack16<T>(*reinterpret_cast<const uint4*>(C + off), u);
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) v[r] += u[r];
+                        }
+                    }
+                    const uint4 pk = pack16<T>(v);
+                    // logits-sized outputs (>> the 256 MiB Infinity Cache) are written non-temporally so they do
+                    // not push the operand panels out of L2 (asm: hipcc would merge a plain and a nontemporal store
+                    // to one address into one plain store)
+                    if (NT && g.nt_c) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(C + off), "v"(__builtin_bit_cast(u32x4, pk)) : "memory");
+                    else *reinterpret_cast<uint4*>(C + off) = pk;
+                }
+            };
             // The runtime-uniform switches (residual / beta / non-temporal) are lifted OUT of the unrolled body into
             // compile-time variants: as branches inside it they cut every 8-row step into its own basic block, so hipcc
             // could not batch the LDS reads and each step exposed an LDS round trip plus a 64-bit multiply for its address.
             auto shuffle = [&](auto plain_c, auto nt_flag) {
-                constexpr bool PLAIN = decltype(plain_c)::value;            // no inline residual load, no beta
-                constexpr bool NT = decltype(nt_flag)::value;
                 uint4 pre[2][PRE ? 4 : 1];
                 auto prefetch = [&](int p, int slot) {
                     if constexpr (PRE) {
@@ -611,67 +677,7 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
                         const int it = ib + k;
                         float v[8] = {lo[k][0], lo[k][1], lo[k][2], lo[k][3], hi[k][0], hi[k][1], hi[k][2], hi[k][3]};
                         const int64_t off = off0 + (p * 4 + it) * row8;
-                        if (EPI == CTMI_EPI_GELU) {
-                            const uint4 tb = pack16<T>(v);
-                            *reinterpret_cast<uint4*>(AUXO + off) = tb;
-                            unpack16<T>(tb, v);
-#pragma unroll
-                            for (int r = 0; r < 8; r += 2) { const f32x2 y = gelu_tanh_pk(f32x2{v[r], v[r + 1]}); v[r] = y[0]; v[r + 1] = y[1]; }
-                        } else if (EPI == CTMI_EPI_RELU) {
-#pragma unroll
-                            for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
-                        } else if (EPI == CTMI_EPI_DGELU || EPI == CTMI_EPI_DRELU) {
-                            float u[8];
-                            if constexpr (PRE_AUX) unpack16<T>(pre[p & 1][it], u);
-                            else unpack16<T>(*reinterpret_cast<const uint4*>(AUXI + off), u);
-                            if (EPI == CTMI_EPI_DGELU) {
-#pragma unroll
-                                for (int r = 0; r < 8; r += 2) { const f32x2 y = f32x2{v[r], v[r + 1]} * gelu_tanh_grad_pk(f32x2{u[r], u[r + 1]}); v[r] = y[0]; v[r + 1] = y[1]; }
-                            } else {
-#pragma unroll
-                                for (int r = 0; r < 8; ++r) v[r] = u[r] > 0.f ? v[r] : 0.f;
-                            }
-                        }
-                        if constexpr (PRE_RES) {
-                            float u[8];
-                            unpack16<T>(pre[p & 1][it], u);
-#pragma unroll
-                            for (int r = 0; r < 8; ++r) v[r] += u[r];
-                        } else if constexpr (!PLAIN) {
-                            if (R != nullptr) {
-                                float u[8];
-                                unpack16<T>(*reinterpret_cast<const uint4*>(R + off), u);
-#pragma unroll
-                                for (int r = 0; r < 8; ++r) v[r] += u[r];
-                            }
-                        }
-                        if constexpr (sizeof(TO) == 4) {
-                            float* Cf = reinterpret_cast<float*>(C) + off;
-                            if constexpr (!PLAIN) {
-                                if (g.beta) {
-                                    const f32x4 c0v = *reinterpret_cast<const f32x4*>(Cf), c1v = *reinterpret_cast<const f32x4*>(Cf + 4);
-#pragma unroll
-                                    for (int r = 0; r < 4; ++r) { v[r] += c0v[r]; v[4 + r] += c1v[r]; }
-                                }
-                            }
-                            *reinterpret_cast<f32x4*>(Cf) = f32x4{v[0], v[1], v[2], v[3]};
-                            *reinterpret_cast<f32x4*>(Cf + 4) = f32x4{v[4], v[5], v[6], v[7]};
-                        } else {
-                            if constexpr (!PLAIN) {
-                                if (g.beta) {
-                                    float u[8];
-                                    unpack16<T>(*reinterpret_cast<const uint4*>(C + off), u);
-#pragma unroll
-                                    for (int r = 0; r < 8; ++r) v[r] += u[r];
-                                }
-                            }
-                            const uint4 pk = pack16<T>(v);
-                            // logits-sized outputs (>> the 256 MiB Infinity Cache) are written non-temporally so they do
-                            // not push the operand panels out of L2 (asm: hipcc would merge a plain and a nontemporal store
-                            // to one address into one plain store)
-                            if (NT && g.nt_c) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(C + off), "v"(__builtin_bit_cast(u32x4, pk)) : "memory");
-                            else *reinterpret_cast<uint4*>(C + off) = pk;
-                        }
+                        finish(plain_c, nt_flag, v, off, pre[p & 1][PRE ? it : 0]);
                     }
                     }
                     __builtin_amdgcn_sched_barrier(0);                         // one pass at a time: keeps the live set at acc + one pass
@@ -683,8 +689,6 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
             // — 16-byte bf16 stores / side-input loads, 64 contiguous bytes per row and instruction, with no LDS round
             // trip (4 swaps per 8 values instead of 2 ds_write_b128 + 2 ds_read_b128 and their waits).
             auto direct = [&](auto plain_c, auto nt_flag) {
-                constexpr bool PLAIN = decltype(plain_c)::value;
-                constexpr bool NT = decltype(nt_flag)::value;
                 const int q = lane >> 4;
                 const int64_t offL = (mw + (lane & 15)) * g.ldc + nw + 16 * (q & 1) + 8 * (q >> 1);
                 const int64_t row16 = 16 * g.ldc;
@@ -716,64 +720,7 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
                                      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
                         float v[8] = {a0, a1, a2, a3, b0, b1, b2, b3};
                         const int64_t off = offL + i * row16 + 32 * jp;
-                        if (EPI == CTMI_EPI_GELU) {
-                            const uint4 tb = pack16<T>(v);
-                            *reinterpret_cast<uint4*>(AUXO + off) = tb;
-                            unpack16<T>(tb, v);
-#pragma unroll
-                            for (int r = 0; r < 8; r += 2) { const f32x2 y = gelu_tanh_pk(f32x2{v[r], v[r + 1]}); v[r] = y[0]; v[r + 1] = y[1]; }
-                        } else if (EPI == CTMI_EPI_RELU) {
-#pragma unroll
-                            for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
-                        } else if (EPI == CTMI_EPI_DGELU || EPI == CTMI_EPI_DRELU) {
-                            float u[8];
-                            if constexpr (PRE_AUX) unpack16<T>(pre[p & 1][it], u);
-                            else unpack16<T>(*reinterpret_cast<const uint4*>(AUXI + off), u);
-                            if (EPI == CTMI_EPI_DGELU) {
-#pragma unroll
-                                for (int r = 0; r < 8; r += 2) { const f32x2 y = f32x2{v[r], v[r + 1]} * gelu_tanh_grad_pk(f32x2{u[r], u[r + 1]}); v[r] = y[0]; v[r + 1] = y[1]; }
-                            } else {
-#pragma unroll
-                                for (int r = 0; r < 8; ++r) v[r] = u[r] > 0.f ? v[r] : 0.f;
-                            }
-                        }
-                        if constexpr (PRE_RES) {
-                            float u[8];
-                            unpack16<T>(pre[p & 1][it], u);
-#pragma unroll
-                            for (int r = 0; r < 8; ++r) v[r] += u[r];
-                        } else if constexpr (!PLAIN) {
-                            if (R != nullptr) {
-                                float u[8];
-                                unpack16<T>(*reinterpret_cast<const uint4*>(R + off), u);
-#pragma unroll
-                                for (int r = 0; r < 8; ++r) v[r] += u[r];
-                            }
-                        }
-                        if constexpr (sizeof(TO) == 4) {
-                            float* Cf = reinterpret_cast<float*>(C) + off;
-                            if constexpr (!PLAIN) {
-                                if (g.beta) {
-                                    const f32x4 c0v = *reinterpret_cast<const f32x4*>(Cf), c1v = *reinterpret_cast<const f32x4*>(Cf + 4);
-#pragma unroll
-                                    for (int r = 0; r < 4; ++r) { v[r] += c0v[r]; v[4 + r] += c1v[r]; }
-                                }
-                            }
-                            *reinterpret_cast<f32x4*>(Cf) = f32x4{v[0], v[1], v[2], v[3]};
-                            *reinterpret_cast<f32x4*>(Cf + 4) = f32x4{v[4], v[5], v[6], v[7]};
-                        } else {
-                            if constexpr (!PLAIN) {
-                                if (g.beta) {
-                                    float u[8];
-                                    unpack16<T>(*reinterpret_cast<const uint4*>(C + off), u);
-#pragma unroll
-                                    for (int r = 0; r < 8; ++r) v[r] += u[r];
-                                }
-                            }
-                            const uint4 pk = pack16<T>(v);
-                            if (NT && g.nt_c) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(C + off), "v"(__builtin_bit_cast(u32x4, pk)) : "memory");
-                            else *reinterpret_cast<uint4*>(C + off) = pk;
-                        }
+                        finish(plain_c, nt_flag, v, off, pre[p & 1][PRE ? it : 0]);
                     }
                     __builtin_amdgcn_sched_barrier(0);                         // one pass at a time: keeps the live set at acc + one pass
                 }
