@@ -60,4 +60,11 @@ traffic = {
             "(private 4 MiB L2) streams the weight panel for each group of 4 tile rows; they are served by the 256 MiB Infinity Cache.",
 }
 json.dump(traffic, open(os.path.join(dst, f"{rnd}_lmhead_traffic.json"), "w"), indent=1)
+# the plain result files of the collection travel as they are
+import shutil
+for name in (f"{rnd}_bench_default.json", f"{rnd}_bench_under_rocprof.json", f"{rnd}_bench_1stream_under_rocprof.json",
+             f"{rnd}_microbench.txt", f"{rnd}_gemm_tile_sweep.txt"):
+    if os.path.exists(os.path.join(src, name)):
+        shutil.copy(os.path.join(src, name), os.path.join(dst, name))
+shutil.copy(one("prof_bench/*/*_kernel_stats.csv"), os.path.join(dst, f"{rnd}_bench_kernel_stats.csv"))
 print("LM-head fwd avg ms: side-stream run %.4f, single-stream run %.4f; traffic %.2f GB/launch" % (a, b, traffic["traffic_bytes_per_launch"] / 1e9))
