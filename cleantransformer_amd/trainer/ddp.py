@@ -32,7 +32,7 @@ _MiB = 1024 * 1024
 
 
 class _Bucket:
-    __slots__ = ("params", "offsets", "numel", "flat", "pending", "work", "index")
+    __slots__ = ("params", "offsets", "numel", "flat", "comm", "pending", "work", "index")
 
     def __init__(self, index: int, params: List[torch.nn.Parameter]):
         self.index = index
@@ -44,6 +44,7 @@ class _Bucket:
             off += p.numel()
         self.numel = off
         self.flat: Optional[torch.Tensor] = None
+        self.comm: Optional[torch.Tensor] = None                 # bf16 wire copy (comm_dtype=torch.bfloat16 only)
         self.pending = 0
         self.work = None
 
@@ -128,8 +129,17 @@ def build_buckets(params: List[torch.nn.Parameter], bucket_cap_bytes: int, first
 class DistributedDataParallel(torch.nn.Module):
     def __init__(self, module: torch.nn.Module, device_ids=None, output_device=None, dim=0, broadcast_buffers=True,
                  process_group=None, bucket_cap_mb=None, find_unused_parameters=False, check_reduction=False,
-                 gradient_as_bucket_view=False, static_graph=False, **kwargs):
+                 gradient_as_bucket_view=False, static_graph=False, comm_dtype=None, **kwargs):
         super().__init__()
+        # comm_dtype=torch.bfloat16 (or CTMI_DDP_COMM_DTYPE=bf16): buckets travel as bf16 — half the xGMI bytes of the fp32
+        # default — and are widened back into the fp32 bucket the gradients view ("O2"-style bf16 gradient communication,
+        # SURVEY §8(f)2).  Opt-in: the averaged gradients then carry bf16 rounding (~2^-9 relative), outside the 1e-4 parity
+        # bar of the default path.  The tied [V,H] gradient's early reduction stays fp32.
+        if comm_dtype is None and os.environ.get("CTMI_DDP_COMM_DTYPE", "").lower() in ("bf16", "bfloat16"):
+            comm_dtype = torch.bfloat16
+        if comm_dtype not in (None, torch.float32, torch.bfloat16):
+            raise ValueError("comm_dtype must be None / torch.float32 / torch.bfloat16")
+        self.comm_dtype = None if comm_dtype == torch.float32 else comm_dtype
         if not dist.is_available() or not dist.is_initialized():
             raise RuntimeError("DistributedDataParallel needs torch.distributed.init_process_group(...) first "
                                "(examples/ft_bloom_DDP.py:183 does init_process_group('nccl'), i.e. RCCL on ROCm)")
@@ -232,7 +242,13 @@ class DistributedDataParallel(torch.nn.Module):
             self._launch(b)
 
     def _launch(self, b: _Bucket):
-        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
+        wire = b.flat
+        if self.comm_dtype is not None:
+            if b.comm is None or b.comm.device != b.flat.device:
+                b.comm = torch.empty(b.numel, dtype=self.comm_dtype, device=b.flat.device)
+            _cast(b.flat, b.comm)                                   # one pass per bucket; the collective is enqueued behind it
+            wire = b.comm
+        b.work = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
 
     def _finalize_backward(self):
         self._callback_queued = False
@@ -244,6 +260,8 @@ class DistributedDataParallel(torch.nn.Module):
             if b.work is None:                                      # the tied parameter's bucket in a step that reduced it early
                 continue
             b.work.wait()                                           # compute stream waits on the RCCL stream; host does not block
+            if self.comm_dtype is not None:
+                _cast(b.comm, b.flat)                               # widen the reduced wire copy back into the fp32 bucket
             for p, off in zip(b.params, b.offsets):
                 # the averaged gradient IS the bucket slot from here on: no copy back (a dense, sliceable [shape] fp32
                 # view — what lm_head.weight.grad[100:110, 100:110], ft_bloom_DDP.py:148, needs)
@@ -270,6 +288,14 @@ class DistributedDataParallel(torch.nn.Module):
 def _embed_scatter(rows: torch.Tensor, ids: torch.Tensor, dtable: torch.Tensor, s: float) -> None:
     from .. import ops
     ops.embed_bwd(rows, ids, dtable, s)                             # (the CPU/gloo semantics tests patch ops.* with emulations)
+
+
+def _cast(src: torch.Tensor, dst: torch.Tensor) -> None:
+    if src.is_cuda:
+        from .. import ops
+        ops.cast(src, dst.dtype, out=dst)
+    else:                                                           # gloo / CPU: semantics tests only
+        dst.copy_(src)
 
 
 def _scale_copy(src: torch.Tensor, dst: torch.Tensor, s: float) -> None:
