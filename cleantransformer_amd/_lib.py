@@ -15,7 +15,7 @@ from ._build import LIB_PATH
 F32, BF16 = 0, 1
 EPI_NONE, EPI_GELU, EPI_DGELU, EPI_RELU, EPI_DRELU = 0, 1, 2, 3, 4
 MT_MAX = 24
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 
@@ -29,6 +29,27 @@ class AttnDesc(C.Structure):
                                    "q_bs", "q_hs", "q_rs", "k_bs", "k_hs", "k_rs",
                                    "v_bs", "v_hs", "v_rs", "o_bs", "o_hs", "o_rs",
                                    "am_b", "am_h", "am_q", "am_k")] + [("scale", f32), ("causal", i32)]
+
+
+class ReduceJob(C.Structure):
+    _fields_ = [("src", vp), ("dst", vp), ("n", i64), ("part_stride", i64), ("nparts", i32), ("accumulate", i32), ("alpha", f32), ("pad_", i32)]
+
+
+BLK_SLOTS = ("ln1", "mean1", "rstd1", "qkv", "att", "stat_m", "stat_l", "h1", "mean2", "rstd2", "ln2", "u", "g", "out")
+BLK_PARAMS = ("ln1_w", "ln1_b", "wqkv", "bqkv", "wd", "bd", "ln2_w", "ln2_b", "w1", "b1", "w2", "b2")
+
+
+class BloomBlock(C.Structure):
+    """ctmi_bloom_block (include/ctmi355.h)."""
+    _fields_ = [("B", i64), ("S", i64), ("H", i64), ("nh", i64), ("eps", f32), ("post_ln_res", i32), ("dtype", i32), ("pad_", i32)] + \
+               [(n, vp) for n in BLK_PARAMS] + [(n, vp) for n in ("slopes", "kpos", "kvalid", "first_valid", "x", "slab")]
+
+
+class BloomBlockGrads(C.Structure):
+    """ctmi_bloom_block_grads (include/ctmi355.h)."""
+    _fields_ = [("dout", vp), ("dx", vp)] + [("d" + n, vp) for n in BLK_PARAMS] + \
+               [("ws", vp), ("ws_bytes", i64), ("splitk_ws", vp), ("splitk_ws_bytes", i64), ("side_stream", vp),
+                ("side_splitk_ws", vp), ("side_splitk_ws_bytes", i64)]
 
 
 # name -> (restype, argtypes); must mirror include/ctmi355.h exactly (checked by tests/test_abi.py)
@@ -48,6 +69,13 @@ PROTOTYPES = {
     "ctmi_embed_bwd": (i32, [vp, vp, vp, i64, i64, i64, i32, f32, vp]),
     "ctmi_ce_fwd": (i32, [vp, i64, vp, vp, vp, vp, i64, i64, i64, i64, i64, i32, i64, i32, vp]),
     "ctmi_ce_bwd": (i32, [vp, i64, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i32, vp]),
+    "ctmi_ce_fwd_bwd": (i32, [vp, i64, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i32, i64, i32, vp]),
+    "ctmi_scale_if": (i32, [vp, i64, i64, i64, vp, i32, vp]),
+    "ctmi_reduce_jobs": (i32, [C.POINTER(ReduceJob), i32, vp]),
+    "ctmi_bloom_block_layout": (i64, [i64, i64, i64, i64, i32, C.POINTER(i64)]),
+    "ctmi_bloom_block_fwd": (i32, [C.POINTER(BloomBlock), vp]),
+    "ctmi_bloom_block_bwd_ws": (i64, [i64, i64, i64, i64, i32]),
+    "ctmi_bloom_block_bwd": (i32, [C.POINTER(BloomBlock), C.POINTER(BloomBlockGrads), vp]),
     "ctmi_ce_soft_fwd": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, i64, i32, i64, i32, vp]),
     "ctmi_ce_soft_bwd": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, vp, i64, i64, i64, i32, vp]),
     "ctmi_adamw_step": (i32, [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64),

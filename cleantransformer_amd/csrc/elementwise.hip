@@ -131,13 +131,21 @@ extern "C" int ctmi_layernorm_fwd(const void* x, const float* w, const float* b,
 // waves per workgroup in ln_bwd_vec: 8 for rows up to 64*VEC*2 elements, fewer for wider rows so the per-wave dw/db partials
 // ([waves][2][cols] fp32 in LDS) stay within 64 KiB
 static constexpr int lnb_waves(int maxv) { return maxv <= 2 ? 8 : (16 / maxv); }
-template <typename T, int MAXV>
+// NS = 2: partial rows {dw, db};  NS = 4: additionally {colsum(dres), colsum(dx)} — the bias gradients of the two Linear layers
+// whose output gradients this kernel already reads (dres) and writes (dx), so no separate column-sum pass over them exists.
+template <typename T, int MAXV, int NS = 2>
 __global__ __launch_bounds__(64 * lnb_waves(MAXV)) void ln_bwd_vec(const T* __restrict__ dy, const T* __restrict__ x,
                                                   const float* __restrict__ w, const float* __restrict__ mean_i,
                                                   const float* __restrict__ rstd_i, const T* __restrict__ dres,
                                                   T* __restrict__ dx, float* __restrict__ ws, int64_t rows, int cols) {
     constexpr int VEC = 16 / sizeof(T);
     constexpr int LNB_WAVES = lnb_waves(MAXV);
+    constexpr int NX = NS == 4 ? MAXV : 1;                             // extra accumulators exist only for NS = 4
+    float ar[NX][VEC], ax[NX][VEC];
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { ar[i][j] = 0.f; ax[i][j] = 0.f; }
     extern __shared__ __attribute__((aligned(16))) float lds[];      // [LNB_WAVES][2][cols]
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int64_t wave0 = (int64_t)blockIdx.x * LNB_WAVES + wid;
@@ -200,32 +208,43 @@ __global__ __launch_bounds__(64 * lnb_waves(MAXV)) void ln_bwd_vec(const T* __re
                     float r[VEC];
                     unpack16<T>(rraw[i], r);
 #pragma unroll
-                    for (int j = 0; j < VEC; ++j) o[j] += r[j];
+                    for (int j = 0; j < VEC; ++j) { o[j] += r[j]; if (NS == 4) ar[NS == 4 ? i : 0][j] += r[j]; }
                 }
-                *reinterpret_cast<uint4*>(dxr + c) = pack16<T>(o);
+                const uint4 pk = pack16<T>(o);
+                *reinterpret_cast<uint4*>(dxr + c) = pk;
+                if (NS == 4) {                                           // column sums of dx as STORED (what the weight-gradient GEMM reads)
+                    float orr[VEC];
+                    unpack16<T>(pk, orr);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) ax[NS == 4 ? i : 0][j] += orr[j];
+                }
             }
         }
     }
-    // block combine
+    // block combine, two partial rows per pass through the [LNB_WAVES][2][cols] LDS patch
+    float* out = ws + (int64_t)blockIdx.x * NS * cols;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c = (i * 64 + lane) * VEC;
-        if (c < cols) {
+    for (int pass = 0; pass < NS / 2; ++pass) {
+        if (pass) __syncthreads();
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                lds[(wid * 2 + 0) * cols + c + j] = aw[i][j];
-                lds[(wid * 2 + 1) * cols + c + j] = ab[i][j];
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = (i * 64 + lane) * VEC;
+            if (c < cols) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    lds[(wid * 2 + 0) * cols + c + j] = pass == 0 ? aw[i][j] : ar[NS == 4 ? i : 0][j];
+                    lds[(wid * 2 + 1) * cols + c + j] = pass == 0 ? ab[i][j] : ax[NS == 4 ? i : 0][j];
+                }
             }
         }
-    }
-    __syncthreads();
-    float* out = ws + (int64_t)blockIdx.x * 2 * cols;
-    for (int c = threadIdx.x; c < 2 * cols; c += 64 * LNB_WAVES) {
-        const int which = c / cols, cc = c - which * cols;
-        float t = 0.f;
+        __syncthreads();
+        for (int c = threadIdx.x; c < 2 * cols; c += 64 * LNB_WAVES) {
+            const int which = c / cols, cc = c - which * cols;
+            float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < LNB_WAVES; ++k) t += lds[(k * 2 + which) * cols + cc];
-        out[c] = t;
+            for (int k = 0; k < LNB_WAVES; ++k) t += lds[(k * 2 + which) * cols + cc];
+            out[pass * 2 * cols + c] = t;
+        }
     }
 }
 
@@ -406,17 +425,20 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce4(const float* __restrict__ 
 static const int LN_BWD_MAX_BLOCKS = 512;
 extern "C" int64_t ctmi_layernorm_bwd_ws(int64_t rows, int64_t cols) {
     (void)rows;
-    return (int64_t)LN_BWD_MAX_BLOCKS * 2 * cols;
+    return (int64_t)LN_BWD_MAX_BLOCKS * 4 * cols;          // up to 4 partial rows per block (dw, db, colsum(dres), colsum(dx))
 }
 
+// Main pass only: dx (+ dres) and the per-block partial rows ws[part][NS][cols] (NS = 2: dw, db; NS = 4: + colsum(dres),
+// colsum(dx) when `want_sums` and the row width has the vector kernel).  The caller reduces the partial rows
+// (ln_bwd_reduce* below, or one ctmi_reduce_jobs launch for a whole transformer block).
 template <typename T>
-static int ln_bwd_launch(const void* dy, const void* x, const float* w, const float* mean, const float* rstd,
-                         const void* dres, void* dx, float* dw, float* db, int accumulate, float* ws,
-                         int64_t rows, int64_t cols, hipStream_t st) {
+static int ln_bwd_parts(const void* dy, const void* x, const float* w, const float* mean, const float* rstd,
+                        const void* dres, void* dx, float* ws, int64_t rows, int64_t cols, int want_sums,
+                        int* nparts_out, int* ns_out, hipStream_t st) {
     constexpr int VEC = 16 / sizeof(T);
     const bool vec_ok = (cols % VEC == 0) && aligned16(x) && aligned16(dy) && aligned16(dx) &&
                         (dres == nullptr || aligned16(dres)) && cols <= 8LL * 64 * VEC;
-    int nparts;
+    int nparts, ns = 2;
     if (vec_ok) {
         const int mv = cols <= 64 * VEC ? 1 : (cols <= 2 * 64 * VEC ? 2 : (cols <= 4 * 64 * VEC ? 4 : 8));
         const int nw = lnb_waves(mv);
@@ -428,11 +450,13 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* w, const fl
         }
         nparts = grid;
         size_t lds = (size_t)cols * 2 * nw * sizeof(float);
-#define LN_BWD_CASE(MV) if (cols <= (int64_t)MV * 64 * VEC) { \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_vec<T, MV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((ln_bwd_vec<T, MV>), dim3(grid), dim3(64 * lnb_waves(MV)), lds, st, (const T*)dy, (const T*)x, w, mean, rstd, \
+#define LN_BWD_CASE(MV, NSV) { \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_vec<T, MV, NSV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((ln_bwd_vec<T, MV, NSV>), dim3(grid), dim3(64 * lnb_waves(MV)), lds, st, (const T*)dy, (const T*)x, w, mean, rstd, \
                                (const T*)dres, (T*)dx, ws, rows, (int)cols); }
-        if (mv >= 4) { (void)lds; } else LN_BWD_CASE(1) else LN_BWD_CASE(2)
+        if (mv >= 4) { (void)lds; }
+        else if (want_sums) { ns = 4; if (mv == 1) LN_BWD_CASE(1, 4) else LN_BWD_CASE(2, 4) }
+        else { if (mv == 1) LN_BWD_CASE(1, 2) else LN_BWD_CASE(2, 2) }
 #undef LN_BWD_CASE
         CTMI_CHECK_LAUNCH("layernorm_bwd");
     } else {
@@ -446,12 +470,33 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* w, const fl
         hipLaunchKernelGGL((ln_bwd_wb_gen<T>), dim3(nparts), dim3(256), 0, st, (const T*)dy, (const T*)x, mean, rstd, ws, rows, cols, chunk);
         CTMI_CHECK_LAUNCH("layernorm_bwd_wb");
     }
+    *nparts_out = nparts; *ns_out = ns;
+    return CTMI_OK;
+}
+
+template <typename T>
+static int ln_bwd_launch(const void* dy, const void* x, const float* w, const float* mean, const float* rstd,
+                         const void* dres, void* dx, float* dw, float* db, int accumulate, float* ws,
+                         int64_t rows, int64_t cols, hipStream_t st) {
+    int nparts = 0, ns = 2;
+    int rc = ln_bwd_parts<T>(dy, x, w, mean, rstd, dres, dx, ws, rows, cols, 0, &nparts, &ns, st);
+    if (rc != CTMI_OK) return rc;
     if (cols % 256 == 0 && cols >= 2048 && aligned16(ws))
         hipLaunchKernelGGL(ln_bwd_reduce4, dim3((unsigned)(cols / 256), 2), dim3(256), 0, st, ws, dw, db, nparts, cols, accumulate);
     else
         hipLaunchKernelGGL(ln_bwd_reduce, dim3((unsigned)cdiv64(cols, 64), 2), dim3(256), 0, st, ws, dw, db, nparts, cols, accumulate);
     CTMI_CHECK_LAUNCH("layernorm_bwd_reduce");
     return CTMI_OK;
+}
+
+// internal (block.hip): main pass + partial rows only
+int ctmi_ln_bwd_parts_internal(const void* dy, const void* x, const float* w, const float* mean, const float* rstd,
+                               const void* dres, void* dx, float* ws, int64_t rows, int64_t cols, int dtype, int want_sums,
+                               int* nparts, int* ns, hipStream_t st) {
+    if (dtype == CTMI_F32) return ln_bwd_parts<float>(dy, x, w, mean, rstd, dres, dx, ws, rows, cols, want_sums, nparts, ns, st);
+    if (dtype == CTMI_BF16) return ln_bwd_parts<bf16_t>(dy, x, w, mean, rstd, dres, dx, ws, rows, cols, want_sums, nparts, ns, st);
+    ctmi_set_error("layernorm_bwd: unsupported dtype %d", dtype);
+    return CTMI_ERR_UNSUPPORTED;
 }
 
 extern "C" int ctmi_layernorm_bwd(const void* dy, const void* x, const float* w, const float* mean, const float* rstd,
@@ -537,9 +582,8 @@ __global__ __launch_bounds__(256) void colsum_final(const float* __restrict__ ws
     }
 }
 
-extern "C" int ctmi_colsum(const void* x, int64_t ld, float* out, int accumulate, float* ws, int64_t M, int64_t N, int dtype, void* stream) {
-    CTMI_REQUIRE(x && out && ws && M > 0 && N > 0, "colsum: bad args");
-    hipStream_t st = as_stream(stream);
+// partial rows only: ws[part][N]; *parts_out partial rows
+int ctmi_colsum_parts_internal(const void* x, int64_t ld, float* ws, int64_t M, int64_t N, int dtype, int* parts_out, hipStream_t st) {
     const int64_t xblocks = cdiv64(N, 64 * (dtype == CTMI_F32 ? 4 : 8));
     // ~2048 workgroups (8 waves per SIMD) so the row streams cover the HBM latency; >= 16 rows per part
     int parts = (int)std::min<int64_t>(std::max<int64_t>(16, std::min<int64_t>(COLSUM_PARTS, cdiv64(2048, xblocks))), cdiv64(M, 16));
@@ -553,8 +597,67 @@ extern "C" int ctmi_colsum(const void* x, int64_t ld, float* out, int accumulate
         hipLaunchKernelGGL((colsum_part<bf16_t>), dim3((unsigned)cdiv64(N, 64 * 8), parts), dim3(256), 0, st, (const bf16_t*)x, ld, ws, M, N, rpp, vec_ok);
     } else { ctmi_set_error("colsum: unsupported dtype %d", dtype); return CTMI_ERR_UNSUPPORTED; }
     CTMI_CHECK_LAUNCH("colsum_part");
+    *parts_out = parts;
+    return CTMI_OK;
+}
+
+extern "C" int ctmi_colsum(const void* x, int64_t ld, float* out, int accumulate, float* ws, int64_t M, int64_t N, int dtype, void* stream) {
+    CTMI_REQUIRE(x && out && ws && M > 0 && N > 0, "colsum: bad args");
+    hipStream_t st = as_stream(stream);
+    int parts = 0;
+    int rc = ctmi_colsum_parts_internal(x, ld, ws, M, N, dtype, &parts, st);
+    if (rc != CTMI_OK) return rc;
     hipLaunchKernelGGL(colsum_final, dim3((unsigned)cdiv64(N, 64)), dim3(256), 0, st, ws, out, parts, N, accumulate);
     CTMI_CHECK_LAUNCH("colsum_final");
+    return CTMI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// multi-job partial-row reduction: dst[c] (+)= alpha * sum_p src[p * part_stride + c], c < n, for up to CTMI_REDUCE_MAX_JOBS
+// independent jobs in ONE launch (fixed summation order: deterministic).  A transformer block's backward leaves the partial
+// rows of its two LayerNorm backward passes and its bias column sums in workspaces and reduces them all here, instead of one
+// small "final" launch per vector (what used to be 96 colsum_final + 50 ln_bwd_reduce launches per Bloom-560M step).
+// ------------------------------------------------------------------------------------------------
+struct ReduceJobs { ctmi_reduce_job j[CTMI_REDUCE_MAX_JOBS]; int chunk0[CTMI_REDUCE_MAX_JOBS + 1]; int count; };
+__global__ __launch_bounds__(256) void reduce_jobs_k(ReduceJobs R) {
+    // block -> (job, 64-column chunk); 64 columns x 4 part-slices per block, LDS combine
+    __shared__ float sm[4][64];
+    int job = 0;
+    while (job + 1 < R.count && (int)blockIdx.x >= R.chunk0[job + 1]) ++job;
+    const ctmi_reduce_job& J = R.j[job];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t c = (int64_t)((int)blockIdx.x - R.chunk0[job]) * 64 + tx;
+    float t = 0.f;
+    if (c < J.n) {
+#pragma unroll 8
+        for (int p = ty; p < J.nparts; p += 4) t += J.src[(int64_t)p * J.part_stride + c];
+    }
+    sm[ty][tx] = t;
+    __syncthreads();
+    if (ty == 0 && c < J.n) {
+        const float r = J.alpha * (sm[0][tx] + sm[1][tx] + sm[2][tx] + sm[3][tx]);
+        J.dst[c] = J.accumulate ? J.dst[c] + r : r;
+    }
+}
+
+extern "C" int ctmi_reduce_jobs(const ctmi_reduce_job* jobs, int count, void* stream) {
+    CTMI_REQUIRE(jobs != nullptr && count >= 0, "reduce_jobs: bad args");
+    hipStream_t st = as_stream(stream);
+    for (int base = 0; base < count; base += CTMI_REDUCE_MAX_JOBS) {
+        ReduceJobs R;
+        R.count = std::min(CTMI_REDUCE_MAX_JOBS, count - base);
+        int chunks = 0;
+        for (int i = 0; i < R.count; ++i) {
+            const ctmi_reduce_job& J = jobs[base + i];
+            CTMI_REQUIRE(J.src && J.dst && J.n > 0 && J.nparts > 0, "reduce_jobs: job %d is malformed", base + i);
+            R.j[i] = J;
+            R.chunk0[i] = chunks;
+            chunks += (int)cdiv64(J.n, 64);
+        }
+        R.chunk0[R.count] = chunks;
+        hipLaunchKernelGGL(reduce_jobs_k, dim3((unsigned)chunks), dim3(256), 0, st, R);
+        CTMI_CHECK_LAUNCH("reduce_jobs");
+    }
     return CTMI_OK;
 }
 
@@ -816,6 +919,196 @@ extern "C" int ctmi_ce_bwd(const void* logits, int64_t ld, const int64_t* labels
         hipLaunchKernelGGL((ce_bwd_k<bf16_t>), dim3((unsigned)N), dim3(256), 0, st, (const bf16_t*)logits, ld, labels, row_lse, loss_out, gout, (bf16_t*)dlogits, ldd, C, seq, shift, ignore_index, vec_ok);
     } else { ctmi_set_error("ce_bwd: unsupported dtype %d", dtype); return CTMI_ERR_UNSUPPORTED; }
     CTMI_CHECK_LAUNCH("ce_bwd");
+    return CTMI_OK;
+}
+
+// ---- training path: loss AND its gradient in one pass over the logits (modeling_bloom.py:224-230 followed by loss.backward()).
+// The two-kernel form reads the 4.1 GB of bf16 logits twice from HBM (statistics, then gradient).  Here ONE 1024-thread
+// workgroup owns a row: pass 1 streams the row (502 KB at V = 250880) and forms its log-sum-exp, pass 2 walks the SAME row
+// back to front — the most recently fetched lines first — and writes dlogits.  One workgroup per CU (the dynamic LDS request
+// enforces it) keeps 256 rows = 128 MiB in flight, inside the 256 MiB Infinity Cache, so the second read does not go to HBM.
+// The gradient is written for an upstream gradient of 1 (loss.backward()); ctmi_scale_if rescales it in the rare other case.
+// 1/denom is needed before any row is finished, so it is counted from the labels alone by ce_count_k first.
+__global__ __launch_bounds__(1024) void ce_count_k(const int64_t* __restrict__ labels, float* __restrict__ loss_out, int64_t N, int64_t C,
+                                                   int64_t seq, int64_t shift, int64_t ignore, int denom_mode, int64_t denom_rows) {
+    __shared__ unsigned long long sm_c[16];
+    unsigned long long cnt = 0;
+    for (int64_t r = threadIdx.x; r < N; r += 1024) {
+        const int64_t t = ce_target(labels, r, seq, shift, ignore);
+        cnt += (t >= 0 && t < C) ? 1 : 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if ((threadIdx.x & 63) == 0) sm_c[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long Cn = 0;
+        for (int k = 0; k < 16; ++k) Cn += sm_c[k];
+        const double denom = denom_mode == 0 ? (double)Cn : (denom_mode == 1 ? (double)denom_rows : 1.0);
+        loss_out[1] = (float)(1.0 / denom);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void ce_fused_k(const T* __restrict__ logits, int64_t ld, const int64_t* __restrict__ labels,
+                                                   float* __restrict__ row_lse, float* __restrict__ row_loss,
+                                                   const float* __restrict__ loss_out, T* __restrict__ dlogits, int64_t ldd,
+                                                   int64_t C, int64_t seq, int64_t shift, int64_t ignore) {
+    constexpr int VEC = 16 / sizeof(T);
+    constexpr int NT = 1024, UNR = 4;
+    __shared__ float sm_m[16], sm_s[16];
+    const int64_t row = blockIdx.x;
+    const T* x = logits + row * ld;
+    T* d = dlogits + row * ldd;
+    const int64_t Cv = C - C % VEC;                                     // vector body (rows are 16-byte aligned: checked by the host)
+    const int64_t nvec = Cv / VEC;                                      // 16-byte chunks in the row
+    float m = -INFINITY, s = 0.f;
+    // ---- pass 1: online (max, sum exp), UNR independent 16-byte loads in flight per lane
+    for (int64_t c = Cv + threadIdx.x; c < C; c += NT) {
+        const float v = Cvt<T>::to_f(x[c]);
+        const float mn = fmaxf(m, v);
+        s = s * __expf(m - mn) + __expf(v - mn);
+        m = mn;
+    }
+    int64_t i = threadIdx.x;
+    for (; i + (UNR - 1) * NT < nvec; i += UNR * NT) {
+        uint4 raw[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) raw[u] = *reinterpret_cast<const uint4*>(x + (i + u * NT) * VEC);
+        float vm = -INFINITY;
+        float v[UNR][VEC];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            unpack16<T>(raw[u], v[u]);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) vm = fmaxf(vm, v[u][j]);
+        }
+        const float mn = fmaxf(m, vm);
+        float add = 0.f;
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) add += __expf(v[u][j] - mn);
+        s = s * __expf(m - mn) + add;
+        m = mn;
+    }
+    for (; i < nvec; i += NT) {
+        float v[VEC];
+        unpack16<T>(*reinterpret_cast<const uint4*>(x + i * VEC), v);
+        float vm = v[0];
+#pragma unroll
+        for (int j = 1; j < VEC; ++j) vm = fmaxf(vm, v[j]);
+        const float mn = fmaxf(m, vm);
+        float add = 0.f;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) add += __expf(v[j] - mn);
+        s = s * __expf(m - mn) + add;
+        m = mn;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+        const float mn = fmaxf(m, m2);
+        const float a = (m == -INFINITY) ? 0.f : s * __expf(m - mn);
+        const float b = (m2 == -INFINITY) ? 0.f : s2 * __expf(m2 - mn);
+        s = a + b; m = mn;
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) { sm_m[wid] = m; sm_s[wid] = s; }
+    __syncthreads();
+    float M = sm_m[0], S = sm_s[0];                                     // every thread folds the 16 wave states in the same order
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+        const float m2 = sm_m[k], s2 = sm_s[k];
+        const float mn = fmaxf(M, m2);
+        const float a = (M == -INFINITY) ? 0.f : S * __expf(M - mn);
+        const float b = (m2 == -INFINITY) ? 0.f : s2 * __expf(m2 - mn);
+        S = a + b; M = mn;
+    }
+    const float lse = M + logf(S);
+    const int64_t t = ce_target(labels, row, seq, shift, ignore);
+    const bool live = (t >= 0 && t < C);
+    if (threadIdx.x == 0) {
+        row_lse[row] = lse;
+        row_loss[row] = live ? (lse - Cvt<T>::to_f(x[t])) : -1.0f;       // -1 marks "no loss"
+    }
+    // ---- pass 2: gradient, back to front (the tail of the row is the freshest in the caches)
+    const float coef = live ? loss_out[1] : 0.f;
+    for (int64_t c = Cv + threadIdx.x; c < C; c += NT)
+        d[c] = Cvt<T>::from_f(live ? (__expf(Cvt<T>::to_f(x[c]) - lse) - ((c == t) ? 1.0f : 0.0f)) * coef : 0.f);
+    if (!live) {
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        for (int64_t k = threadIdx.x; k < nvec; k += NT) stg_stream16(d + k * VEC, z);
+        return;
+    }
+    int64_t k = nvec - 1 - threadIdx.x;
+    for (; k - (UNR - 1) * NT >= 0; k -= UNR * NT) {
+        uint4 raw[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) raw[u] = ldg_stream16(x + (k - u * NT) * VEC);       // logits: last use
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t c = (k - u * NT) * VEC;
+            float v[VEC], o[VEC];
+            unpack16<T>(raw[u], v);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) o[j] = (__expf(v[j] - lse) - ((c + j == t) ? 1.0f : 0.0f)) * coef;
+            stg_stream16(d + c, pack16<T>(o));
+        }
+    }
+    for (; k >= 0; k -= NT) {
+        const int64_t c = k * VEC;
+        float v[VEC], o[VEC];
+        unpack16<T>(ldg_stream16(x + c), v);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] = (__expf(v[j] - lse) - ((c + j == t) ? 1.0f : 0.0f)) * coef;
+        stg_stream16(d + c, pack16<T>(o));
+    }
+}
+
+extern "C" int ctmi_ce_fwd_bwd(const void* logits, int64_t ld, const int64_t* labels, float* row_lse, float* row_loss,
+                               float* loss_out, void* dlogits, int64_t ldd, int64_t N, int64_t C, int64_t seq, int64_t shift,
+                               int64_t ignore_index, int denom_mode, int64_t denom_rows, int dtype, void* stream) {
+    CTMI_REQUIRE(logits && labels && row_lse && row_loss && loss_out && dlogits, "ce_fwd_bwd: null pointer");
+    CTMI_REQUIRE(N > 0 && C > 0 && seq > 0 && N % seq == 0 && shift >= 0 && ld >= C && ldd >= C, "ce_fwd_bwd: bad shape N=%lld C=%lld seq=%lld", (long long)N, (long long)C, (long long)seq);
+    CTMI_REQUIRE(dtype == CTMI_F32 || dtype == CTMI_BF16, "ce_fwd_bwd: unsupported dtype %d", dtype);
+    const int vec = dtype == CTMI_F32 ? 4 : 8;
+    CTMI_REQUIRE(ld % vec == 0 && ldd % vec == 0 && aligned16(logits) && aligned16(dlogits),
+                 "ce_fwd_bwd: rows must be 16-byte aligned (use ctmi_ce_fwd + ctmi_ce_bwd otherwise)");
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(ce_count_k, dim3(1), dim3(1024), 0, st, labels, loss_out, N, C, seq, shift, ignore_index, denom_mode, denom_rows);
+    CTMI_CHECK_LAUNCH("ce_count");
+    const size_t lds_hold = 96 * 1024;                                   // one workgroup per CU: 256 rows in flight (see above)
+    if (dtype == CTMI_F32) {
+        auto kern = &ce_fused_k<float>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hold);
+        hipLaunchKernelGGL(kern, dim3((unsigned)N), dim3(1024), lds_hold, st, (const float*)logits, ld, labels, row_lse, row_loss, loss_out, (float*)dlogits, ldd, C, seq, shift, ignore_index);
+    } else {
+        auto kern = &ce_fused_k<bf16_t>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hold);
+        hipLaunchKernelGGL(kern, dim3((unsigned)N), dim3(1024), lds_hold, st, (const bf16_t*)logits, ld, labels, row_lse, row_loss, loss_out, (bf16_t*)dlogits, ldd, C, seq, shift, ignore_index);
+    }
+    CTMI_CHECK_LAUNCH("ce_fused");
+    hipLaunchKernelGGL(ce_finalize_k, dim3(1), dim3(1024), 0, st, row_loss, loss_out, N, denom_mode, denom_rows);
+    CTMI_CHECK_LAUNCH("ce_finalize");
+    return CTMI_OK;
+}
+
+// x *= s[0] unless s[0] == 1 exactly (then every workgroup returns after one scalar load): the backward of the fused loss, whose
+// gradient was written for an upstream gradient of 1.
+template <typename T>
+__global__ __launch_bounds__(256) void scale_if_k(T* __restrict__ x, int64_t ld, int64_t rows, int64_t cols, const float* __restrict__ sp) {
+    const float s = sp[0];
+    if (s == 1.0f) return;
+    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x)
+        for (int64_t c = threadIdx.x; c < cols; c += 256) x[r * ld + c] = Cvt<T>::from_f(Cvt<T>::to_f(x[r * ld + c]) * s);
+}
+extern "C" int ctmi_scale_if(void* x, int64_t ld, int64_t rows, int64_t cols, const float* s_dev, int dtype, void* stream) {
+    CTMI_REQUIRE(x && s_dev && rows > 0 && cols > 0 && ld >= cols, "scale_if: bad args");
+    const unsigned grid = (unsigned)std::min<int64_t>(rows, 4096);
+    if (dtype == CTMI_F32) hipLaunchKernelGGL((scale_if_k<float>), dim3(grid), dim3(256), 0, as_stream(stream), (float*)x, ld, rows, cols, s_dev);
+    else if (dtype == CTMI_BF16) hipLaunchKernelGGL((scale_if_k<bf16_t>), dim3(grid), dim3(256), 0, as_stream(stream), (bf16_t*)x, ld, rows, cols, s_dev);
+    else { ctmi_set_error("scale_if: unsupported dtype %d", dtype); return CTMI_ERR_UNSUPPORTED; }
+    CTMI_CHECK_LAUNCH("scale_if");
     return CTMI_OK;
 }
 

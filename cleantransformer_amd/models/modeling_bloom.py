@@ -102,95 +102,67 @@ class _AttnCtx:
 
 # ------------------------------------------------------------------------------------------------ one block = one node
 class BloomBlockFn(torch.autograd.Function):
-    """modeling_bloom.py:142-159 (+ 76-124, 255-271) forward and its full backward."""
+    """modeling_bloom.py:142-159 (+ 76-124, 255-271) forward and its full backward: ONE autograd node and ONE library call
+    per direction (ctmi_bloom_block_fwd / ctmi_bloom_block_bwd run the fixed kernel sequences; include/ctmi355.h)."""
 
     @staticmethod
     def forward(ctx, x, ln1_w, ln1_b, wqkv, bqkv, wd, bd, ln2_w, ln2_b, w1, b1, w2, b2, actx: _AttnCtx, eps: float,
-                post_ln_res: bool):
+                post_ln_res: bool, kv_out: list):
         B, S, H = x.shape
-        T = B * S
-        nh = actx.nh
-        hd = H // nh
         cd = x.dtype
-        x2 = x.reshape(T, H)
+        x2 = x.reshape(B * S, H)
         x2 = x2 if x2.is_contiguous() else x2.contiguous()
-        wqkv_c, wd_c = ops.compute_weight(wqkv, cd), ops.compute_weight(wd, cd)
-        w1_c, w2_c = ops.compute_weight(w1, cd), ops.compute_weight(w2, cd)
-
-        ln1, mean1, rstd1 = ops.layernorm_fwd(x2, ln1_w.detach(), ln1_b.detach(), eps)
-        qkv = ops.linear_fwd(ln1, wqkv_c, bqkv.detach())                                  # [T, 3H] head-interleaved
-        desc = ops.fused_qkv_desc(B, S, nh, hd, causal=S > 1)
-        att = torch.empty((T, H), dtype=cd, device=x.device)
-        stat_m, stat_l = ops.attn_fwd(qkv, qkv[:, hd:], qkv[:, 2 * hd:], att, desc, actx.slopes, actx.mask)
-        res1 = ln1 if post_ln_res else x2
-        h1 = ops.linear_fwd(att, wd_c, bd.detach(), residual=res1)
-        ln2, mean2, rstd2 = ops.layernorm_fwd(h1, ln2_w.detach(), ln2_b.detach(), eps)
-        u = torch.empty((T, 4 * H), dtype=cd, device=x.device)
-        g = ops.linear_fwd(ln2, w1_c, b1.detach(), epilogue=_lib.EPI_GELU, aux_out=u)
-        res2 = ln2 if post_ln_res else h1
-        out = ops.linear_fwd(g, w2_c, b2.detach(), residual=res2)
-
-        ctx.save_for_backward(x2, ln1_w, wqkv, wd, ln2_w, w1, w2, mean1, rstd1, ln1, qkv, att, stat_m, stat_l,
-                              h1, mean2, rstd2, ln2, u, g)
-        ctx.actx, ctx.desc, ctx.post_ln_res, ctx.shape = actx, desc, post_ln_res, (B, S, H)
-        ctx.set_materialize_grads(False)                 # the K/V "present" outputs carry no gradient: do not zero-fill them
-        qv = qkv.view(B, S, nh, 3, hd)
-        present_k = qv[:, :, :, 1, :].transpose(1, 2)                                       # views, like the reference's k_v_past
-        present_v = qv[:, :, :, 2, :].transpose(1, 2)
-        ctx.mark_non_differentiable(present_k, present_v)
-        return out.view(B, S, H), present_k, present_v
+        params = (ln1_w.detach(), ln1_b.detach(), ops.compute_weight(wqkv, cd), bqkv.detach(), ops.compute_weight(wd, cd), bd.detach(),
+                  ln2_w.detach(), ln2_b.detach(), ops.compute_weight(w1, cd), b1.detach(), ops.compute_weight(w2, cd), b2.detach())
+        acts = ops.bloom_block_fwd(x2, params, actx.mask, actx.slopes, eps, post_ln_res, B, S, actx.nh)
+        ctx.save_for_backward(x2, ln1_w, ln1_b, wqkv, bqkv, wd, bd, ln2_w, ln2_b, w1, b1, w2, b2)
+        ctx.acts, ctx.actx, ctx.eps, ctx.post_ln_res, ctx.shape = acts, actx, eps, post_ln_res, (B, S, H)
+        kv_out.append(_LazyKV(acts, B, S, actx.nh))                     # the K/V "present" views (no gradient), made on demand
+        return acts.out.view(B, S, H)
 
     @staticmethod
-    def backward(ctx, dout, _dk, _dv):
+    def backward(ctx, dout):
         if dout is None:
-            return (None,) * 16
-        (x2, ln1_w, wqkv, wd, ln2_w, w1, w2, mean1, rstd1, ln1, qkv, att, stat_m, stat_l,
-         h1, mean2, rstd2, ln2, u, g) = ctx.saved_tensors
+            return (None,) * 17
+        x2, ln1_w, ln1_b, wqkv, bqkv, wd, bd, ln2_w, ln2_b, w1, b1, w2, b2 = ctx.saved_tensors
         B, S, H = ctx.shape
-        T = B * S
-        nh = ctx.actx.nh
-        hd = H // nh
         cd = x2.dtype
-        post = ctx.post_ln_res
-        wqkv_c, wd_c = ops.compute_weight(wqkv, cd), ops.compute_weight(wd, cd)
-        w1_c, w2_c = ops.compute_weight(w1, cd), ops.compute_weight(w2, cd)
-        dout2 = dout.reshape(T, H)
+        dout2 = dout.reshape(B * S, H)
         dout2 = dout2 if dout2.is_contiguous() else dout2.contiguous()
+        params = (ln1_w.detach(), ln1_b.detach(), ops.compute_weight(wqkv, cd), bqkv.detach(), ops.compute_weight(wd, cd), bd.detach(),
+                  ln2_w.detach(), ln2_b.detach(), ops.compute_weight(w1, cd), b1.detach(), ops.compute_weight(w2, cd), b2.detach())
+        # Parameter gradients (wgrad GEMMs + bias column sums) feed nothing further down the backward chain: inside the
+        # library call they run on a side HIP stream, concurrently with the dgrad GEMMs / attention backward, and are joined
+        # back into the current stream before the call returns, so everything downstream (autograd accumulation, DDP hooks,
+        # optimizer) is ordered.
+        dx, g = ops.bloom_block_bwd(ctx.acts, x2, params, ctx.actx.mask, ctx.actx.slopes, ctx.eps, ctx.post_ln_res, dout2,
+                                    use_side_stream=_WGRAD_SIDE_STREAM and x2.is_cuda)
+        return (dx.view(B, S, H), *g, None, None, None, None)
 
-        # Parameter gradients (wgrad GEMMs + bias column sums) feed nothing further down the backward chain: they run on
-        # a side HIP stream, concurrently with the dgrad GEMMs / attention backward (MFMA-bound next to VALU-bound work,
-        # and their kernel tails overlap).  The side stream waits for each producer; the main stream waits for the side
-        # stream before this node returns, so everything downstream (autograd accumulation, optimizer) is ordered.
-        use_side = _WGRAD_SIDE_STREAM and x2.is_cuda
-        main = torch.cuda.current_stream(x2.device) if use_side else None
-        side = ops.side_stream(x2.device) if use_side else None
 
-        def param_grads(dy, xin):
-            if side is None:
-                return ops.linear_wgrad(dy, xin), ops.colsum(dy)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                return ops.linear_wgrad(dy, xin), ops.colsum(dy)
+class _LazyKV:
+    """``(present_k, present_v)`` of one block (modeling_bloom.py:88-92 returns them on every call): [B,nh,S,hd] views of the fused
+    QKV activation, built when first indexed — a training step never looks at them."""
+    __slots__ = ("_acts", "_geo", "_kv")
 
-        # MLP: out = res2 + W2 gelu(W1 ln2 + b1) + b2
-        dw2, db2 = param_grads(dout2, g)
-        du = ops.linear_dgrad(dout2, w2_c, epilogue=_lib.EPI_DGELU, aux_in=u)             # dgelu fused (modeling_bloom.py:348-363)
-        dw1, db1 = param_grads(du, ln2)
-        dln2 = ops.linear_dgrad(du, w1_c, residual=dout2 if post else None)
-        dh1, dln2_w, dln2_b = ops.layernorm_bwd(dln2, h1, ln2_w.detach(), mean2, rstd2, dres=None if post else dout2)
-        # attention: h1 = res1 + Wd att + bd
-        dwd, dbd = param_grads(dh1, att)
-        datt = ops.linear_dgrad(dh1, wd_c)
-        dqkv = torch.empty_like(qkv)
-        ops.attn_bwd(qkv, qkv[:, hd:], qkv[:, 2 * hd:], att, datt, stat_m, stat_l,
-                     dqkv, dqkv[:, hd:], dqkv[:, 2 * hd:], ctx.desc, ctx.actx.slopes, ctx.actx.mask)
-        dwqkv, dbqkv = param_grads(dqkv, ln1)
-        dln1 = ops.linear_dgrad(dqkv, wqkv_c, residual=dh1 if post else None)
-        dx, dln1_w, dln1_b = ops.layernorm_bwd(dln1, x2, ln1_w.detach(), mean1, rstd1, dres=None if post else dh1)
-        if side is not None:
-            main.wait_stream(side)
-        return (dx.view(B, S, H), dln1_w, dln1_b, dwqkv, dbqkv, dwd, dbd, dln2_w, dln2_b, dw1, db1, dw2, db2,
-                None, None, None)
+    def __init__(self, acts, B, S, nh):
+        self._acts, self._geo, self._kv = acts, (B, S, nh), None
+
+    def _make(self):
+        if self._kv is None:
+            B, S, nh = self._geo
+            qv = self._acts.qkv.view(B, S, nh, 3, -1)
+            self._kv = (qv[:, :, :, 1, :].transpose(1, 2), qv[:, :, :, 2, :].transpose(1, 2))
+        return self._kv
+
+    def __getitem__(self, i):
+        return self._make()[i]
+
+    def __iter__(self):
+        return iter(self._make())
+
+    def __len__(self):
+        return 2
 
 
 def _decode_block(blk: "BloomBlock", x: Tensor, actx: _AttnCtx, past, eps: float, post_ln_res: bool):
@@ -320,9 +292,13 @@ class LMHeadFn(torch.autograd.Function):
         return dh.view(B, S, H), dw, None
 
 
+_FUSED_CE = _os.environ.get("CTMI_FUSED_CE", "1") != "0"
+
+
 class ShiftedCrossEntropyFn(torch.autograd.Function):
     """modeling_bloom.py:224-230: logits[..., :-1, :] vs labels[..., 1:], torch CE 'mean'; the shift is index
-    arithmetic inside the kernel (no .contiguous() copy of the logits)."""
+    arithmetic inside the kernel (no .contiguous() copy of the logits).  When a gradient will be wanted, the loss and
+    dlogits come out of ONE pass over the logits (ctmi_ce_fwd_bwd): the backward is then only a conditional rescale."""
 
     @staticmethod
     def forward(ctx, logits: Tensor, labels: Tensor):
@@ -331,17 +307,30 @@ class ShiftedCrossEntropyFn(torch.autograd.Function):
         l2 = l2 if l2.stride(1) == 1 else l2.contiguous()                  # a padded row pitch is fine: the kernels take ld
         lab = labels.to(torch.int64)
         lab = lab if lab.is_contiguous() else lab.contiguous()
+        ctx.shape = (B, S, V)
+        ctx.fused = bool(_FUSED_CE and ctx.needs_input_grad[0] and ops.ce_fused_ok(l2))
+        if ctx.fused:
+            loss_out, _, dl = ops.ce_fwd_bwd(l2, lab, seq=S, shift=1, ignore_index=-100, denom_mode=0)
+            ctx.dl, ctx.used = dl, False
+            return loss_out[0].clone()
         loss_out, row_lse = ops.ce_fwd(l2, lab, seq=S, shift=1, ignore_index=-100, denom_mode=0)
         ctx.save_for_backward(l2, lab, row_lse, loss_out)
-        ctx.shape = (B, S, V)
         return loss_out[0].clone()
 
     @staticmethod
     def backward(ctx, gout: Tensor):
-        l2, lab, row_lse, loss_out = ctx.saved_tensors
         B, S, V = ctx.shape
         g = gout.to(torch.float32).reshape(1)
         g = g if g.is_contiguous() else g.contiguous()
+        if ctx.fused:
+            if ctx.used:
+                raise RuntimeError("the fused loss node keeps ONE gradient buffer and rescales it in place: it cannot be "
+                                   "backpropagated twice (set CTMI_FUSED_CE=0 for retain_graph workflows)")
+            ctx.used = True
+            d = ops.scale_if_(ctx.dl, g)                                  # no-op on the device for loss.backward() (gout == 1)
+            ctx.dl = None
+            return d.view(B, S, V), None
+        l2, lab, row_lse, loss_out = ctx.saved_tensors
         out = None
         if l2.is_cuda and l2.stride(0) != V and l2.stride(0) == ops.pad_rows(V):
             # logits came with a padded row pitch (odd vocabulary): give dlogits the same pitch and zero its pad columns, and
@@ -426,13 +415,14 @@ class BloomBlock(torch.nn.Module):
             if torch.is_grad_enabled() and hidden_states.requires_grad:
                 raise NotImplementedError("training through a KV cache is not supported")
             return _decode_block(self, hidden_states, actx, k_v_past, self.eps, self.apply_residual_connection_post_layernorm)
-        out, pk, pv = BloomBlockFn.apply(
+        kv = []
+        out = BloomBlockFn.apply(
             hidden_states, self.input_layernorm.weight, self.input_layernorm.bias,
             sa.query_key_value.weight, sa.query_key_value.bias, sa.dense.weight, sa.dense.bias,
             self.post_attention_layernorm.weight, self.post_attention_layernorm.bias,
             mlp.dense_h_to_4h.weight, mlp.dense_h_to_4h.bias, mlp.dense_4h_to_h.weight, mlp.dense_4h_to_h.bias,
-            actx, self.eps, self.apply_residual_connection_post_layernorm)
-        return out, (pk, pv)
+            actx, self.eps, self.apply_residual_connection_post_layernorm, kv)
+        return out, kv[0]
 
 
 class BloomModel(torch.nn.Module):

@@ -310,6 +310,146 @@ def ce_soft_bwd(logits2d: Tensor, target: Tensor, row_lse: Tensor, row_tsum: Ten
     return out
 
 
+def ce_fwd_bwd(logits2d: Tensor, labels: Tensor, seq: int, shift: int, ignore_index: int = -100, denom_mode: int = 0,
+               denom_rows: int = 0):
+    """Loss and dlogits (for an upstream gradient of 1) in one pass -> loss_out fp32[2], row_lse fp32[N], dlogits [N,C]."""
+    N, Cn = logits2d.shape
+    dev = logits2d.device
+    row_lse = torch.empty(N, dtype=torch.float32, device=dev)
+    row_loss = torch.empty(N, dtype=torch.float32, device=dev)
+    loss_out = torch.empty(2, dtype=torch.float32, device=dev)
+    dl = torch.empty((N, Cn), dtype=logits2d.dtype, device=dev)
+    check(_lib.load().ctmi_ce_fwd_bwd(_p(logits2d), logits2d.stride(0), _p(labels), _p(row_lse), _p(row_loss), _p(loss_out), _p(dl),
+                                      dl.stride(0), N, Cn, seq, shift, ignore_index, denom_mode, denom_rows, dt_code(logits2d.dtype),
+                                      _stream()), "ce_fwd_bwd")
+    return loss_out, row_lse, dl
+
+
+def ce_fused_ok(logits2d: Tensor) -> bool:
+    """Rows 16-byte aligned and densely packed: the single-pass loss+gradient kernel applies."""
+    vec = 16 // logits2d.element_size()
+    return logits2d.is_cuda and logits2d.stride(1) == 1 and logits2d.stride(0) == logits2d.shape[1] and logits2d.shape[1] % vec == 0 \
+        and logits2d.data_ptr() % 16 == 0
+
+
+def scale_if_(x2d: Tensor, s_dev: Tensor) -> Tensor:
+    """x2d *= s_dev[0], skipped on the device when the scalar is exactly 1."""
+    rows, cols = x2d.shape
+    check(_lib.load().ctmi_scale_if(_p(x2d), x2d.stride(0), rows, cols, _p(s_dev), dt_code(x2d.dtype), _stream()), "scale_if")
+    return x2d
+
+
+# ------------------------------------------------------------------------------------------------ one Bloom block per call
+class _BlockLayout:
+    __slots__ = ("off", "bytes", "bwd_ws_bytes")
+
+
+_BLOCK_LAYOUTS = {}
+_BLOCK_WS = {}
+
+
+def block_layout(B: int, S: int, H: int, nh: int, dtype: torch.dtype) -> _BlockLayout:
+    key = (B, S, H, nh, dtype)
+    lay = _BLOCK_LAYOUTS.get(key)
+    if lay is None:
+        lib = _lib.load()
+        offs = (C.c_int64 * len(_lib.BLK_SLOTS))()
+        lay = _BlockLayout()
+        lay.bytes = int(lib.ctmi_bloom_block_layout(B, S, H, nh, dt_code(dtype), offs))
+        lay.off = dict(zip(_lib.BLK_SLOTS, [int(o) for o in offs]))
+        lay.bwd_ws_bytes = int(lib.ctmi_bloom_block_bwd_ws(B, S, H, nh, dt_code(dtype)))
+        _BLOCK_LAYOUTS[key] = lay
+    return lay
+
+
+def _block_ws(device, nbytes: int) -> Tensor:
+    """Scratch of the block backward (intermediate gradients, partial rows): one buffer per device, grown on demand.  The
+    backward of consecutive blocks is ordered on the compute stream (and joins its side stream before returning), so they
+    may share it."""
+    ws = _BLOCK_WS.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _BLOCK_WS[device] = ws
+    return ws
+
+
+class BlockActs:
+    """Activations one block keeps for its backward: ONE slab (layout: ctmi_bloom_block_layout) plus the geometry."""
+    __slots__ = ("slab", "lay", "B", "S", "H", "nh", "dtype")
+
+    def view(self, slot: str, rows: int, cols: int, dtype=None) -> Tensor:
+        dtype = dtype or self.dtype
+        n = rows * cols * (torch.finfo(dtype).bits // 8)
+        o = self.lay.off[slot]
+        return self.slab[o:o + n].view(dtype).view(rows, cols)
+
+    @property
+    def out(self) -> Tensor:
+        return self.view("out", self.B * self.S, self.H)
+
+    @property
+    def qkv(self) -> Tensor:
+        return self.view("qkv", self.B * self.S, 3 * self.H)
+
+
+def _fill_block_desc(d: "_lib.BloomBlock", x2: Tensor, params, mask: Optional[MaskInfo], slopes: Optional[Tensor], eps: float,
+                     post_ln_res: bool, B: int, S: int, H: int, nh: int, slab: Tensor) -> None:
+    d.B, d.S, d.H, d.nh = B, S, H, nh
+    d.eps, d.post_ln_res, d.dtype = float(eps), int(post_ln_res), dt_code(x2.dtype)
+    for name, t in zip(_lib.BLK_PARAMS, params):
+        setattr(d, name, t.data_ptr())
+    d.slopes = None if slopes is None else slopes.data_ptr()
+    d.kpos = mask.kpos.data_ptr() if (mask is not None and slopes is not None) else None
+    d.kvalid = None if mask is None else mask.kvalid.data_ptr()
+    d.first_valid = None if mask is None else mask.first_valid.data_ptr()
+    d.x = x2.data_ptr()
+    d.slab = slab.data_ptr()
+
+
+def bloom_block_fwd(x2: Tensor, params, mask: Optional[MaskInfo], slopes: Optional[Tensor], eps: float, post_ln_res: bool,
+                    B: int, S: int, nh: int) -> BlockActs:
+    """modeling_bloom.py:142-159 for x2 [B*S, H]; `params` = the 12 block parameters in _lib.BLK_PARAMS order, weight
+    matrices already in the compute dtype.  One library call; returns the saved activations (whose `.out` is the result)."""
+    _need_cuda(x2, *params)
+    H = x2.shape[1]
+    acts = BlockActs()
+    acts.B, acts.S, acts.H, acts.nh, acts.dtype = B, S, H, nh, x2.dtype
+    acts.lay = block_layout(B, S, H, nh, x2.dtype)
+    acts.slab = torch.empty(acts.lay.bytes, dtype=torch.uint8, device=x2.device)
+    d = _lib.BloomBlock()
+    _fill_block_desc(d, x2, params, mask, slopes, eps, post_ln_res, B, S, H, nh, acts.slab)
+    check(_lib.load().ctmi_bloom_block_fwd(C.byref(d), _stream()), "bloom_block_fwd")
+    return acts
+
+
+def bloom_block_bwd(acts: BlockActs, x2: Tensor, params, mask: Optional[MaskInfo], slopes: Optional[Tensor], eps: float,
+                    post_ln_res: bool, dout2: Tensor, use_side_stream: bool = True):
+    """Backward of bloom_block_fwd -> (dx [T,H] in the compute dtype, the 12 fp32 parameter gradients in BLK_PARAMS order)."""
+    _need_cuda(x2, dout2)
+    B, S, H, nh = acts.B, acts.S, acts.H, acts.nh
+    dev = x2.device
+    d = _lib.BloomBlock()
+    _fill_block_desc(d, x2, params, mask, slopes, eps, post_ln_res, B, S, H, nh, acts.slab)
+    g = _lib.BloomBlockGrads()
+    dx = torch.empty_like(x2)
+    grads = [torch.empty(p.shape, dtype=torch.float32, device=dev) for p in params]
+    g.dout, g.dx = dout2.data_ptr(), dx.data_ptr()
+    for name, t in zip(_lib.BLK_PARAMS, grads):
+        setattr(g, "d" + name, t.data_ptr())
+    ws = _block_ws(dev, acts.lay.bwd_ws_bytes)
+    g.ws, g.ws_bytes = ws.data_ptr(), ws.numel()
+    sk = _splitk_ws(dev)
+    g.splitk_ws, g.splitk_ws_bytes = sk.data_ptr(), sk.numel() * 4
+    if use_side_stream:
+        side = side_stream(dev)
+        with torch.cuda.stream(side):
+            sk2 = _splitk_ws(dev)
+        g.side_stream = side.cuda_stream
+        g.side_splitk_ws, g.side_splitk_ws_bytes = sk2.data_ptr(), sk2.numel() * 4
+    check(_lib.load().ctmi_bloom_block_bwd(C.byref(d), C.byref(g), _stream()), "bloom_block_bwd")
+    return dx, grads
+
+
 # ------------------------------------------------------------------------------------------------ utilities
 def cast(src: Tensor, dtype: torch.dtype, out: Optional[Tensor] = None) -> Tensor:
     _need_cuda(src)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CTMI_ABI_VERSION 1
+#define CTMI_ABI_VERSION 2
 
 enum ctmi_dtype { CTMI_F32 = 0, CTMI_BF16 = 1 };
 enum ctmi_status { CTMI_OK = 0, CTMI_ERR_ARG = -1, CTMI_ERR_LAUNCH = -2, CTMI_ERR_UNSUPPORTED = -3 };
@@ -130,6 +130,16 @@ int ctmi_ce_bwd(const void* logits, int64_t ld, const int64_t* labels, const flo
                 const float* gout /* device scalar or NULL = 1 */, void* dlogits, int64_t ldd,
                 int64_t N, int64_t C, int64_t seq, int64_t shift, int64_t ignore_index, int dtype, void* stream);
 
+/* Training path: loss and dlogits in ONE pass over the logits (the loss forward of modeling_bloom.py:224-230 and the first
+ * step of loss.backward()): same arguments and results as ctmi_ce_fwd, plus dlogits written for an upstream gradient of 1
+ * (ctmi_ce_bwd with gout = NULL).  Rows must be 16-byte aligned (ld, ldd multiples of 16 bytes). */
+int ctmi_ce_fwd_bwd(const void* logits, int64_t ld, const int64_t* labels, float* row_lse, float* row_loss,
+                    float* loss_out, void* dlogits, int64_t ldd, int64_t N, int64_t C, int64_t seq, int64_t shift,
+                    int64_t ignore_index, int denom_mode, int64_t denom_rows, int dtype, void* stream);
+/* x[rows, cols] (ld) *= s_dev[0], skipped on the device when s_dev[0] == 1: applies the upstream gradient of the loss to a
+ * dlogits produced by ctmi_ce_fwd_bwd (autograd of `loss * k`, e.g. GradScaler.scale(loss), ft_bloom_DDP.py:124). */
+int ctmi_scale_if(void* x, int64_t ld, int64_t rows, int64_t cols, const float* s_dev, int dtype, void* stream);
+
 /* probability targets, the second branch of loss.py:43-46: loss = -sum t * log_softmax(x) (÷ denom_rows for 'mean': denom_mode 1;
  * 'sum': denom_mode 2).  target fp32 [N, C] (ldt).  row_tsum keeps sum_c t[n,c] for the backward:
  * dlogits = (softmax * row_tsum - target) * gout[0] * loss_out[1]. */
@@ -187,6 +197,56 @@ int ctmi_group_topk(const void* x, int64_t ld, const float* stats, const float* 
    masked_fill of TopKLogitsWrapper (logits_processor.py:35-56); fp32, out may alias x */
 int ctmi_scores_filter(const float* x, int64_t ld, float divisor, const float* thr, int64_t thr_stride, float fill, float* out,
                        int64_t ldo, int64_t rows, int64_t cols, void* stream);
+
+/* ---- partial-row reductions: dst[c] (+)= alpha * sum_{p < nparts} src[p * part_stride + c], c < n — up to
+ * CTMI_REDUCE_MAX_JOBS independent vectors per launch, fixed summation order (deterministic).  Used by the block backward
+ * below for the LayerNorm affine gradients and the Linear bias gradients (autograd of transformer.py:71-89 and of the biases
+ * at modeling_bloom.py:79,121,256,267). */
+#define CTMI_REDUCE_MAX_JOBS 16
+typedef struct ctmi_reduce_job {
+    const float* src; float* dst; int64_t n; int64_t part_stride; int32_t nparts; int32_t accumulate; float alpha; int32_t pad_;
+} ctmi_reduce_job;
+int ctmi_reduce_jobs(const ctmi_reduce_job* jobs /* host */, int count, void* stream);
+
+/* ---- one Bloom block, forward and backward, as ONE call each  (modeling_bloom.py:142-159 BloomBlock.forward =
+ * :76-124 BloomAttentionLayer + :255-271 BloomMLP, and its autograd).  The host makes one call per block instead of 7 / 17
+ * kernel-level calls; the launch sequence (LayerNorm -> QKV GEMM -> attention -> dense GEMM(+residual) -> LayerNorm ->
+ * h->4h GEMM(+GELU) -> 4h->h GEMM(+residual), and the hand-derived reverse) runs inside the library.
+ * All pointers are device pointers.  Weight matrices are in the compute dtype ([out,in] row-major, as torch.nn.Linear
+ * stores them), biases / LayerNorm parameters fp32.  Activations saved for the backward live in ONE caller-allocated slab
+ * whose layout ctmi_bloom_block_layout() defines (byte offsets, 256-byte aligned). */
+enum ctmi_block_slot {                  /* index into the offsets[] array filled by ctmi_bloom_block_layout */
+    CTMI_BLK_LN1 = 0, CTMI_BLK_MEAN1, CTMI_BLK_RSTD1, CTMI_BLK_QKV, CTMI_BLK_ATT, CTMI_BLK_STAT_M, CTMI_BLK_STAT_L,
+    CTMI_BLK_H1, CTMI_BLK_MEAN2, CTMI_BLK_RSTD2, CTMI_BLK_LN2, CTMI_BLK_U, CTMI_BLK_G, CTMI_BLK_OUT, CTMI_BLK_NSLOTS
+};
+typedef struct ctmi_bloom_block {
+    int64_t B, S, H, nh;
+    float eps; int32_t post_ln_res;     /* apply_residual_connection_post_layernorm (modeling_bloom.py:145-148,157) */
+    int32_t dtype; int32_t pad_;
+    const float *ln1_w, *ln1_b; const void* wqkv; const float* bqkv; const void* wd; const float* bd;
+    const float *ln2_w, *ln2_b; const void* w1; const float* b1; const void* w2; const float* b2;
+    const float* slopes;                /* [nh] ALiBi slopes */
+    const float* kpos; const int32_t* kvalid; const int32_t* first_valid;   /* ctmi_mask_prep outputs */
+    const void* x;                      /* block input [B*S, H] */
+    void* slab;                         /* saved activations + block output, ctmi_bloom_block_layout bytes */
+} ctmi_bloom_block;
+/* fills offsets[CTMI_BLK_NSLOTS] (bytes from the slab base) and returns the slab size in bytes */
+int64_t ctmi_bloom_block_layout(int64_t B, int64_t S, int64_t H, int64_t nh, int dtype, int64_t* offsets /* host */);
+int ctmi_bloom_block_fwd(const ctmi_bloom_block* blk /* host */, void* stream);
+
+typedef struct ctmi_bloom_block_grads {
+    const void* dout;                   /* gradient of the block output [B*S, H], compute dtype */
+    void* dx;                           /* gradient of the block input  [B*S, H], compute dtype */
+    float *dln1_w, *dln1_b, *dwqkv, *dbqkv, *dwd, *dbd, *dln2_w, *dln2_b, *dw1, *db1, *dw2, *db2;   /* fp32, overwritten */
+    void* ws; int64_t ws_bytes;         /* scratch of >= ctmi_bloom_block_bwd_ws() bytes (intermediate gradients, partial rows) */
+    void* splitk_ws; int64_t splitk_ws_bytes;   /* optional split-K slabs for the weight-gradient GEMMs (see ctmi_gemm) */
+    void* side_stream;                  /* optional second hipStream_t: weight/bias gradients run there, concurrently with the
+                                           data-gradient chain; joined back into `stream` before the call returns (host-side
+                                           enqueue: the call itself never blocks) */
+    void* side_splitk_ws; int64_t side_splitk_ws_bytes;
+} ctmi_bloom_block_grads;
+int64_t ctmi_bloom_block_bwd_ws(int64_t B, int64_t S, int64_t H, int64_t nh, int dtype);
+int ctmi_bloom_block_bwd(const ctmi_bloom_block* blk /* host */, const ctmi_bloom_block_grads* gr /* host */, void* stream);
 
 /* ---- hardware probe (diagnostics: dumps MFMA / LDS-transpose lane layouts into out[]; used by tests only) */
 int ctmi_probe(int which, const float* in /* device */, float* out /* device, 256 floats */, void* stream);

@@ -327,11 +327,97 @@ def sgd_step(params, grads, bufs, shadows, *, lr, momentum, dampening, weight_de
         p.sub_(lr * gg)
 
 
+def ce_fwd_bwd(logits2d, labels, seq, shift, ignore_index=-100, denom_mode=0, denom_rows=0):
+    loss_out, lse = ce_fwd(logits2d, labels, seq, shift, ignore_index, denom_mode, denom_rows)
+    return loss_out, lse, ce_bwd(logits2d, labels, lse, loss_out, None, seq, shift, ignore_index)
+
+
+def ce_fused_ok(logits2d):
+    return logits2d.stride(1) == 1 and logits2d.stride(0) == logits2d.shape[1]
+
+
+def scale_if_(x2d, s_dev):
+    if float(s_dev[0]) != 1.0:
+        x2d.copy_((x2d.float() * s_dev[0]).to(x2d.dtype))
+    return x2d
+
+
+class BlockActs:
+    """Emulated counterpart of ops.BlockActs: the saved activations as plain tensors."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def _fused_desc(B, S, nh, hd):
+    from cleantransformer_amd import ops
+    return ops.fused_qkv_desc(B, S, nh, hd, causal=S > 1)
+
+
+def bloom_block_fwd(x2, params, mask, slopes, eps, post_ln_res, B, S, nh, K=None):
+    """The kernel sequence ctmi_bloom_block_fwd issues (csrc/block.hip), on the emulated kernels — or, with K =
+    cleantransformer_amd.ops, on the individually verified HIP kernels (the -m gpu tests check the one-call form against it)."""
+    K = K or _THIS
+    layernorm_fwd, gemm, attn_fwd = K.layernorm_fwd, K.gemm, K.attn_fwd
+    ln1_w, ln1_b, wqkv, bqkv, wd, bd, ln2_w, ln2_b, w1, b1, w2, b2 = params
+    T, H = x2.shape
+    hd = H // nh
+    cd = x2.dtype
+    ln1, mean1, rstd1 = layernorm_fwd(x2, ln1_w, ln1_b, eps)
+    qkv = gemm(ln1, H, False, wqkv, H, False, T, 3 * H, H, bias=bqkv)
+    desc = _fused_desc(B, S, nh, hd)
+    att = torch.empty((T, H), dtype=cd, device=x2.device)
+    stat_m, stat_l = attn_fwd(qkv, qkv[:, hd:], qkv[:, 2 * hd:], att, desc, slopes, mask)
+    h1 = gemm(att, H, False, wd, H, False, T, H, H, bias=bd, residual=ln1 if post_ln_res else x2)
+    ln2, mean2, rstd2 = layernorm_fwd(h1, ln2_w, ln2_b, eps)
+    u = torch.empty((T, 4 * H), dtype=cd, device=x2.device)
+    g = gemm(ln2, H, False, w1, H, False, T, 4 * H, H, bias=b1, epilogue=1, aux_out=u)
+    out = gemm(g, 4 * H, False, w2, 4 * H, False, T, H, 4 * H, bias=b2, residual=ln2 if post_ln_res else h1)
+    return BlockActs(B=B, S=S, H=H, nh=nh, dtype=cd, desc=desc, ln1=ln1, mean1=mean1, rstd1=rstd1, qkv=qkv, att=att, stat_m=stat_m,
+                     stat_l=stat_l, h1=h1, mean2=mean2, rstd2=rstd2, ln2=ln2, u=u, g=g, out=out)
+
+
+def bloom_block_bwd(a, x2, params, mask, slopes, eps, post_ln_res, dout2, use_side_stream=True, K=None):
+    """The kernel sequence ctmi_bloom_block_bwd issues (csrc/block.hip), on the emulated kernels (or on K = ops, see above)."""
+    K = K or _THIS
+    layernorm_bwd, gemm, attn_bwd, colsum = K.layernorm_bwd, K.gemm, K.attn_bwd, K.colsum
+    ln1_w, ln1_b, wqkv, bqkv, wd, bd, ln2_w, ln2_b, w1, b1, w2, b2 = params
+    T, H = x2.shape
+    hd = H // a.nh
+    post = post_ln_res
+
+    def dgrad(dy, w, **kw):
+        return gemm(dy, dy.shape[1], False, w, w.shape[1], True, T, w.shape[1], dy.shape[1], **kw)
+
+    def wgrad(dy, x):
+        return gemm(dy, dy.shape[1], True, x, x.shape[1], True, dy.shape[1], x.shape[1], T, out_f32=True)
+
+    dw2, db2 = wgrad(dout2, a.g), colsum(dout2)
+    du = dgrad(dout2, w2, epilogue=2, aux_in=a.u)
+    dw1, db1 = wgrad(du, a.ln2), colsum(du)
+    dln2 = dgrad(du, w1, residual=dout2 if post else None)
+    dh1, dln2_w, dln2_b = layernorm_bwd(dln2, a.h1, ln2_w, a.mean2, a.rstd2, dres=None if post else dout2)
+    dwd, dbd = wgrad(dh1, a.att), colsum(dh1)
+    datt = dgrad(dh1, wd)
+    dqkv = torch.empty_like(a.qkv)
+    attn_bwd(a.qkv, a.qkv[:, hd:], a.qkv[:, 2 * hd:], a.att, datt, a.stat_m, a.stat_l, dqkv, dqkv[:, hd:], dqkv[:, 2 * hd:], a.desc,
+             slopes, mask)
+    dwqkv, dbqkv = wgrad(dqkv, a.ln1), colsum(dqkv)
+    dln1 = dgrad(dqkv, wqkv, residual=dh1 if post else None)
+    dx, dln1_w, dln1_b = layernorm_bwd(dln1, x2, ln1_w, a.mean1, a.rstd1, dres=None if post else dh1)
+    return dx, [dln1_w, dln1_b, dwqkv, dbqkv, dwd, dbd, dln2_w, dln2_b, dw1, db1, dw2, db2]
+
+
+import sys as _sys
+
+_THIS = _sys.modules[__name__]
+
+
 def install(monkeypatch):
     """Patch cleantransformer_amd.ops in place (pytest's monkeypatch undoes it after the test)."""
     from cleantransformer_amd import ops
     for name in ("layernorm_fwd", "layernorm_bwd", "gemm", "colsum", "MaskInfo", "attn_fwd", "attn_bwd", "embed_fwd", "embed_bwd",
-                 "ce_fwd", "ce_bwd", "ce_soft_fwd", "ce_soft_bwd", "cast", "transpose_cast", "sumsq", "scale_", "argmax_lastdim", "row_lse", "group_topk",
+                 "ce_fwd", "ce_bwd", "ce_fwd_bwd", "ce_fused_ok", "scale_if_", "bloom_block_fwd", "bloom_block_bwd", "ce_soft_fwd", "ce_soft_bwd", "cast", "transpose_cast", "sumsq", "scale_", "argmax_lastdim", "row_lse", "group_topk",
                  "scores_filter", "amp_unscale", "amp_update", "adamw_step", "sgd_step"):
         monkeypatch.setattr(ops, name, globals()[name])
     monkeypatch.setattr(ops, "_need_cuda", lambda *a: None)
