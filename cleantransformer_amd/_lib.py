@@ -60,6 +60,8 @@ PROTOTYPES = {
     "ctmi_layernorm_bwd_ws": (i64, [i64, i64]),
     "ctmi_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i64, i64, i32, vp]),
     "ctmi_gemm": (i32, [vp, i64, i32, vp, i64, i32, vp, i64, i64, i64, i64, f32, i32, vp, vp, i32, vp, vp, i32, i32, vp, i64, vp]),
+    "ctmi_set_launch_policy": (i32, [i32, i32]),
+    "ctmi_get_launch_policy": (i32, [C.POINTER(i32), C.POINTER(i32)]),
     "ctmi_colsum": (i32, [vp, i64, vp, i32, vp, i64, i64, i32, vp]),
     "ctmi_colsum_ws": (i64, [i64, i64]),
     "ctmi_attn_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(AttnDesc), i32, vp]),

@@ -16,6 +16,12 @@
 #include "common.h"
 #include <type_traits>
 #include "mma.h"
+#include <atomic>
+// translation-unit split (see the note above ctmi_gemm_bf16_nt below)
+#ifndef CTMI_GEMM_PART
+#define CTMI_GEMM_PART (-1)
+#endif
+#define CTMI_GEMM_HAS(p) (CTMI_GEMM_PART == -1 || CTMI_GEMM_PART == (p))
 
 // Ping-pong epilogue re-layout.  0 (default): 128-row tiles (WM = 4) re-layout across lanes with v_permlane16_swap, 256-row tiles
 // through the per-wave LDS patches; 1: LDS patches everywhere (A/B builds).  Same-box A/B of "cross-lane everywhere" against
@@ -981,6 +987,7 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ s
 }
 
 static bool shared_mode();
+static int reserved_cus();
 
 template <typename TO, bool AK, bool BKM, int EPI, int WM, int WGN, bool PP = false, bool RES = false>
 static void glds_launch(GemmArgs& g, hipStream_t st) {
@@ -989,14 +996,14 @@ static void glds_launch(GemmArgs& g, hipStream_t st) {
     const int64_t nwork = cdiv64(g.M, BM) * cdiv64(g.N, BN) * g.splits;
     // persistent launch: one resident workgroup per occupancy slot (256 CUs x workgroups that fit a CU's 160 KiB LDS),
     // each walking work items bid, bid+G, ... with its DMA stream prefetching across item boundaries
-    static int persist = -1;
-    if (persist < 0) { const char* e = getenv("CTMI_GEMM_PERSIST"); persist = e ? atoi(e) : (shared_mode() ? 0 : 1); }
+    static int persist_env = -2;                                            // CTMI_GEMM_PERSIST overrides the policy (experiments)
+    if (persist_env == -2) { const char* e = getenv("CTMI_GEMM_PERSIST"); persist_env = e ? atoi(e) : -1; }
+    const int persist = persist_env >= 0 ? persist_env : (shared_mode() ? 0 : 1);
     // CTMI_GEMM_RESERVE_CUS = R leaves R of the 256 CUs out of every persistent launch.  A persistent GEMM owns each CU it
     // runs on until it ends (all LDS, all VGPRs), so with R = 0 a concurrent RCCL all-reduce kernel makes no progress for
     // the length of the GEMM (up to ~4 ms for the LM head); data-parallel runs set R ~ 16 so communication streams
     // continuously under backward (bench.py does for --gpus > 1).
-    static int reserve = -1;
-    if (reserve < 0) { const char* e = getenv("CTMI_GEMM_RESERVE_CUS"); reserve = e ? std::max(0, std::min(128, atoi(e))) : 0; }
+    const int reserve = reserved_cus();
     const int64_t per_cu = (int64_t)std::min<size_t>((size_t)(WGN == 4 ? 1 : 8), (160 * 1024) / lds);
     const int64_t slots = (256 - reserve) / 8 * 8 * per_cu;                  // multiple of 8: the XCD-aware item order needs it
     const unsigned grid = (unsigned)((persist && nwork > slots) ? slots : nwork);
@@ -1021,11 +1028,37 @@ static void glds_launch(GemmArgs& g, hipStream_t st) {
 // balances), (b) keeps the one-workgroup-per-CU ping-pong tiles for launches of >= 2048 items only (the LM head), with an
 // 8-way split of the K = V dgrad, and (c) runs the layer GEMMs on the 128x128 / 256x128 tiles (2-3 workgroups per CU,
 // which also co-reside with a small foreign workgroup).
+// The policy is process state set through ctmi_set_launch_policy() (the data-parallel wrapper calls it whenever it is
+// constructed or re-armed, so a model that already ran a GEMM before being wrapped still switches); the environment variables
+// CTMI_GEMM_SHARED / CTMI_GEMM_RESERVE_CUS only provide the initial value.
+#if CTMI_GEMM_HAS(0)
+std::atomic<int> g_ctmi_policy_shared{-1}, g_ctmi_policy_reserve{-1};    // ONE copy for all translation units of this file
+#else
+extern std::atomic<int> g_ctmi_policy_shared, g_ctmi_policy_reserve;
+#endif
 static bool shared_mode() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("CTMI_GEMM_SHARED"); v = (e && e[0] != '0') ? 1 : 0; }
+    int v = g_ctmi_policy_shared.load(std::memory_order_relaxed);
+    if (v < 0) { const char* e = getenv("CTMI_GEMM_SHARED"); v = (e && e[0] != '0') ? 1 : 0; g_ctmi_policy_shared.store(v, std::memory_order_relaxed); }
     return v == 1;
 }
+static int reserved_cus() {
+    int v = g_ctmi_policy_reserve.load(std::memory_order_relaxed);
+    if (v < 0) { const char* e = getenv("CTMI_GEMM_RESERVE_CUS"); v = e ? std::max(0, std::min(128, atoi(e))) : 0; g_ctmi_policy_reserve.store(v, std::memory_order_relaxed); }
+    return v;
+}
+#if CTMI_GEMM_HAS(0)
+extern "C" int ctmi_set_launch_policy(int shared, int reserve_cus) {
+    CTMI_REQUIRE(reserve_cus >= 0 && reserve_cus <= 128, "set_launch_policy: reserve_cus must be in [0, 128]");
+    g_ctmi_policy_shared.store(shared ? 1 : 0, std::memory_order_relaxed);
+    g_ctmi_policy_reserve.store(reserve_cus, std::memory_order_relaxed);
+    return CTMI_OK;
+}
+extern "C" int ctmi_get_launch_policy(int* shared, int* reserve_cus) {
+    if (shared) *shared = shared_mode() ? 1 : 0;
+    if (reserve_cus) *reserve_cus = reserved_cus();
+    return CTMI_OK;
+}
+#endif
 
 static void pick_tile(int64_t M, int64_t N, int64_t K, bool wgrad, bool bkm, int epi, int max_splits, int& tile, int& splits) {
     static int force = -2, force_split = -2;
@@ -1136,10 +1169,6 @@ static int gemm_launch(GemmArgs& g, bool fast, hipStream_t st) {
 // This file is compiled as FOUR translation units (-DCTMI_GEMM_PART=0..3, see _build.py) so the bf16 kernel instantiations
 // — three operand layouts x epilogues x five tile shapes — build in parallel: part 0 = C entry point + fp32 (parity mode),
 // parts 1/2/3 = bf16 forward (NT) / data-gradient (NN) / weight-gradient (TN) families.  Undefined = everything in one unit.
-#ifndef CTMI_GEMM_PART
-#define CTMI_GEMM_PART (-1)
-#endif
-#define CTMI_GEMM_HAS(p) (CTMI_GEMM_PART == -1 || CTMI_GEMM_PART == (p))
 int ctmi_gemm_bf16_nt(GemmArgs& g, int epi, bool fast, hipStream_t st);
 int ctmi_gemm_bf16_nn(GemmArgs& g, int epi, bool fast, hipStream_t st);
 int ctmi_gemm_bf16_tn(GemmArgs& g, int epi, bool fast, hipStream_t st);

@@ -219,6 +219,9 @@ class EmbedFn(torch.autograd.Function):
         ctx.vh, ctx.tie, ctx.err = tuple(weight.shape), tie, err
         if tie is not None:
             tie.embed_wants = weight.requires_grad
+            sync = getattr(weight, "_ct_tied_sync", None)               # set by trainer/ddp.py on the shared [V,H] parameter
+            if sync is not None and weight.requires_grad and sync.owner.require_backward_grad_sync:
+                sync.announce(ids.numel(), weight.device)              # ranks agree on the row capacity of this step's exchange
         return out
 
     @staticmethod

@@ -502,6 +502,29 @@ def scale_copy(src: Tensor, dst: Tensor, s: float) -> Tensor:
     return dst
 
 
+def set_launch_policy(shared: bool, reserve_cus: Optional[int] = None) -> None:
+    """GEMM launch policy (include/ctmi355.h ctmi_set_launch_policy): shared=True while RCCL kernels hold CUs under backward."""
+    lib = _lib.load()
+    if reserve_cus is None:
+        r = C.c_int(0)
+        lib.ctmi_get_launch_policy(None, C.byref(r))
+        reserve_cus = r.value
+    check(lib.ctmi_set_launch_policy(int(bool(shared)), int(reserve_cus)), "set_launch_policy")
+
+
+def get_launch_policy() -> Tuple[bool, int]:
+    sh, r = C.c_int(0), C.c_int(0)
+    _lib.load().ctmi_get_launch_policy(C.byref(sh), C.byref(r))
+    return bool(sh.value), r.value
+
+
+def invalidate_compute_copies(p: Tensor) -> None:
+    """Forget the cached compute-dtype copies of a parameter whose storage was rewritten behind the version counter."""
+    for a in ("_ct_shadow", "_ct_shadow_pad", "_ct_shadow_ver", "_ct_shadow_ptr", "_ct_wt", "_ct_wt_ver", "_ct_wt_ptr"):
+        if hasattr(p, a):
+            delattr(p, a)
+
+
 def argmax_lastdim(x2d: Tensor) -> Tensor:
     rows, cols = x2d.shape
     out = torch.empty(rows, dtype=torch.int64, device=x2d.device)

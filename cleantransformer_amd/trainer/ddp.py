@@ -63,6 +63,9 @@ class _TiedGradSync:
         self.work = None
         self.active = False
         self.steps = 0                                               # how many backward passes took the early path
+        self._tmax = None                                            # agreed row capacity of this step's exchange (announce)
+        self._announced = False
+        self._tbuf = self._thost = self._tstream = self._tevent = None
 
     def prescale(self, weight: torch.nn.Parameter):
         """1/world if this backward pass reduces the dense part early (the LM-head weight-gradient GEMM then applies it as
@@ -73,6 +76,46 @@ class _TiedGradSync:
         if not o.require_backward_grad_sync or single or weight.grad is not None:
             return None
         return 1.0 / o.world_size
+
+    def announce(self, n_tokens: int, device) -> None:
+        """Called from the embedding forward (every rank, every forward that will be synchronised): agree on max_r T_r, the
+        row capacity of this step's exchange.  The reference's collate pads each rank's batch to ITS longest sample
+        (examples/ft_bloom_DDP.py:45-60, padding=True), so T = B*S differs between ranks; all_gather needs equal extents.
+        The maximum is taken by a tiny all-reduce issued now and read at the end of backward; on RCCL it is copied to pinned
+        host memory on a side stream, so reading it never waits for the compute stream."""
+        o = self.owner
+        self._tmax = None
+        self._announced = True
+        if o.world_size == 1:
+            self._tmax = int(n_tokens)
+            return
+        if dist.get_backend(o.process_group) != "nccl" or not torch.device(device).type == "cuda":
+            t = torch.tensor([int(n_tokens)], dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=o.process_group)
+            self._tmax = int(t[0])
+            return
+        if self._tbuf is None or self._tbuf.device != torch.device(device):
+            self._tbuf = torch.empty(1, dtype=torch.int64, device=device)
+            self._thost = torch.empty(1, dtype=torch.int64, pin_memory=True)
+            self._tstream = torch.cuda.Stream(device=device)
+            self._tevent = torch.cuda.Event()
+        self._tbuf.fill_(int(n_tokens))
+        work = dist.all_reduce(self._tbuf, op=dist.ReduceOp.MAX, group=o.process_group, async_op=True)
+        with torch.cuda.stream(self._tstream):
+            work.wait()                                              # the side stream waits for the collective; the host does not
+            self._thost.copy_(self._tbuf, non_blocking=True)
+            self._tevent.record(self._tstream)
+
+    def _row_capacity(self, n_local: int) -> int:
+        if not self._announced:
+            raise RuntimeError("tied-gradient row exchange: the embedding forward of this step did not announce its row count "
+                               "(was the forward run under no_sync() and the backward outside of it?)")
+        if self._tmax is None:
+            self._tevent.synchronize()
+            self._tmax = int(self._thost[0])
+        if self._tmax < n_local:
+            raise RuntimeError(f"tied-gradient row exchange: announced capacity {self._tmax} < local rows {n_local}")
+        return self._tmax
 
     def begin(self, dw: torch.Tensor) -> None:
         """dw = dW_lm_head / world (contiguous fp32 [V,H]): start its all-reduce now, under the rest of backward."""
@@ -86,10 +129,20 @@ class _TiedGradSync:
         W = o.world_size
         ids = ids.reshape(-1).contiguous()
         drows = drows.contiguous()
-        all_ids = torch.empty((W,) + tuple(ids.shape), dtype=ids.dtype, device=ids.device)
-        all_rows = torch.empty((W,) + tuple(drows.shape), dtype=drows.dtype, device=drows.device)
+        n, Hc = ids.numel(), drows.shape[-1]
+        cap = self._row_capacity(n)
+        if cap != n:
+            # pad to the agreed capacity: id -1 (the scatter kernel skips ids outside [0, V)) and zero rows
+            pid = torch.full((cap,), -1, dtype=ids.dtype, device=ids.device)
+            pid[:n] = ids
+            prow = torch.zeros((cap, Hc), dtype=drows.dtype, device=drows.device)
+            prow[:n] = drows.view(n, Hc)
+            ids, drows = pid, prow
+        drows = drows.view(cap, Hc)
+        all_ids = torch.empty((W, cap), dtype=ids.dtype, device=ids.device)
+        all_rows = torch.empty((W, cap, Hc), dtype=drows.dtype, device=drows.device)
         if ids.is_cuda and dist.get_backend(o.process_group) == "gloo":
-            # gloo has no device all_gather (debug configuration only: several ranks sharing one GPU); RCCL takes the direct path
+            # gloo has no device all_gather (several ranks sharing one GPU): stage through the host; RCCL takes the direct path
             hi, hr = ids.cpu(), drows.float().cpu()
             li, lr = [torch.empty_like(hi) for _ in range(W)], [torch.empty_like(hr) for _ in range(W)]
             dist.all_gather(li, hi, group=o.process_group)
@@ -104,7 +157,8 @@ class _TiedGradSync:
             dist.all_gather(list(all_rows.unbind(0)), drows, group=o.process_group)
         self.work.wait()
         self.work = None
-        _embed_scatter(all_rows.view(-1, drows.shape[-1]), all_ids.view(-1), dw, 1.0 / W)
+        self._tmax, self._announced = None, False
+        _embed_scatter(all_rows.view(-1, Hc), all_ids.view(-1), dw, 1.0 / W)
 
 
 def build_buckets(params: List[torch.nn.Parameter], bucket_cap_bytes: int, first_bucket_bytes: int = _MiB) -> List[List[int]]:
@@ -149,10 +203,7 @@ class DistributedDataParallel(torch.nn.Module):
         self.module = module
         self.process_group = process_group if process_group is not None else dist.group.WORLD
         self.world_size = dist.get_world_size(self.process_group)
-        if self.world_size > 1:
-            # the all-reduce kernels will hold CUs under backward: switch the GEMM launcher to its shared-GPU policy
-            # (csrc/gemm.hip shared_mode(); read once, at the first GEMM launch, so wrap the model before running it)
-            os.environ.setdefault("CTMI_GEMM_SHARED", "1")
+        self._arm_launch_policy()
         self.device_ids = device_ids
         self.broadcast_buffers = broadcast_buffers
         self.bucket_cap_mb = 25 if bucket_cap_mb is None else bucket_cap_mb
@@ -183,12 +234,26 @@ class DistributedDataParallel(torch.nn.Module):
         self._callback_queued = False
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad_ready) for p in self._params]
 
+    def _arm_launch_policy(self):
+        """world > 1: the all-reduce kernels will hold CUs under backward — switch the GEMM launcher to its shared-GPU policy
+        (ctmi_set_launch_policy; csrc/gemm.hip).  An explicit library call, re-made at every training forward, so it also
+        takes effect for a model that already ran GEMMs before it was wrapped (CTMI_DDP_LAUNCH_POLICY=0 leaves it alone)."""
+        if self.world_size > 1 and os.environ.get("CTMI_DDP_LAUNCH_POLICY", "1") != "0" and \
+                any(p.is_cuda for p in self.module.parameters()):
+            from .. import ops
+            if not ops.get_launch_policy()[0]:
+                ops.set_launch_policy(True)
+
     # ---------------------------------------------------------------- construction-time broadcast (rank 0 wins)
     def _sync_module_states(self):
         tensors = [p.data for p in self.module.parameters()]
         if self.broadcast_buffers:
             tensors += [b.data for b in self.module.buffers()]
         self._broadcast_coalesced(tensors)
+        # the broadcast wrote through .data (no version bump): drop compute-dtype copies cached by an earlier forward
+        from .. import ops
+        for p in self.module.parameters():
+            ops.invalidate_compute_copies(p)
 
     def _broadcast_coalesced(self, tensors, chunk_bytes: int = 256 * _MiB):
         seen, groups = set(), {}
@@ -278,7 +343,21 @@ class DistributedDataParallel(torch.nn.Module):
         finally:
             self.require_backward_grad_sync = old
 
+    def _reset_step_state(self):
+        """A backward pass that raised after its first gradient hook leaves the per-step bookkeeping half-way (the end-of-
+        backward callback never ran): start every training forward from a clean slate."""
+        self._callback_queued = False
+        for b in self._buckets:
+            b.pending = 0
+            b.work = None
+        if self._tied_sync is not None:
+            self._tied_sync.active = False
+            self._tied_sync.work = None
+
     def forward(self, *inputs, **kwargs):
+        if torch.is_grad_enabled():
+            self._reset_step_state()
+            self._arm_launch_policy()
         return self.module(*inputs, **kwargs)
 
     def bucket_summary(self):
@@ -291,18 +370,10 @@ def _embed_scatter(rows: torch.Tensor, ids: torch.Tensor, dtable: torch.Tensor, 
 
 
 def _cast(src: torch.Tensor, dst: torch.Tensor) -> None:
-    if src.is_cuda:
-        from .. import ops
-        ops.cast(src, dst.dtype, out=dst)
-    else:                                                           # gloo / CPU: semantics tests only
-        dst.copy_(src)
+    from .. import ops
+    ops.cast(src, dst.dtype, out=dst)
 
 
 def _scale_copy(src: torch.Tensor, dst: torch.Tensor, s: float) -> None:
-    if src.is_cuda:
-        from .. import ops
-        ops.scale_copy(src, dst, s)
-    elif src.data_ptr() == dst.data_ptr():                          # gloo / CPU: semantics tests only
-        dst.mul_(s)
-    else:
-        torch.mul(src, s, out=dst)
+    from .. import ops
+    ops.scale_copy(src, dst, s)

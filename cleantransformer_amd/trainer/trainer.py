@@ -369,6 +369,7 @@ class Trainer():
         grad_norm = None
         norm_ws = torch.zeros(1, dtype=torch.float64, device=self.device) if self.device.type == "cuda" else None
         params = [p for p in self.model.parameters() if p.requires_grad]
+        need_zero = True
         for epoch in range(epochs_trained, num_train_epochs):
             self._fire("on_epoch_begin")
             if hasattr(getattr(loader, "sampler", None), "set_epoch"):
@@ -391,7 +392,9 @@ class Trainer():
                 window_end = total_batched_samples % ga == 0 or last_short
                 if window_start:
                     self._fire("on_step_begin")
-                    self.optimizer.zero_grad()              # once per window (see module docstring)
+                if need_zero:                               # once per window (see module docstring): set by EVERY window end,
+                    self.optimizer.zero_grad()              # including the short last window of an epoch (steps_in_epoch <= ga)
+                    need_zero = False
                 if not window_end and isinstance(model, DistributedDataParallel):
                     with model.no_sync():
                         tr_loss += self.training_step(model, inputs)
@@ -402,6 +405,7 @@ class Trainer():
                         grad_norm = clip_grad_norm_(params, args.max_grad_norm, norm_ws)
                     self.optimizer.step()
                     self.lr_scheduler.step()
+                    need_zero = True                        # applied gradients must never reach the next optimizer step
                     self.state.global_step += 1
                     self.state.epoch = epoch + (step + 1 + steps_skipped) / steps_in_epoch
                     self._default_flow()

@@ -70,6 +70,13 @@ int ctmi_gemm(const void* A, int64_t lda, int a_kmajor, const void* B, int64_t l
               const void* aux_in, void* aux_out, int out_f32, int dtype,
               void* workspace, int64_t workspace_bytes, void* stream);
 
+/* GEMM launch policy (process-wide).  shared = 0: the GPU is ours — persistent launches sized to the 256 CUs, one-workgroup-
+ * per-CU ping-pong tiles.  shared = 1: another long-running kernel holds CUs under our GEMMs (the RCCL all-reduce of a
+ * data-parallel job, trainer DDP at examples/ft_bloom_DDP.py:99): no persistent launches, 2-3 workgroups per CU for the
+ * layer GEMMs.  reserve_cus: CUs left out of persistent launches.  Initial values: CTMI_GEMM_SHARED / CTMI_GEMM_RESERVE_CUS. */
+int ctmi_set_launch_policy(int shared, int reserve_cus);
+int ctmi_get_launch_policy(int* shared /* host, may be NULL */, int* reserve_cus /* host, may be NULL */);
+
 /* column sum: out[n] (+)= sum_m x[m,n]  — bias gradients (autograd of the Linear biases). */
 int ctmi_colsum(const void* x, int64_t ld, float* out, int accumulate, float* ws, int64_t M, int64_t N, int dtype, void* stream);
 int64_t ctmi_colsum_ws(int64_t M, int64_t N);

@@ -151,7 +151,10 @@ def embed_fwd(table, ids, err_flag=None):
 
 
 def embed_bwd(dout, ids, dtable, scale=1.0):
-    dtable.index_add_(0, ids.reshape(-1), dout.float().reshape(-1, dtable.shape[1]) * torch.tensor(scale, dtype=torch.float32))
+    flat = ids.reshape(-1)
+    ok = (flat >= 0) & (flat < dtable.shape[0])                      # the kernel skips ids outside [0, V) (padding rows of the DDP exchange)
+    rows = dout.float().reshape(-1, dtable.shape[1])
+    dtable.index_add_(0, flat[ok], rows[ok] * torch.tensor(scale, dtype=torch.float32))
 
 
 def _targets(labels, N, seq, shift, ignore):
@@ -214,6 +217,11 @@ def sumsq(x, out=None, accumulate=False):
 def scale_(x, s, s_dev=None):
     x.mul_(s * (float(s_dev[0]) if s_dev is not None else 1.0))
     return x
+
+
+def scale_copy(src, dst, s):
+    torch.mul(src, s, out=dst)
+    return dst
 
 
 def argmax_lastdim(x2d):
@@ -417,7 +425,7 @@ def install(monkeypatch):
     """Patch cleantransformer_amd.ops in place (pytest's monkeypatch undoes it after the test)."""
     from cleantransformer_amd import ops
     for name in ("layernorm_fwd", "layernorm_bwd", "gemm", "colsum", "MaskInfo", "attn_fwd", "attn_bwd", "embed_fwd", "embed_bwd",
-                 "ce_fwd", "ce_bwd", "ce_fwd_bwd", "ce_fused_ok", "scale_if_", "bloom_block_fwd", "bloom_block_bwd", "ce_soft_fwd", "ce_soft_bwd", "cast", "transpose_cast", "sumsq", "scale_", "argmax_lastdim", "row_lse", "group_topk",
+                 "ce_fwd", "ce_bwd", "ce_fwd_bwd", "ce_fused_ok", "scale_if_", "bloom_block_fwd", "bloom_block_bwd", "ce_soft_fwd", "ce_soft_bwd", "cast", "transpose_cast", "sumsq", "scale_", "scale_copy", "argmax_lastdim", "row_lse", "group_topk",
                  "scores_filter", "amp_unscale", "amp_update", "adamw_step", "sgd_step"):
         monkeypatch.setattr(ops, name, globals()[name])
     monkeypatch.setattr(ops, "_need_cuda", lambda *a: None)

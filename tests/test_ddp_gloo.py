@@ -94,7 +94,6 @@ def _worker(rank, world, port, bucket_mb, ret):
         ret["early_in_accum"] = early_in_accum
         for n, a in accum.items():
             ret["acc_" + n] = a
-        (l3, _, _), _ = ddp(input_ids=ids, attention_mask=am, labels=ids.clone())     # recompute synced grads for export
     for p in m.parameters():
         p.grad = None
     (l3, _, _), _ = ddp(input_ids=ids, attention_mask=am, labels=ids.clone())
@@ -248,3 +247,91 @@ def test_ddp_bf16_bucket_communication_is_opt_in_and_within_bf16_rounding():
             else:                                                  # the tied gradient took the fp32 early path
                 assert np.allclose(a, b, rtol=1e-4, atol=1e-8), name
     assert worst_default_bar > 1e-4                                 # i.e. the bf16 wire really was used for the bucketed gradients
+
+
+def _uneven_worker(rank, world, port, ret):
+    """Ranks with DIFFERENT sequence lengths (the reference's collate pads per rank), and a backward that raises mid-way."""
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import copy
+    import cpu_kernel_emulation as emu
+    from oracle import bloom_ref as R
+    from cleantransformer_amd.models.modeling_bloom import BloomConfig, BloomForCausalLM
+    from cleantransformer_amd.trainer.ddp import DistributedDataParallel as DDP
+    emu.install(_Patch())
+    V, H, L, nh, B = 211, 64, 2, 8, 2
+    seqs = [16, 11, 7, 13][:world]                               # T = B*S differs on every rank
+    m = BloomForCausalLM(BloomConfig(vocab_size=V, hidden_size=H, n_layer=L, num_attention_heads=nh))
+    m._tie_weight()
+    sd = dict(R.det_init(R.BloomShape(V, H, L, nh)))
+    sd["lm_head.weight"] = sd["bloom.word_embeddings.weight"]
+    m.load_state_dict(sd)
+    m._tie_weight()
+    plain = copy.deepcopy(m)
+    plain._tie_weight()
+    ddp = DDP(m, device_ids=None, bucket_cap_mb=0.05).train()
+    batches = [torch.randint(0, V, (B, s), generator=torch.Generator().manual_seed(40 + r)) for r, s in enumerate(seqs)]
+    # expected: the mean over ranks of each rank's local gradient, computed without the wrapper
+    want = None
+    for r, ids in enumerate(batches):
+        for p in plain.parameters():
+            p.grad = None
+        (l, _, _), _ = plain(input_ids=ids, attention_mask=torch.ones_like(ids), labels=ids.clone())
+        l.backward()
+        g = torch.cat([p.grad.reshape(-1) for p in plain.parameters()]) / world
+        want = g if want is None else want + g
+    ids = batches[rank]
+
+    def run():
+        for p in m.parameters():
+            p.grad = None
+        (loss, _, _), _ = ddp(input_ids=ids, attention_mask=torch.ones_like(ids), labels=ids.clone())
+        loss.backward()
+        return torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+
+    early0 = ddp._tied_sync.steps
+    got = run()
+    ok_uneven = bool(torch.allclose(got, want, rtol=1e-4, atol=1e-8))
+    took_early = ddp._tied_sync.steps - early0
+    # a backward that raises after the first gradient hooks fired (every rank raises at the same point: the collectives that
+    # were issued match up), then a normal step: the wrapper must start from a clean slate
+    victim = m.bloom.blocks[0].mlp.dense_h_to_4h.weight
+
+    def boom(g):
+        raise RuntimeError("boom")
+    h = victim.register_hook(boom)
+    raised = False
+    for p in m.parameters():
+        p.grad = None
+    try:
+        (loss, _, _), _ = ddp(input_ids=ids, attention_mask=torch.ones_like(ids), labels=ids.clone())
+        loss.backward()
+    except RuntimeError as e:
+        raised = "boom" in str(e)
+    h.remove()
+    for b in ddp._buckets:                                       # drain what the failed pass left in flight
+        if b.work is not None:
+            b.work.wait()
+    if ddp._tied_sync.work is not None:
+        ddp._tied_sync.work.wait()
+    dist.barrier()
+    again = run()
+    ok_after_failure = bool(torch.allclose(again, want, rtol=1e-4, atol=1e-8))
+    if rank == 0:
+        ret["ok_uneven"], ret["took_early"], ret["raised"], ret["ok_after_failure"] = ok_uneven, took_early, raised, ok_after_failure
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_ddp_uneven_sequence_lengths_and_failed_backward_recovery(world):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_uneven_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert ret["took_early"] == 1, "the tied [V,H] gradient must still take its early dense + row-exchange path"
+    assert ret["ok_uneven"], "averaged gradients with rank-dependent T differ from the mean of the local gradients"
+    assert ret["raised"] and ret["ok_after_failure"]

@@ -133,3 +133,52 @@ def test_gpt2_medium_geometry_vs_oracle_fp32():
     for n, prm in m.named_parameters():
         a, b = float(prm.grad.double().norm()), float(grads_o[n].double().norm())
         assert abs(a - b) <= 1e-4 * b + 1e-9, (n, a, b)
+
+
+def test_gpt2_medium_seq2048_config3():
+    """BASELINE configs[3] at its STATED sequence length — GPT-2-medium (n_embd 1024, 16 heads, V 50257), n_ctx = S = 2048.
+    (a) 2 layers, fp32, B=1, one right-padded tail: loss / logits / per-parameter gradient norms against the oracle (pinned to the
+    reference at the tiny size); (b) all 24 layers, bf16, B=2: size-independent properties — causality of the logits (bit-exact),
+    a finite loss near ln V for a random-init model, and a descending loss over three AdamW steps."""
+    s = GR.GPTShape(50257, 1024, 2, 16, 2048, version="gpt2")
+    p = GR.det_init(s)
+    B, S = 1, 2048
+    ids = torch.randint(0, s.vocab_size, (B, S), generator=torch.Generator().manual_seed(12))
+    am = torch.ones(B, S, dtype=torch.long)
+    am[0, 1900:] = 0
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    loss_o, logits_o, _, grads_o = GR.loss_and_grads(p, s, ids, am)
+    m = build(s, params=p)
+    (loss, logits, _), _ = m(ids.to(DEV), attention_mask=am.to(DEV), labels=ids.to(DEV).clone())
+    loss.backward()
+    assert abs(float(loss) - float(loss_o)) <= 1e-5 * float(loss_o)
+    assert torch.equal(logits.argmax(-1).cpu(), logits_o.argmax(-1))
+    close("logits", logits[:, ::97, ::501], logits_o[:, ::97, ::501], 1e-4, 1e-5)
+    for n, prm in m.named_parameters():
+        a, b = float(prm.grad.double().norm()), float(grads_o[n].double().norm())
+        assert abs(a - b) <= 1e-4 * b + 1e-9, (n, a, b)
+    del m, logits_o, grads_o
+    # (b) full depth, bf16
+    from cleantransformer_amd.optimizer import AdamW
+    s24 = GR.GPTShape(50257, 1024, 24, 16, 2048, version="gpt2")
+    m = build(s24, params=GR.det_init(s24), cd="bf16")
+    B = 2
+    ids = torch.randint(0, s24.vocab_size, (B, S), generator=torch.Generator().manual_seed(13)).to(DEV)
+    am = torch.ones(B, S, dtype=torch.long, device=DEV)
+    with torch.no_grad():
+        (lg1, _), _ = m(ids, attention_mask=am)
+        ids2 = ids.clone()
+        ids2[:, 1500:] = (ids2[:, 1500:] + 1) % s24.vocab_size
+        (lg2, _), _ = m(ids2, attention_mask=am)
+    assert torch.equal(lg1[:, :1500], lg2[:, :1500]) and not torch.equal(lg1[:, 1500:], lg2[:, 1500:])
+    del lg1, lg2
+    opt = AdamW(m.parameters(), lr=1e-4, weight_decay=0.0, decoupled=True)
+    losses = []
+    for t in range(3):
+        (loss, _, _), _ = m(ids, attention_mask=am, labels=ids.clone())
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert all(math.isfinite(x) for x in losses) and losses[0] > losses[1] > losses[2], losses
+    assert 9.0 < losses[0] < 14.0, losses                                                  # ln 50257 = 10.8

@@ -174,3 +174,31 @@ def test_safetensors_checkpoint_and_dataset_path(monkeypatch, tmp_path):
     for (n, pa), (_, pb) in zip(tr.model.named_parameters(), fresh.model.named_parameters()):
         assert torch.equal(pa, pb), n
     assert fresh.model.lm_head.weight is fresh.model.bloom.word_embeddings.weight
+
+
+def test_short_last_window_does_not_leak_applied_gradients(monkeypatch, tmp_path):
+    """gradient_accumulation_steps=4 with 3 batches per epoch: every epoch ends in a SHORT window (steps_in_epoch <= ga), so
+    optimizer steps do not fall on multiples of ga.  Gradients that were already applied must not be accumulated into the next
+    step (round-1 advisor finding): the run must equal a hand-written loop that zeroes after every optimizer step."""
+    emu.install(monkeypatch)
+    from cleantransformer_amd.optimizer import AdamW
+    from cleantransformer_amd.trainer import TrainingArguments
+    data = rand_batches(3, seed=11)
+    args = TrainingArguments(output_dir=str(tmp_path), device="cpu", num_train_epochs=2, gradient_accumulation_steps=4, learning_rate=1e-3,
+                             weight_decay=0.0, lr_scheduler_type="constant", max_grad_norm=None, logging_steps=1, save_strategy="no",
+                             per_device_train_batch_size=2)
+    tr = make(args, data)
+    tr.train()
+    assert tr.state.global_step == 2                                    # one (short) window per epoch
+    ref = build(V, H, L, NH)
+    opt = AdamW(ref.parameters(), lr=1e-3, weight_decay=0.0, decoupled=True)
+    # window 1 = the three batches of epoch 1 (short last window); window 2 closes at total_batched_samples == 4, i.e. after the
+    # FIRST batch of epoch 2 (the reference loop's rule, trainer.py:468-480 — kept) and must contain that batch's gradient only
+    for window in (data, data[:1]):
+        opt.zero_grad()
+        for b in window:
+            (loss, _, _), _ = ref(input_ids=b["input_ids"], attention_mask=b["attention_mask"], labels=b["labels"])
+            (loss / 4).backward()
+        opt.step()
+    for (n, pa), (_, pb) in zip(tr.model.named_parameters(), ref.named_parameters()):
+        close(pa, pb, 1e-6, 1e-7)
