@@ -35,12 +35,16 @@ def flops_per_token(S: int) -> float:
 
 
 def _profiled_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed PMC profile (profiles/r01_lmhead_traffic.json:
-    separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied); None if the profile is absent."""
-    try:
-        return float(json.load(open(os.path.join(ROOT, "profiles", "r01_lmhead_traffic.json")))["traffic_bytes_per_launch"])
-    except Exception:
-        return None
+    """HBM bytes per launch of the dominant kernel from the committed PMC profile (profiles/rNN_lmhead_traffic.json, newest
+    round: separate FETCH_SIZE / WRITE_SIZE passes of the same command, gfx950 correction applied — the counters cannot be
+    collected inside a timed run); None if no profile is committed."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_lmhead_traffic.json")), reverse=True):
+        try:
+            return float(json.load(open(f))["traffic_bytes_per_launch"])
+        except Exception:
+            continue
+    return None
 
 
 def build_model(device, compute_dtype):
@@ -62,12 +66,22 @@ def build_model(device, compute_dtype):
     return m.train()
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """The oracle (CPU restatement, validated against the reference) timed on this box's host cores on a bounded sample:
-    Bloom-560M 24 layers, B=2, S=128, fp32, full SFT step."""
+def _cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    import platform
+    return platform.processor() or "unknown"
+
+
+def _cpu_sample(L_, B, S, warm, timed, budget_s):
+    """One shape of BASELINE.md §3: the oracle's full SFT step (forward -> zero_grad -> backward -> AdamW), `warm` warm-up steps
+    then up to `timed` timed ones (median), stopping early once `budget_s` seconds are spent."""
     from oracle import bloom_ref as R
-    B, S = 2, 128
-    sh = R.BloomShape(V, H, L, NH)
+    sh = R.BloomShape(V, H, L_, NH)
     g = torch.Generator().manual_seed(5)
     p = {}
     for n in R.param_names(sh):
@@ -76,19 +90,37 @@ def cpu_baseline(seconds_budget=25.0):
     ids = torch.randint(0, V, (B, S), generator=g)
     am = torch.ones(B, S, dtype=torch.long)
     st = R.AdamState(p)
-    t_all = []
-    t_start = time.time()
-    for i in range(4):
+    t_all, t_start = [], time.time()
+    for i in range(warm + timed):
         t0 = time.time()
         R.train_step(p, sh, ids, am, st)
         t_all.append(time.time() - t0)
-        if time.time() - t_start > seconds_budget and i >= 1:
+        if time.time() - t_start > budget_s and i >= warm:
             break
-    timed = t_all[1:] if len(t_all) > 1 else t_all
-    dt = sorted(timed)[len(timed) // 2]
-    return {"value": round(B * S / dt, 2), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle (CPU restatement) Bloom-560M 24L fp32 SFT step, B={B} S={S}, {len(timed)} timed step(s) after 1 warm-up, "
-                      f"{dt:.2f} s/step"}
+    done_timed = t_all[warm:] if len(t_all) > warm else t_all[-1:]
+    dt = sorted(done_timed)[len(done_timed) // 2]
+    return {"layers": L_, "batch": B, "seq": S, "tokens_per_s": round(B * S / dt, 2), "s_per_step": round(dt, 3),
+            "warmup_steps": min(warm, len(t_all) - len(done_timed)), "timed_steps": len(done_timed)}
+
+
+def cpu_baseline(mode="full"):
+    """the oracle (CPU restatement of the reference path, pinned to the reference through the committed golden
+    vectors) timed on THIS box's host cores, fp32, plain torch CPU ops, on a bounded sample of the workload:
+      C1 (BASELINE configs[0]: 2-layer slice, B=2, S=128), Bloom-560M 24 layers B=2 S=128, and — mode "full" — 24 layers B=2
+      S=1024 (one timed step after one warm-up: a step takes tens of seconds).
+    `value` is the 24-layer S=128 sample (the configuration closest to the GPU workload that fits the time bound); all samples
+    are listed with thread count and CPU model."""
+    threads = torch.get_num_threads()
+    samples = [_cpu_sample(2, 2, 128, 2, 3, 12.0), _cpu_sample(L, 2, 128, 1, 3, 25.0)]
+    if mode == "full":
+        samples.append(_cpu_sample(L, 2, 1024, 1, 1, 45.0))
+    head = samples[1]
+    return {"value": head["tokens_per_s"], "unit": "tokens/s", "cores": threads, "kind": "port", "cpu_model": _cpu_model(),
+            "host_logical_cpus": os.cpu_count(),
+            "sample": f"oracle (CPU restatement) fp32 full SFT step (fwd, zero_grad, bwd, AdamW), torch.set_num_threads({threads}); value = "
+                      f"Bloom-560M 24L B=2 S=128 median of {head['timed_steps']} timed step(s) after {head['warmup_steps']} warm-up, "
+                      f"{head['s_per_step']} s/step",
+            "samples": samples}
 
 
 def main():
@@ -100,6 +132,7 @@ def main():
     ap.add_argument("--seq", type=int, default=1024)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", default="full", choices=["full", "short"], help="short: skip the 24-layer S=1024 CPU sample")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -187,7 +220,7 @@ def main():
                          "flops_per_token": f_tok},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(args.cpu_baseline)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

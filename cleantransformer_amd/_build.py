@@ -31,6 +31,33 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_variant(name: str, extra_flags, verbose: bool = True) -> str:
+    """A/B builds for kernel experiments (tools/): the same sources with extra -D flags, into lib/variants/<name>/.  The product
+    never loads these unless CTMI_LIB_PATH points at one (see _lib.py)."""
+    vdir = os.path.join(LIB_DIR, "variants", name)
+    os.makedirs(vdir, exist_ok=True)
+    hipcc = _hipcc()
+    objs, jobs = [], []
+    for src, obj, extra in SOURCES:
+        o = os.path.join(vdir, obj)
+        objs.append(o)
+        jobs.append([hipcc, *FLAGS, *extra, *extra_flags, "-c", os.path.join(CSRC, src), "-o", o])
+
+    def run(cmd):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        list(ex.map(run, jobs))
+    out = os.path.join(vdir, "libctmi355.so")
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out])
+    for o in objs:
+        os.remove(o)
+    if verbose:
+        print("[ctmi355 variant]", name, extra_flags, "->", out)
+    return out
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIB_DIR, exist_ok=True)
     hipcc = _hipcc()

@@ -10,10 +10,13 @@ import os
 import torch  # noqa: F401  (must come first: libctmi355.so has to bind to the HIP runtime torch already loaded — two
 #                              HIP runtimes in one process cannot both initialise the device)
 
-from ._build import LIB_PATH
+from ._build import LIB_PATH as _DEFAULT_LIB_PATH
+
+# CTMI_LIB_PATH: load another build of the same sources (kernel A/B experiments under tools/; see _build.build_variant)
+LIB_PATH = os.environ.get("CTMI_LIB_PATH") or _DEFAULT_LIB_PATH
 
 F32, BF16 = 0, 1
-EPI_NONE, EPI_GELU, EPI_DGELU, EPI_RELU, EPI_DRELU = 0, 1, 2, 3, 4
+EPI_NONE, EPI_GELU, EPI_DGELU, EPI_RELU, EPI_DRELU, EPI_GELUG, EPI_MUL = 0, 1, 2, 3, 4, 5, 6
 MT_MAX = 24
 ABI_VERSION = 2
 

@@ -12,6 +12,21 @@
 // Masked scores take finfo(float).min like the reference's masked_fill, so all-masked rows become uniform.
 #include "common.h"
 #include "mma.h"
+#include <type_traits>
+
+// A/B knobs for tools/ variant builds (defaults = the adopted configuration)
+#ifndef CTMI_ATTN_FASTBODY
+#define CTMI_ATTN_FASTBODY 1     // backward kernels: mask-free loop body for tiles that cannot contain a masked score
+#endif
+#ifndef CTMI_ATTN_SWAPRED
+#define CTMI_ATTN_SWAPRED 1      // forward kernel: row-max across the 4 lane groups by v_permlane{16,32}_swap instead of ds_bpermute
+#endif
+#ifndef CTMI_ATTN_MINW
+#define CTMI_ATTN_MINW 2         // __launch_bounds__ minimum waves per SIMD of the three streaming kernels (register cap = 512 / MINW)
+#endif
+#ifndef CTMI_ATTN_NBUF
+#define CTMI_ATTN_NBUF 0         // 0: two LDS stages whenever they fit (one barrier per tile); 1: force one stage (more workgroups per CU)
+#endif
 
 struct AttnP {
     const void *q, *k, *v, *o, *d_o;
@@ -33,6 +48,15 @@ struct AttnP {
 // 16 bytes of tile data in flight: a first-class vector, NOT the uint4 struct — struct copies become memcpy intrinsics that
 // SROA left in private memory (scratch stores + vmcnt(0) after every tile load) once the scalar gather path was compiled out
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// Loads through pointers that hipcc cannot prove to be global (loop-carried / selected pointers derived from the by-value
+// kernel-argument struct) are emitted as flat_load, and a FLAT access counts on LGKM_CNT as well as VM_CNT: every
+// `s_waitcnt lgkmcnt(0)` in front of an MFMA (placed there for the LDS fragment reads) then also waited for the tile prefetch
+// issued just before it — the software pipeline was serialised on HBM/L2 latency in all three kernels.  These helpers cast to
+// the global address space explicitly, so the loads are global_load_* and only the vmcnt wait at their use sees them.
+template <typename V> __device__ __forceinline__ V ldg_as1(const void* p) {
+    typedef const __attribute__((address_space(1))) V* gptr;
+    return *(gptr)(p);
+}
 template <typename T, int HDP>
 struct AT {
     static constexpr int VEC = 16 / sizeof(T);
@@ -56,7 +80,7 @@ struct AT {
             for (int i = 0; i < NCH; ++i) {
                 const int id = tid + 256 * i;
                 const int64_t grow = min(row0 + id / CPR, nrows - 1);
-                regs[i] = *reinterpret_cast<const u32x4*>(base + grow * rs + (id % CPR) * VEC);
+                regs[i] = ldg_as1<u32x4>(base + grow * rs + (id % CPR) * VEC);
             }
             return;
         }
@@ -106,7 +130,7 @@ struct AT {
                 }
             }
 #pragma unroll
-            for (int i = 0; i < NCH; ++i) regs[i] = *reinterpret_cast<const u32x4*>(src[i]);
+            for (int i = 0; i < NCH; ++i) regs[i] = ldg_as1<u32x4>(src[i]);
         } else {
             load(regs, base, rs, row0, nrows, hd, false, tid);
         }
@@ -136,7 +160,7 @@ template <> __device__ __forceinline__ float frag_rm<float, 128>(const float* __
 template <typename T, bool FAST = false> __device__ __forceinline__ typename Mma<T>::Frag frag_global(const T* row, int kofs, int hd, bool vec_ok);
 template <> __device__ __forceinline__ short8 frag_global<bf16_t, true>(const bf16_t* row, int kofs, int, bool) {
     short8 f = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (row != nullptr) f = *reinterpret_cast<const short8*>(row + kofs);
+    if (row != nullptr) f = ldg_as1<short8>(row + kofs);
     return f;
 }
 template <> __device__ __forceinline__ short8 frag_global<bf16_t, false>(const bf16_t* row, int kofs, int hd, bool vec_ok) {
@@ -160,13 +184,16 @@ __device__ __forceinline__ void dot_tile(f32x4 (&x)[4], const T* __restrict__ rm
                                          const typename Mma<T>::Frag (&own)[HDP / Mma<T>::K], int lane) {
     constexpr int MK = Mma<T>::K, KL = Mma<T>::KL;
     const int g = lane >> 4, li = lane & 15;
+    // k-step outer, key group inner: consecutive MFMAs go to four DIFFERENT accumulators, so the second k-step of a group
+    // issues four matrix instructions after the first instead of right behind it (a dependent MFMA pair stalls for the whole
+    // pipeline latency; hipcc kept the source order and padded it with s_nop)
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        x[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < 4; ++nt) x[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kk = 0; kk < HDP / MK; ++kk)
+    for (int kk = 0; kk < HDP / MK; ++kk)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
             x[nt] = Mma<T>::mma(frag_rm<T, HDP>(rm_tile, nt * 16 + li, kk * MK + g * KL), own[kk], x[nt]);
-    }
 }
 
 // acc[dt][r] += sum_{j in tile} tile[j][dt*16 + g*4 + r] * x(j)      with x in accumulator layout:
@@ -225,6 +252,24 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
     float r;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
+}
+
+// max over the 4 lane groups (lanes l, l^16, l^32, l^48) of a per-lane value, without the LDS crossbar: v_permlane16_swap
+// exchanges the odd 16-lane rows of its first operand with the even rows of its second, v_permlane32_swap the upper 32 lanes of
+// the first with the lower 32 of the second; applied to two copies of v, max(a, b) is the xor-16 / xor-32 butterfly step.
+// (__shfl_xor compiles to ds_bpermute_b32: ~6 integer VALU instructions for the lane index — recomputed every tile — plus an
+// LDS round trip and an lgkmcnt(0) in the middle of the softmax dependency chain, twice per tile.)
+__device__ __forceinline__ float group_max4(float v) {
+#if CTMI_ATTN_SWAPRED
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    float c = max3f(a, a, b), d = c;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(c), "+v"(d));
+    return max3f(c, c, d);
+#else
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+#endif
 }
 
 // Per-key additive bias staged once per tile (one float per key):
@@ -286,10 +331,10 @@ __device__ __forceinline__ void store_own_row(T* rowp, const f32x4 (&acc)[HDP / 
 template <typename T, int HDP> struct FwdStage { static constexpr int BYTES = 2 * AT<T, HDP>::RM_ELEMS * (int)sizeof(T) + 256; };
 template <typename T, int HDP> struct DkdvStage { static constexpr int BYTES = 2 * AT<T, HDP>::RM_ELEMS * (int)sizeof(T) + 768; };
 template <typename T, int HDP> struct DqStage { static constexpr int BYTES = 2 * AT<T, HDP>::RM_ELEMS * (int)sizeof(T) + 256; };
-constexpr int nbuf_for(int stage_bytes) { return 2 * stage_bytes <= 80 * 1024 ? 2 : 1; }
+constexpr int nbuf_for(int stage_bytes) { return CTMI_ATTN_NBUF ? CTMI_ATTN_NBUF : (2 * stage_bytes <= 80 * 1024 ? 2 : 1); }
 
 template <typename T, int HDP, bool AM, bool FAST>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
+__global__ __launch_bounds__(256, CTMI_ATTN_MINW) void attn_fwd_kernel(AttnP p) {
     using A = AT<T, HDP>;
     constexpr int MK = Mma<T>::K, KL = Mma<T>::KL, NKK = HDP / MK, NDT = HDP / 16;
     constexpr int STAGE = FwdStage<T, HDP>::BYTES, NBUF = nbuf_for(STAGE);
@@ -388,8 +433,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
         }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) mx = max3f(max3f(mx, x[nt][0], x[nt][1]), x[nt][2], x[nt][3]);
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = group_max4(mx);
         const float m_new = fmaxf(m, mx);                                   // finite: every tile holds >= 1 real key
         const float alpha = __expf(m - m_new);
         f32x4 rs4 = {0.f, 0.f, 0.f, 0.f};
@@ -505,7 +549,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnP p) {
 // own rows = keys.  Per query tile: S = Q K^T and dP = dO V^T (own key in the accumulator column), P = exp(S-m)/l,
 // dS = P (dP - delta); dV^T += dO^T P, dK^T += Q^T dS  (Q, dO staged both row-major and transposed).
 template <typename T, int HDP, bool AM, bool FAST>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
+__global__ __launch_bounds__(256, CTMI_ATTN_MINW) void attn_bwd_dkdv_kernel(AttnP p) {
     using A = AT<T, HDP>;
     constexpr int MK = Mma<T>::K, KL = Mma<T>::KL, NKK = HDP / MK, NDT = HDP / 16;
     constexpr int STAGE = DkdvStage<T, HDP>::BYTES, NBUF = nbuf_for(STAGE);
@@ -564,7 +608,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
     const float* sbase = (tid >> 6) == 0 ? sm : ((tid >> 6) == 1 ? sl : sd);
     auto load_stats = [&](int t) {
         const int64_t q = (int64_t)t * 64 + (tid & 63);
-        if (tid < 192) rstat = sbase[min(q, p.Sq - 1)];
+        if (tid < 192) rstat = ldg_as1<float>(sbase + min(q, p.Sq - 1));
     };
     auto stat_value = [&](int t) {
         const int64_t q = (int64_t)t * 64 + (tid & 63);
@@ -585,7 +629,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
     }
     __syncthreads();
 
-    for (int t = qt_begin; t < qt_end; ++t) {
+    // A tile can hold a masked score only if it crosses the causal diagonal (query block == key block in training) or reaches
+    // beyond Sq; every other tile takes the mask-free body (MASKED = false): no per-element compares / selects at all — padding
+    // keys still get P through their FINFO_MIN bias (uniform rows) and their dK column is zeroed once, after the loop; rows
+    // q >= Sq exist only in a tile that reaches beyond Sq.  The exception is a batch row with LEFT padding: its leading queries
+    // see only masked keys (uniform over ALL keys), so every tile of such a row keeps the general body.
+    const bool general = AM || !CTMI_ATTN_FASTBODY || (p.kvalid != nullptr && p.first_valid[b] - p.off > 0);
+    auto body = [&](auto masked_c, const int t) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked_c)::value;
         if (t + 1 < qt_end && !(p.dbg & 1)) {
             load_stats(t + 1);
             A::stream_load(rq, pq, qp, p.q_rs, (int64_t)(t + 1) * 64, p.Sq, hd_, fast, tid);
@@ -595,9 +646,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
         const float* st = ST(cur);
         dot_tile<T, HDP>(x, QS(cur), kf, lane);                              // x[nt][r] = q[qi] . k[my_k]
         dot_tile<T, HDP>(y, GS(cur), vf, lane);                              // y[nt][r] = dO[qi] . v[my_k]
-        // (a tile-uniform "crosses the diagonal" test here made hipcc unswitch the loop: +29 % time.)  The per-element masks are
-        // one integer compare each against per-tile, per-lane thresholds on the compile-time offset c = nt*16 + r of the
-        // query inside the tile (query index = qbase + c):
+        // The per-element masks of the general body are one integer compare each against per-tile, per-lane thresholds on the
+        // compile-time offset c = nt*16 + r of the query inside the tile (query index = qbase + c):
         //   masked(c) = padding key | (causal & my_k > q + off)   <=>  c < thr_m
         //   valid(c)  = key row exists & q < Sq                   <=>  c < thr_v
         const int qbase = t * 64 + g * 4;
@@ -613,22 +663,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) s4[r] = score_raw<true>(p, x[nt][r], my_kb, qbase + nt * 16 + r, (int)my_k, am_base);
             }
-            bool msk[4];
+            bool msk[4] = {false, false, false, false};
+            if constexpr (MASKED) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                msk[r] = (nt * 16 + r) < thr_m;
-                s4[r] = msk[r] ? FINFO_MIN : s4[r];
+                for (int r = 0; r < 4; ++r) {
+                    msk[r] = (nt * 16 + r) < thr_m;
+                    s4[r] = msk[r] ? FINFO_MIN : s4[r];
+                }
             }
             const f32x4 e4 = (s4 - mm) * 1.4426950408889634f;                     // (s - m) first (finfo.min - finfo.min = 0)
             f32x4 p4;
 #pragma unroll
             for (int r = 0; r < 4; ++r) p4[r] = __builtin_amdgcn_exp2f(e4[r]);
             p4 = p4 * il;
+            if constexpr (MASKED) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) p4[r] = ((nt * 16 + r) < thr_v) ? p4[r] : 0.f;
+                for (int r = 0; r < 4; ++r) p4[r] = ((nt * 16 + r) < thr_v) ? p4[r] : 0.f;
+            }
             f32x4 d4 = p4 * (y[nt] - dl);                                         // already 0 where the row / key does not exist
+            if constexpr (MASKED) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) d4[r] = msk[r] ? 0.f : d4[r];            // masked entries: P kept (uniform rows), dS = 0
+                for (int r = 0; r < 4; ++r) d4[r] = msk[r] ? 0.f : d4[r];        // masked entries: P kept (uniform rows), dS = 0
+            }
             x[nt] = p4;
             y[nt] = d4;
         }
@@ -643,6 +699,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
             cur = nx;
         }
         __syncthreads();
+    };
+    for (int t = qt_begin; t < qt_end; ++t) {
+        // tile-uniform: queries t*64 .. t*64+63 against keys k0 .. k0+63
+        const bool crosses = p.causal && ((int64_t)t * 64 + p.off < k0 + 63);
+        const bool partial = (int64_t)t * 64 + 64 > p.Sq;
+        if (general || crosses || partial) body(std::true_type{}, t);
+        else body(std::false_type{}, t);
+    }
+    if (!general && key_pad) {                                               // the mask-free tiles left dS != 0 in a padding key's column
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if (my_k < p.Sk) {
         T* dkp = reinterpret_cast<T*>(p.dk) + b * p.k_bs + h * p.k_hs + my_k * p.k_rs;
@@ -655,7 +722,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnP p) {
 // ------------------------------------------------------------------------------------------------ backward: dQ
 // own rows = queries.  Per key tile: S^T = K Q^T, dP^T = V dO^T, dS^T = P^T (dP^T - delta); dQ^T += K^T dS^T.
 template <typename T, int HDP, bool AM, bool FAST>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
+__global__ __launch_bounds__(256, CTMI_ATTN_MINW) void attn_bwd_dq_kernel(AttnP p) {
     using A = AT<T, HDP>;
     constexpr int MK = Mma<T>::K, KL = Mma<T>::KL, NKK = HDP / MK, NDT = HDP / 16;
     constexpr int STAGE = DqStage<T, HDP>::BYTES, NBUF = nbuf_for(STAGE);
@@ -718,7 +785,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
     if (tid < 64) KB(0)[tid] = rkb;
     __syncthreads();
 
-    for (int t = 0; t < ntiles; ++t) {
+    // Mask-free body for key tiles entirely in the causal past of all 64 queries (all but the last tile of a query block):
+    // padding keys carry the FINFO_MIN bias, so P — and with it dS — is exactly 0 for every row that sees a real key; that is
+    // every row unless the batch row has LEFT padding (leading queries see only masked keys: P uniform, dS must still be 0) or
+    // the query block reaches beyond Sq (dead rows: 1/l = 0 but exp of an un-shifted score may overflow) — those keep the general body.
+    const bool general = AM || !CTMI_ATTN_FASTBODY || (p.kvalid != nullptr && p.first_valid[b] - p.off > 0) || (q0 + 64 > p.Sq);
+    auto body = [&](auto masked_c, const int t) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked_c)::value;
         if (t + 1 < ntiles && !(p.dbg & 1)) {
             if (tid < 64) kbr.load(p, b, (int64_t)(t + 1) * 64 + tid);
             A::stream_load(rk, pk, kp, p.k_rs, (int64_t)(t + 1) * 64, p.Sk, hd_, fast, tid);
@@ -745,10 +818,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) p4[r] = __builtin_amdgcn_exp2f(e4[r]);
             f32x4 d4 = (p4 * il) * (y[nt] - dl);
+            if constexpr (MASKED) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool use = (kb4[r] > FINFO_MIN) & ((nt * 16 + r) <= thr_u);   // padding / missing / future keys, dead rows: dS = 0
-                d4[r] = use ? d4[r] : 0.f;
+                for (int r = 0; r < 4; ++r) {
+                    const bool use = (kb4[r] > FINFO_MIN) & ((nt * 16 + r) <= thr_u);   // padding / missing / future keys, dead rows: dS = 0
+                    d4[r] = use ? d4[r] : 0.f;
+                }
             }
             y[nt] = d4;
         }
@@ -762,6 +837,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnP p) {
             cur = nx;
         }
         __syncthreads();
+    };
+    for (int t = 0; t < ntiles; ++t) {
+        const bool crosses = p.causal && (t * 64 + 63 > (int)q0 + p.off);    // tile-uniform: some (query, key) pair of the tile is in the causal future
+        const bool tail = (int64_t)t * 64 + 64 > p.Sk;                       // keys beyond Sk carry -inf (P = 0 exactly): harmless, but keep it simple
+        if (general || crosses || tail) body(std::true_type{}, t);
+        else body(std::false_type{}, t);
     }
     if (live) {
         T* dqp = reinterpret_cast<T*>(p.dq) + b * p.q_bs + h * p.q_hs + my_q * p.q_rs;

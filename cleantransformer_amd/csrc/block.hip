@@ -22,6 +22,11 @@ int ctmi_ln_bwd_parts_internal(const void* dy, const void* x, const float* w, co
                                int* nparts, int* ns, hipStream_t st);
 int ctmi_colsum_parts_internal(const void* x, int64_t ld, float* ws, int64_t M, int64_t N, int dtype, int* parts_out, hipStream_t st);
 
+#ifndef CTMI_BLOCK_GELUG
+#define CTMI_BLOCK_GELUG 0      // 1: forward saves gelu'(u) (GELUG) and the backward multiplies (MUL); 0: save u, DGELU epilogue.
+                                // Same-box A/B (3 interleaved bench runs each): 43.05 vs 43.04 ms/step — the dGELU arithmetic is not
+                                // what the [T,4H] data-gradient epilogue costs; the default stays with the reference's saved tensor.
+#endif
 static inline int64_t al256(int64_t b) { return (b + 255) / 256 * 256; }
 
 extern "C" int64_t ctmi_bloom_block_layout(int64_t B, int64_t S, int64_t H, int64_t nh, int dtype, int64_t* offs) {
@@ -138,7 +143,7 @@ extern "C" int ctmi_bloom_block_fwd(const ctmi_bloom_block* b, void* stream) {
                      b->slopes, b->kpos, b->kvalid, b->first_valid, nullptr, &d, dt, st));
     RC(linear_fwd(s.at(CTMI_BLK_ATT), b->wd, s.at(CTMI_BLK_H1), T, H, H, b->bd, post ? s.at(CTMI_BLK_LN1) : b->x, CTMI_EPI_NONE, nullptr, dt, st));
     RC(ctmi_layernorm_fwd(s.at(CTMI_BLK_H1), b->ln2_w, b->ln2_b, s.at(CTMI_BLK_LN2), s.at<float>(CTMI_BLK_MEAN2), s.at<float>(CTMI_BLK_RSTD2), T, H, b->eps, dt, st));
-    RC(linear_fwd(s.at(CTMI_BLK_LN2), b->w1, s.at(CTMI_BLK_G), T, 4 * H, H, b->b1, nullptr, CTMI_EPI_GELU, s.at(CTMI_BLK_U), dt, st));
+    RC(linear_fwd(s.at(CTMI_BLK_LN2), b->w1, s.at(CTMI_BLK_G), T, 4 * H, H, b->b1, nullptr, CTMI_BLOCK_GELUG ? CTMI_EPI_GELUG : CTMI_EPI_GELU, s.at(CTMI_BLK_U), dt, st));
     RC(linear_fwd(s.at(CTMI_BLK_G), b->w2, s.at(CTMI_BLK_OUT), T, H, 4 * H, b->b2, post ? s.at(CTMI_BLK_LN2) : s.at(CTMI_BLK_H1), CTMI_EPI_NONE, nullptr, dt, st));
     return CTMI_OK;
 }
@@ -218,7 +223,7 @@ extern "C" int ctmi_bloom_block_bwd(const ctmi_bloom_block* b, const ctmi_bloom_
     // ---- MLP: out = res2 + W2 gelu(W1 ln2 + b1) + b2
     RC(fork());
     RC(linear_wgrad(dout, s.at(CTMI_BLK_G), gr->dw2, T, H, 4 * H, dt, pws, pws_bytes, pst));
-    RC(linear_dgrad(dout, b->w2, W(W_DU), T, H, 4 * H, CTMI_EPI_DGELU, s.at(CTMI_BLK_U), nullptr, dt, nullptr, 0, main_st));      // modeling_bloom.py:348-363 fused
+    RC(linear_dgrad(dout, b->w2, W(W_DU), T, H, 4 * H, CTMI_BLOCK_GELUG ? CTMI_EPI_MUL : CTMI_EPI_DGELU, s.at(CTMI_BLK_U), nullptr, dt, nullptr, 0, main_st));        // modeling_bloom.py:348-363 fused
     RC(fork());
     RC(linear_wgrad(W(W_DU), s.at(CTMI_BLK_LN2), gr->dw1, T, 4 * H, H, dt, pws, pws_bytes, pst));
     RC(colsum_job(W(W_DU), 4 * H, W_CS_DU, gr->db1));

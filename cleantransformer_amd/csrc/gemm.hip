@@ -309,22 +309,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                 if (full) { const float4 bb = *reinterpret_cast<const float4*>(g.bias + n); v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
                 else { for (int r = 0; r < 4; ++r) if (n + r < g.N) v[r] += g.bias[n + r]; }
             }
-            if (EPI == CTMI_EPI_GELU) {
+            if (EPI == CTMI_EPI_GELU || EPI == CTMI_EPI_GELUG) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = Cvt<T>::to_f(Cvt<T>::from_f(v[r]));       // GELU sees the stored value
-                if (full) store4<T>(AUXO + off, v);
-                else { for (int r = 0; r < 4; ++r) if (n + r < g.N) AUXO[off + r] = Cvt<T>::from_f(v[r]); }
+                float ax[4];                                                                    // what the backward wants: x, or gelu'(x)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ax[r] = (EPI == CTMI_EPI_GELUG) ? gelu_tanh_grad_f(v[r]) : v[r];
+                if (full) store4<T>(AUXO + off, ax);
+                else { for (int r = 0; r < 4; ++r) if (n + r < g.N) AUXO[off + r] = Cvt<T>::from_f(ax[r]); }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(v[r]);
             } else if (EPI == CTMI_EPI_RELU) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-            } else if (EPI == CTMI_EPI_DGELU || EPI == CTMI_EPI_DRELU) {
+            } else if (EPI == CTMI_EPI_DGELU || EPI == CTMI_EPI_DRELU || EPI == CTMI_EPI_MUL) {
                 float u[4] = {0.f, 0.f, 0.f, 0.f};
                 if (full) load4<T>(AUXI + off, u);
                 else { for (int r = 0; r < 4; ++r) if (n + r < g.N) u[r] = Cvt<T>::to_f(AUXI[off + r]); }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = (EPI == CTMI_EPI_DGELU) ? v[r] * gelu_tanh_grad_f(u[r]) : (u[r] > 0.f ? v[r] : 0.f);
+                for (int r = 0; r < 4; ++r) v[r] = (EPI == CTMI_EPI_DGELU) ? v[r] * gelu_tanh_grad_f(u[r]) : (EPI == CTMI_EPI_MUL ? v[r] * u[r] : (u[r] > 0.f ? v[r] : 0.f));
             }
             if (R != nullptr) {
                 float u[4] = {0.f, 0.f, 0.f, 0.f};
@@ -568,7 +571,7 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
             // RES) is fetched one pass ahead, into the registers the previous pass's accumulators just freed: loaded
             // where it is used, each of the 16 row groups of a tile would expose a full global-load latency
             // (only the 128-row tiles have the registers for it: with 128 accumulators live hipcc spills the prefetch)
-            constexpr bool PRE_AUX = (EPI == CTMI_EPI_DGELU || EPI == CTMI_EPI_DRELU) && WM == 4;
+            constexpr bool PRE_AUX = (EPI == CTMI_EPI_DGELU || EPI == CTMI_EPI_DRELU || EPI == CTMI_EPI_MUL) && WM == 4;
             constexpr bool PRE_RES = RES && !PRE_AUX && WM == 4;
             constexpr bool PRE = PRE_AUX || PRE_RES;
             const T* side = PRE_AUX ? AUXI : R;
@@ -587,14 +590,33 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
                     unpack16<T>(tb, v);
 #pragma unroll
                     for (int r = 0; r < 8; r += 2) { const f32x2 y = gelu_tanh_pk(f32x2{v[r], v[r + 1]}); v[r] = y[0]; v[r + 1] = y[1]; }
+                } else if (EPI == CTMI_EPI_GELUG) {
+                    // forward of the MLP activation that ALSO leaves gelu'(x) for the backward (instead of x): the logistic factor
+                    // s is shared, so the derivative costs ~5 more packed ops here and the 4h->h data-gradient GEMM's epilogue
+                    // shrinks to one multiply per element (CTMI_EPI_MUL) — no exp / rcp on that kernel's critical tail
+                    const uint4 tb = pack16<T>(v);
+                    unpack16<T>(tb, v);                                                     // the activation sees the value as stored before
+                    float gd[8];
+#pragma unroll
+                    for (int r = 0; r < 8; r += 2) {
+                        const f32x2 x = f32x2{v[r], v[r + 1]}, x2 = x * x;
+                        const f32x2 sg = gelu_sigma_pk(x, x2);
+                        const f32x2 d = sg * (x * (1.0f - sg) * (x2 * 0.21406445f + 1.5957691f) + 1.0f);
+                        const f32x2 y = x * sg;
+                        gd[r] = d[0]; gd[r + 1] = d[1]; v[r] = y[0]; v[r + 1] = y[1];
+                    }
+                    *reinterpret_cast<uint4*>(AUXO + off) = pack16<T>(gd);
                 } else if (EPI == CTMI_EPI_RELU) {
 #pragma unroll
                     for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
-                } else if (EPI == CTMI_EPI_DGELU || EPI == CTMI_EPI_DRELU) {
+                } else if (EPI == CTMI_EPI_DGELU || EPI == CTMI_EPI_DRELU || EPI == CTMI_EPI_MUL) {
                     float u[8];
                     if constexpr (PRE_AUX) unpack16<T>(pre_it, u);
                     else unpack16<T>(*reinterpret_cast<const uint4*>(AUXI + off), u);
-                    if (EPI == CTMI_EPI_DGELU) {
+                    if (EPI == CTMI_EPI_MUL) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] *= u[r];
+                    } else if (EPI == CTMI_EPI_DGELU) {
 #pragma unroll
                         for (int r = 0; r < 8; r += 2) { const f32x2 y = f32x2{v[r], v[r + 1]} * gelu_tanh_grad_pk(f32x2{u[r], u[r + 1]}); v[r] = y[0]; v[r + 1] = y[1]; }
                     } else {
@@ -754,21 +776,21 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
                 const int64_t off = m * g.ldc + n;
                 f32x4 v = acc[i][j] * g.alpha;
                 if (g.bias != nullptr) v += *reinterpret_cast<const f32x4*>(g.bias + n);
-                if (EPI == CTMI_EPI_GELU) {
-                    float t[4] = {v[0], v[1], v[2], v[3]};
+                if (EPI == CTMI_EPI_GELU || EPI == CTMI_EPI_GELUG) {
+                    float t[4] = {v[0], v[1], v[2], v[3]}, ax[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) t[r] = Cvt<T>::to_f(Cvt<T>::from_f(t[r]));
-                    store4<T>(AUXO + off, t);
+                    for (int r = 0; r < 4; ++r) { t[r] = Cvt<T>::to_f(Cvt<T>::from_f(t[r])); ax[r] = (EPI == CTMI_EPI_GELUG) ? gelu_tanh_grad_f(t[r]) : t[r]; }
+                    store4<T>(AUXO + off, ax);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(t[r]);
                 } else if (EPI == CTMI_EPI_RELU) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-                } else if (EPI == CTMI_EPI_DGELU || EPI == CTMI_EPI_DRELU) {
+                } else if (EPI == CTMI_EPI_DGELU || EPI == CTMI_EPI_DRELU || EPI == CTMI_EPI_MUL) {
                     float u[4];
                     load4<T>(AUXI + off, u);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = (EPI == CTMI_EPI_DGELU) ? v[r] * gelu_tanh_grad_f(u[r]) : (u[r] > 0.f ? v[r] : 0.f);
+                    for (int r = 0; r < 4; ++r) v[r] = (EPI == CTMI_EPI_DGELU) ? v[r] * gelu_tanh_grad_f(u[r]) : (EPI == CTMI_EPI_MUL ? v[r] * u[r] : (u[r] > 0.f ? v[r] : 0.f));
                 }
                 if (R != nullptr) { float u[4]; load4<T>(R + off, u); v += f32x4{u[0], u[1], u[2], u[3]}; }
                 if (g.beta) { float u[4]; load4<TO>(C + off, u); v += f32x4{u[0], u[1], u[2], u[3]}; }
@@ -795,22 +817,25 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
                 if (full) { const float4 bb = *reinterpret_cast<const float4*>(g.bias + n); v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
                 else { for (int r = 0; r < 4; ++r) if (n + r < g.N) v[r] += g.bias[n + r]; }
             }
-            if (EPI == CTMI_EPI_GELU) {
+            if (EPI == CTMI_EPI_GELU || EPI == CTMI_EPI_GELUG) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = Cvt<T>::to_f(Cvt<T>::from_f(v[r]));
-                if (full) store4<T>(AUXO + off, v);
-                else { for (int r = 0; r < 4; ++r) if (n + r < g.N) AUXO[off + r] = Cvt<T>::from_f(v[r]); }
+                float ax[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ax[r] = (EPI == CTMI_EPI_GELUG) ? gelu_tanh_grad_f(v[r]) : v[r];
+                if (full) store4<T>(AUXO + off, ax);
+                else { for (int r = 0; r < 4; ++r) if (n + r < g.N) AUXO[off + r] = Cvt<T>::from_f(ax[r]); }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(v[r]);
             } else if (EPI == CTMI_EPI_RELU) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-            } else if (EPI == CTMI_EPI_DGELU || EPI == CTMI_EPI_DRELU) {
+            } else if (EPI == CTMI_EPI_DGELU || EPI == CTMI_EPI_DRELU || EPI == CTMI_EPI_MUL) {
                 float u[4] = {0.f, 0.f, 0.f, 0.f};
                 if (full) load4<T>(AUXI + off, u);
                 else { for (int r = 0; r < 4; ++r) if (n + r < g.N) u[r] = Cvt<T>::to_f(AUXI[off + r]); }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = (EPI == CTMI_EPI_DGELU) ? v[r] * gelu_tanh_grad_f(u[r]) : (u[r] > 0.f ? v[r] : 0.f);
+                for (int r = 0; r < 4; ++r) v[r] = (EPI == CTMI_EPI_DGELU) ? v[r] * gelu_tanh_grad_f(u[r]) : (EPI == CTMI_EPI_MUL ? v[r] * u[r] : (u[r] > 0.f ? v[r] : 0.f));
             }
             if (R != nullptr) {
                 float u[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1100,7 +1125,7 @@ static void pick_tile(int64_t M, int64_t N, int64_t K, bool wgrad, bool bkm, int
     else tile = 0;
     // epilogues that read a second [M,N] operand (activation-derivative input): only the 128-row ping-pong tile has the
     // registers to prefetch it a pass ahead (measured 112 vs 121 us on the [T,4H] DGELU dgrad)
-    if ((epi == CTMI_EPI_DGELU || epi == CTMI_EPI_DRELU) && tile == 3) tile = 4;
+    if ((epi == CTMI_EPI_DGELU || epi == CTMI_EPI_DRELU || epi == CTMI_EPI_MUL) && tile == 3) tile = 4;
     if (force >= 0) tile = force;
 }
 
@@ -1181,6 +1206,7 @@ static int gemm_unsupported(int ak, int bk, int epi, int out_f32) {
 int ctmi_gemm_bf16_nt(GemmArgs& g, int epi, bool fast, hipStream_t st) {
     if (epi == CTMI_EPI_NONE) return gemm_launch<bf16_t, bf16_t, false, false, CTMI_EPI_NONE>(g, fast, st);
     if (epi == CTMI_EPI_GELU) return gemm_launch<bf16_t, bf16_t, false, false, CTMI_EPI_GELU>(g, fast, st);
+    if (epi == CTMI_EPI_GELUG) return gemm_launch<bf16_t, bf16_t, false, false, CTMI_EPI_GELUG>(g, fast, st);
     if (epi == CTMI_EPI_RELU) return gemm_launch<bf16_t, bf16_t, false, false, CTMI_EPI_RELU>(g, fast, st);
     return gemm_unsupported(0, 0, epi, 0);
 }
@@ -1189,6 +1215,7 @@ int ctmi_gemm_bf16_nt(GemmArgs& g, int epi, bool fast, hipStream_t st) {
 int ctmi_gemm_bf16_nn(GemmArgs& g, int epi, bool fast, hipStream_t st) {
     if (epi == CTMI_EPI_NONE) return gemm_launch<bf16_t, bf16_t, false, true, CTMI_EPI_NONE>(g, fast, st);
     if (epi == CTMI_EPI_DGELU) return gemm_launch<bf16_t, bf16_t, false, true, CTMI_EPI_DGELU>(g, fast, st);
+    if (epi == CTMI_EPI_MUL) return gemm_launch<bf16_t, bf16_t, false, true, CTMI_EPI_MUL>(g, fast, st);
     if (epi == CTMI_EPI_DRELU) return gemm_launch<bf16_t, bf16_t, false, true, CTMI_EPI_DRELU>(g, fast, st);
     return gemm_unsupported(0, 1, epi, 0);
 }
@@ -1213,11 +1240,13 @@ static int gemm_dispatch_f32(GemmArgs& g, int ak, int bk, int epi, bool fast, hi
     if (!ak && !bk) {
         if (epi == CTMI_EPI_NONE) return gemm_launch<T, float, false, false, CTMI_EPI_NONE>(g, fast, st);
         if (epi == CTMI_EPI_GELU) return gemm_launch<T, float, false, false, CTMI_EPI_GELU>(g, fast, st);
+        if (epi == CTMI_EPI_GELUG) return gemm_launch<T, float, false, false, CTMI_EPI_GELUG>(g, fast, st);
         if (epi == CTMI_EPI_RELU) return gemm_launch<T, float, false, false, CTMI_EPI_RELU>(g, fast, st);
     }
     if (!ak && bk) {
         if (epi == CTMI_EPI_NONE) return gemm_launch<T, float, false, true, CTMI_EPI_NONE>(g, fast, st);
         if (epi == CTMI_EPI_DGELU) return gemm_launch<T, float, false, true, CTMI_EPI_DGELU>(g, fast, st);
+        if (epi == CTMI_EPI_MUL) return gemm_launch<T, float, false, true, CTMI_EPI_MUL>(g, fast, st);
         if (epi == CTMI_EPI_DRELU) return gemm_launch<T, float, false, true, CTMI_EPI_DRELU>(g, fast, st);
     }
     if (ak && bk && epi == CTMI_EPI_NONE) return gemm_launch<T, float, true, true, CTMI_EPI_NONE>(g, fast, st);
@@ -1232,8 +1261,8 @@ extern "C" int ctmi_gemm(const void* A, int64_t lda, int a_kmajor, const void* B
     CTMI_REQUIRE(A && B && C, "gemm: null operand");
     CTMI_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
     CTMI_REQUIRE(lda >= (a_kmajor ? M : K) && ldb >= (b_kmajor ? N : K) && ldc >= N, "gemm: leading dimension too small");
-    CTMI_REQUIRE(epilogue != CTMI_EPI_GELU || aux_out, "gemm: GELU epilogue needs aux_out");
-    CTMI_REQUIRE((epilogue != CTMI_EPI_DGELU && epilogue != CTMI_EPI_DRELU) || aux_in, "gemm: dGELU/dReLU epilogue needs aux_in");
+    CTMI_REQUIRE((epilogue != CTMI_EPI_GELU && epilogue != CTMI_EPI_GELUG) || aux_out, "gemm: GELU epilogues need aux_out");
+    CTMI_REQUIRE((epilogue != CTMI_EPI_DGELU && epilogue != CTMI_EPI_DRELU && epilogue != CTMI_EPI_MUL) || aux_in, "gemm: dGELU/dReLU/MUL epilogues need aux_in");
     CTMI_REQUIRE(dtype == CTMI_F32 || dtype == CTMI_BF16, "gemm: unsupported dtype %d", dtype);
     const int es = dtype == CTMI_F32 ? 4 : 2;
     const int vec = 16 / es;

@@ -57,13 +57,17 @@ int ctmi_layernorm_bwd(const void* dy, const void* x, const float* w, const floa
  *     + bias[n] (fp32, NULL = none)
  *     CTMI_EPI_GELU : aux_out[m,n] = v (pre-activation, storage dtype);  v = bloom tanh-GELU(v)   (modeling_bloom.py:335-344)
  *     CTMI_EPI_DGELU: v *= gelu'(aux_in[m,n])                                                     (modeling_bloom.py:348-363)
+ *     CTMI_EPI_GELUG: aux_out[m,n] = gelu'(v) (storage dtype);  v = bloom tanh-GELU(v) — the forward leaves the DERIVATIVE
+ *                     for the backward (modeling_bloom.py:348-363 evaluated where its logistic factor already exists), and
+ *     CTMI_EPI_MUL  : v *= aux_in[m,n] is then the whole activation backward (one multiply in the data-gradient epilogue)
  *     CTMI_EPI_RELU : v = max(v,0)          CTMI_EPI_DRELU: v = aux_in[m,n] > 0 ? v : 0            (transformer.py:98-102 FFN)
  *     + residual[m,n] (storage dtype, NULL = none; ldc stride)                                     (modeling_bloom.py:122,269)
  *     beta=1: + C_old
  *   out_f32=1 writes C as fp32 regardless of dtype (parameter gradients).
  *   workspace (optional, may be NULL): scratch for deterministic split-K of small-tile-count problems (weight
  *   gradients): fp32 slabs [splits][M][N]; more workspace = more splits (up to 8). */
-enum ctmi_epilogue { CTMI_EPI_NONE = 0, CTMI_EPI_GELU = 1, CTMI_EPI_DGELU = 2, CTMI_EPI_RELU = 3, CTMI_EPI_DRELU = 4 };
+enum ctmi_epilogue { CTMI_EPI_NONE = 0, CTMI_EPI_GELU = 1, CTMI_EPI_DGELU = 2, CTMI_EPI_RELU = 3, CTMI_EPI_DRELU = 4,
+                     CTMI_EPI_GELUG = 5, CTMI_EPI_MUL = 6 };
 int ctmi_gemm(const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor,
               void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
               float alpha, int beta, const float* bias, const void* residual, int epilogue,

@@ -56,6 +56,12 @@ def gemm(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, *, out=None, out_f32=False
         v = _gelu(v)
     elif epilogue == 2:
         v = v * _dgelu(aux_in.float())
+    elif epilogue == 5:                                    # GELUG: the forward leaves gelu'(x) for the backward
+        v = v.to(cd).float()
+        aux_out.copy_(_dgelu(v).to(cd))
+        v = _gelu(v)
+    elif epilogue == 6:                                    # MUL
+        v = v * aux_in.float()
     elif epilogue == 3:
         v = torch.relu(v)
     elif epilogue == 4:

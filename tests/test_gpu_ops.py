@@ -189,6 +189,11 @@ def test_gemm_forward_dgrad_wgrad(dtype, rtol, atol, M, N, K):
     check("gemm.gelu.pre", u.float() * sc, pre * sc, rtol, atol)
     pre_seen = bf(pre) if dtype == torch.bfloat16 else pre
     check("gemm.gelu.out", gl.float() * sc, R.gelu_tanh(pre_seen) * sc, rtol * 3, atol * 3)
+    # GELUG: same activation output, but the saved tensor is gelu'(pre) for the backward's MUL epilogue (round 2)
+    gd = torch.empty((M, N), dtype=dtype, device=DEV)
+    gl2 = o.linear_fwd(xd, wd, (bias * 0.1).to(DEV), epilogue=L.EPI_GELUG, aux_out=gd)
+    assert torch.equal(gl2, gl)
+    check("gemm.gelug.grad", gd.float(), R.gelu_tanh_bwd(torch.ones_like(pre_seen), pre_seen), rtol * 3, atol * 3)
     rl = o.linear_fwd(xd, wd, (bias * 0.1).to(DEV), epilogue=L.EPI_RELU)
     check("gemm.relu", rl.float() * sc, torch.relu(pre) * sc, rtol, atol)
     # dgrad: dx = dy w   (w read K-major)
@@ -202,6 +207,8 @@ def test_gemm_forward_dgrad_wgrad(dtype, rtol, atol, M, N, K):
     auxs = bf(aux) if dtype == torch.bfloat16 else aux
     dxg = o.linear_dgrad(dyd, wd, epilogue=L.EPI_DGELU, aux_in=to_dev(aux, dtype))
     check("gemm.dgrad.dgelu", dxg.float() * scn, R.gelu_tanh_bwd(dys @ ws, auxs) * scn, rtol * 2, atol * 2)
+    dxm = o.linear_dgrad(dyd, wd, epilogue=L.EPI_MUL, aux_in=to_dev(aux, dtype))
+    check("gemm.dgrad.mul", dxm.float() * scn, (dys @ ws) * auxs * scn, rtol * 2, atol * 2)
     dxr = o.linear_dgrad(dyd, wd, epilogue=L.EPI_DRELU, aux_in=to_dev(aux, dtype))
     check("gemm.dgrad.drelu", dxr.float() * scn, torch.where(auxs > 0, dys @ ws, torch.zeros(())) * scn, rtol, atol)
     # wgrad: dW = dy^T x  (fp32 out, both operands K-major), and accumulation
