@@ -16,7 +16,7 @@
 
 // A/B knobs for tools/ variant builds (defaults = the adopted configuration)
 #ifndef CTMI_ATTN_FASTBODY
-#define CTMI_ATTN_FASTBODY 1     // backward kernels: mask-free loop body for tiles that cannot contain a masked score
+#define CTMI_ATTN_FASTBODY 0     // backward kernels: mask-free loop body for tiles that cannot contain a masked score (A/B: slower while it costs a wave per SIMD: 207 VGPRs)
 #endif
 #ifndef CTMI_ATTN_SWAPRED
 #define CTMI_ATTN_SWAPRED 1      // forward kernel: row-max across the 4 lane groups by v_permlane{16,32}_swap instead of ds_bpermute

@@ -422,7 +422,10 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce4(const float* __restrict__ 
     }
 }
 
-static const int LN_BWD_MAX_BLOCKS = 512;
+#ifndef CTMI_LN_BWD_BLOCKS
+#define CTMI_LN_BWD_BLOCKS 256      // one workgroup per CU: same-box A/B vs 512: 31.0 -> 21.4 us at [8192,1024] bf16 (half the end-of-kernel LDS combines and partial rows)
+#endif
+static const int LN_BWD_MAX_BLOCKS = 512;                               // workspace sizing (fixed); the launch uses CTMI_LN_BWD_BLOCKS <= this
 extern "C" int64_t ctmi_layernorm_bwd_ws(int64_t rows, int64_t cols) {
     (void)rows;
     return (int64_t)LN_BWD_MAX_BLOCKS * 4 * cols;          // up to 4 partial rows per block (dw, db, colsum(dres), colsum(dx))
@@ -442,7 +445,7 @@ static int ln_bwd_parts(const void* dy, const void* x, const float* w, const flo
     if (vec_ok) {
         const int mv = cols <= 64 * VEC ? 1 : (cols <= 2 * 64 * VEC ? 2 : (cols <= 4 * 64 * VEC ? 4 : 8));
         const int nw = lnb_waves(mv);
-        int grid = (int)std::min<int64_t>(cdiv64(rows, nw), LN_BWD_MAX_BLOCKS);
+        int grid = (int)std::min<int64_t>(cdiv64(rows, nw), CTMI_LN_BWD_BLOCKS);
         if (mv >= 4) {                                                  // wide rows: one workgroup per row, columns split over 4 waves
             grid = (int)std::min<int64_t>(rows, LN_BWD_MAX_BLOCKS);
             if (mv == 4) hipLaunchKernelGGL((ln_bwd_wide<T, 1>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, w, mean, rstd, (const T*)dres, (T*)dx, ws, rows, (int)cols);

@@ -436,7 +436,10 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
     const int ntile = tiles_m * tiles_n;
     const int nwork = ntile * g.splits;                                       // work items: (split, output tile)
     const int bid = blockIdx.x, G = gridDim.x;                                // G == nwork, or a multiple of 8 (persistent)
-    constexpr int GM = (WM == 8) ? 4 : 8;
+#ifndef CTMI_GEMM_GM256
+#define CTMI_GEMM_GM256 4
+#endif
+    constexpr int GM = (WM == 8) ? CTMI_GEMM_GM256 : 8;
     // work item w -> (split, tile origin).  Items w, w+8, w+16, ... run on one XCD (workgroup b lands on XCD b % 8), so
     // each XCD gets a CONTIGUOUS range of the grouped tile order and its private L2 sees the operand panels reused.
     auto decode = [&](int w, int64_t& m0, int64_t& n0, int& split) {
@@ -1085,6 +1088,9 @@ extern "C" int ctmi_get_launch_policy(int* shared, int* reserve_cus) {
 }
 #endif
 
+#ifndef CTMI_WGRAD_ITEMS
+#define CTMI_WGRAD_ITEMS 256     // (same-box A/B vs 512: -0.15 ms per step — half the fp32 slab traffic) split-K target of the layer weight gradients: work items (tiles x splits) to aim for
+#endif
 static void pick_tile(int64_t M, int64_t N, int64_t K, bool wgrad, bool bkm, int epi, int max_splits, int& tile, int& splits) {
     static int force = -2, force_split = -2;
     if (force == -2) { const char* e = getenv("CTMI_GEMM_TILE"); force = e ? atoi(e) : -1; }
@@ -1116,7 +1122,7 @@ static void pick_tile(int64_t M, int64_t N, int64_t K, bool wgrad, bool bkm, int
         else {
             tile = t1 >= 128 ? 1 : 0;
             const int64_t tiles = tile ? t1 : t0;
-            while (splits < max_splits && tiles * splits < 512 && K / (splits * 2) >= 1024) splits *= 2;
+            while (splits < max_splits && tiles * splits < CTMI_WGRAD_ITEMS && K / (splits * 2) >= 1024) splits *= 2;
         }
     } else if (K >= 32768 && max_splits >= 2 && t2 * 2 >= 192) { tile = 3; splits = 2; }
     else if (t2 >= 350) tile = 3;
@@ -1125,7 +1131,10 @@ static void pick_tile(int64_t M, int64_t N, int64_t K, bool wgrad, bool bkm, int
     else tile = 0;
     // epilogues that read a second [M,N] operand (activation-derivative input): only the 128-row ping-pong tile has the
     // registers to prefetch it a pass ahead (measured 112 vs 121 us on the [T,4H] DGELU dgrad)
-    if ((epi == CTMI_EPI_DGELU || epi == CTMI_EPI_DRELU || epi == CTMI_EPI_MUL) && tile == 3) tile = 4;
+#ifndef CTMI_GEMM_MUL_TILE3
+#define CTMI_GEMM_MUL_TILE3 0
+#endif
+    if ((epi == CTMI_EPI_DGELU || epi == CTMI_EPI_DRELU || (epi == CTMI_EPI_MUL && !CTMI_GEMM_MUL_TILE3)) && tile == 3) tile = 4;
     if (force >= 0) tile = force;
 }
 

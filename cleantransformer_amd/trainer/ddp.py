@@ -86,10 +86,11 @@ class _TiedGradSync:
         o = self.owner
         self._tmax = None
         self._announced = True
-        if o.world_size == 1:
+        on_rccl = dist.get_backend(o.process_group) == "nccl" and torch.device(device).type == "cuda"
+        if o.world_size == 1 and not on_rccl:
             self._tmax = int(n_tokens)
             return
-        if dist.get_backend(o.process_group) != "nccl" or not torch.device(device).type == "cuda":
+        if not on_rccl:
             t = torch.tensor([int(n_tokens)], dtype=torch.int64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=o.process_group)
             self._tmax = int(t[0])

