@@ -38,6 +38,7 @@ struct AttnP {
     int64_t q_bs, q_hs, q_rs, k_bs, k_hs, k_rs, v_bs, v_hs, v_rs, o_bs, o_hs, o_rs;
     int64_t am_b, am_h, am_q, am_k;
     float scale;
+    float future_fill;       // score of a (query, key) pair in the causal future whose key may be attended: FINFO_MIN (Bloom masked_fill) or GPT's -1e4
     int causal, off, vec_ok;
     int dbg;                 // timing experiments only (CTMI_ATTN_DBG): 1 = no steady-state global loads, 2 = no LDS restage
 };
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(256, CTMI_ATTN_MINW) void attn_fwd_kernel(AttnP p) 
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    x[nt][r] = (nt * 16 + r > thr) ? fminf(x[nt][r], FINFO_MIN) : x[nt][r];   // masked_fill; -inf (no such key) stays -inf
+                    x[nt][r] = (nt * 16 + r > thr) ? (kb4[nt][r] > FINFO_MIN ? p.future_fill : kb4[nt][r]) : x[nt][r];   // future: fill (padding stays finfo.min, no key stays -inf)
         }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) mx = max3f(max3f(mx, x[nt][0], x[nt][1]), x[nt][2], x[nt][3]);
@@ -587,6 +588,7 @@ __global__ __launch_bounds__(256, CTMI_ATTN_MINW) void attn_bwd_dkdv_kernel(Attn
     const float my_kb = key_bias(p, b, my_k, slope);                         // -inf: key row does not exist
     const bool key_live = my_kb > -INFINITY;
     const bool key_pad = my_kb <= FINFO_MIN;
+    const float lane_fill = key_pad ? FINFO_MIN : p.future_fill;            // what a masked score of this lane's key is replaced by
     const float* am_base = AM ? p.add_mask + b * p.am_b + h * p.am_h : nullptr;
 
     int qt_begin = 0;
@@ -668,7 +670,7 @@ __global__ __launch_bounds__(256, CTMI_ATTN_MINW) void attn_bwd_dkdv_kernel(Attn
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     msk[r] = (nt * 16 + r) < thr_m;
-                    s4[r] = msk[r] ? FINFO_MIN : s4[r];
+                    s4[r] = msk[r] ? lane_fill : s4[r];
                 }
             }
             const f32x4 e4 = (s4 - mm) * 1.4426950408889634f;                     // (s - m) first (finfo.min - finfo.min = 0)
@@ -860,6 +862,8 @@ static int fill_params(AttnP& p, const ctmi_attn_desc* d, int dtype, const char*
     p.v_bs = d->v_bs; p.v_hs = d->v_hs; p.v_rs = d->v_rs; p.o_bs = d->o_bs; p.o_hs = d->o_hs; p.o_rs = d->o_rs;
     p.am_b = d->am_b; p.am_h = d->am_h; p.am_q = d->am_q; p.am_k = d->am_k;
     p.scale = d->scale; p.causal = d->causal; p.off = (int)(d->Sk - d->Sq);
+    p.future_fill = d->future_fill == 0.0f ? FINFO_MIN : d->future_fill;
+    CTMI_REQUIRE(p.future_fill < 0.0f && p.future_fill >= FINFO_MIN, "%s: future_fill must be 0 (= finfo.min) or a negative finite value", who);
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("CTMI_ATTN_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
     const int vec = dtype == CTMI_F32 ? 4 : 8;
     auto ok = [&](const void* ptr, int64_t a, int64_t b2, int64_t c) {

@@ -10,9 +10,10 @@ What differs from the Bloom path, and how it maps onto the same kernels:
   * the fused ``c_attn`` activation is ``[B,S,3H]`` laid out q | k | v (modeling_gpt.py:71-73), not head-interleaved: the
     attention kernels take it through (batch, head, row) strides, no split / permute copies.
   * causal mask: the reference REPLACES future scores by -1e4 (``w*b - 1e4*(1-b)``, :88-89) and ADDS ``(1-mask)*finfo.min``
-    per key (:91-92, :172-175).  exp(-1e4 - rowmax) is exactly 0 in fp32 whenever a row has one visible unpadded key, so the
-    kernel's "future keys do not exist" causal mode gives identical probabilities; rows whose whole causal window is padding
-    (left padding) are the one place the reference attends to the future, and are not reproduced (right padding is exact).
+    per key (:91-92, :172-175).  exp(-1e4 - rowmax) is exactly 0 in fp32 whenever a row has one visible unpadded key; rows whose
+    whole causal window is padding (LEFT padding) are the one place the reference attends to the future — the -1e4 of the
+    future keys sits above the finfo.min of the padded visible ones.  The attention kernels take that fill value
+    (``ctmi_attn_desc.future_fill = -1e4``), so left-padded batches match the reference too (tests/golden/tiny_gpt_leftpad.npz).
   * ``gelu_new`` (:113-119) is the same tanh GELU as Bloom's: the GELU / dGELU GEMM epilogues serve it.
   * ``version='gpt'`` is the post-LN GPT-1 block (:138-143), anything else the pre-LN GPT-2 block with ``ln_f`` (:144-149).
   * every Dropout must be inactive (p = 0 or eval): note the reference's MLP ends in ``torch.nn.Dropout()`` with p = 0.5.
@@ -125,7 +126,7 @@ class GPTAttnFn(torch.autograd.Function):
         qkv = qkv if qkv.is_contiguous() else qkv.contiguous()
         q2 = qkv.view(B * S, H3)
         st = (S * H3, hd, H3)
-        desc = ops._strided_desc(B, nh, S, S, hd, st, st, st, (S * H, hd, H), scale, S > 1)
+        desc = ops._strided_desc(B, nh, S, S, hd, st, st, st, (S * H, hd, H), scale, S > 1, future_fill=-1e4)
         out = torch.empty((B, S, H), dtype=qkv.dtype, device=qkv.device)
         stat_m, stat_l = ops.attn_fwd(q2, q2[:, H:], q2[:, 2 * H:], out, desc, None, mask)
         ctx.save_for_backward(q2, out, stat_m, stat_l)
@@ -155,7 +156,7 @@ def _attend_cached(qkv: Tensor, past, mask: ops.MaskInfo, nh: int, scale: float)
     Sk = k.shape[-2]
     q2 = qkv.reshape(B * S, H3)
     cs = (nh * Sk * hd, Sk * hd, hd)
-    desc = ops._strided_desc(B, nh, S, Sk, hd, (S * H3, hd, H3), cs, cs, (S * H, hd, H), scale, S > 1)
+    desc = ops._strided_desc(B, nh, S, Sk, hd, (S * H3, hd, H3), cs, cs, (S * H, hd, H), scale, S > 1, future_fill=-1e4)
     out = torch.empty((B, S, H), dtype=qkv.dtype, device=qkv.device)
     ops.attn_fwd(q2, k, v, out, desc, None, mask)
     return out, (k, v)

@@ -193,7 +193,7 @@ class MaskInfo:
               "mask_prep")
 
 
-def _strided_desc(B, nh, Sq, Sk, hd, q_str, k_str, v_str, o_str, scale, causal, am_str=(0, 0, 0, 0)) -> AttnDesc:
+def _strided_desc(B, nh, Sq, Sk, hd, q_str, k_str, v_str, o_str, scale, causal, am_str=(0, 0, 0, 0), future_fill: float = 0.0) -> AttnDesc:
     d = AttnDesc()
     d.B, d.nh, d.Sq, d.Sk, d.hd = B, nh, Sq, Sk, hd
     d.q_bs, d.q_hs, d.q_rs = q_str
@@ -203,6 +203,7 @@ def _strided_desc(B, nh, Sq, Sk, hd, q_str, k_str, v_str, o_str, scale, causal, 
     d.am_b, d.am_h, d.am_q, d.am_k = am_str
     d.scale = float(scale)
     d.causal = int(causal)
+    d.future_fill = float(future_fill)                                # 0 = finfo.min (Bloom); GPT-2 passes -1e4 (modeling_gpt.py:88-89)
     return d
 
 

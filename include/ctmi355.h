@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CTMI_ABI_VERSION 2
+#define CTMI_ABI_VERSION 3
 
 enum ctmi_dtype { CTMI_F32 = 0, CTMI_BF16 = 1 };
 enum ctmi_status { CTMI_OK = 0, CTMI_ERR_ARG = -1, CTMI_ERR_LAUNCH = -2, CTMI_ERR_UNSUPPORTED = -3 };
@@ -104,6 +104,12 @@ typedef struct ctmi_attn_desc {
     int64_t am_b, am_h, am_q, am_k;
     float scale;
     int causal;
+    float future_fill;   /* score of a causally-future pair whose key is attendable.  0 = finfo(float).min: the bool-mask masked_fill
+                            of modeling_bloom.py:108-110.  GPT-2 replaces future scores by -1e4 instead (w*b - 1e4*(1-b),
+                            modeling_gpt.py:88-89): identical unless a query's whole causal window is padding (left padding) — then
+                            the -1e4 of the future keys is ABOVE the finfo.min of the padded visible ones and the reference attends to
+                            the future; pass -1e4 to reproduce that. */
+    int32_t reserved_;
 } ctmi_attn_desc;
 int ctmi_attn_fwd(const void* q, const void* k, const void* v, void* o, float* stat_m, float* stat_l,
                   const float* slopes, const float* kpos, const int32_t* kvalid, const int32_t* first_valid,

@@ -112,13 +112,18 @@ def _scores(q, k, desc, slopes, mask, add_mask):
     if add_mask is not None:
         s = s + add_mask.as_strided((B, nh, Sq, Sk), (desc.am_b, desc.am_h, desc.am_q, desc.am_k), add_mask.storage_offset())
     masked = torch.zeros(B, 1, Sq, Sk, dtype=torch.bool)
+    ff = float(getattr(desc, "future_fill", 0.0)) or FMIN            # 0 = finfo.min (Bloom); GPT-2: -1e4 on future pairs
     if desc.causal:
         qi = torch.arange(Sq).view(Sq, 1) + (Sk - Sq)
-        masked = masked | (torch.arange(Sk).view(1, Sk) > qi).view(1, 1, Sq, Sk)
+        fut = (torch.arange(Sk).view(1, Sk) > qi).view(1, 1, Sq, Sk)
+        masked = masked | fut
+        s = torch.where(fut.expand(B, nh, Sq, Sk), torch.full((), ff), s)
     if mask is not None:
-        masked = masked | (mask.kvalid.view(B, 1, 1, Sk) == 0)
+        pad = (mask.kvalid.view(B, 1, 1, Sk) == 0)
+        masked = masked | pad
+        s = torch.where(pad.expand(B, nh, Sq, Sk), torch.full((), FMIN), s)
     masked = masked.expand(B, nh, Sq, Sk)
-    return torch.where(masked, torch.full((), FMIN), s), masked
+    return s, masked
 
 
 def attn_fwd(q, k, v, out, desc, slopes, mask, add_mask=None):

@@ -372,6 +372,41 @@ def gen_gpt():
 
 
 # ---------------------------------------------------------------------------------------
+def gen_gpt_leftpad():
+    """LEFT-padded tiny GPT-2 batch through the reference's modeling_gpt.py.  Rows whose whole causal window is padding are the one
+    place the reference attends to the FUTURE (``w*b - 1e4*(1-b)`` leaves -1e4 on future keys, above the finfo.min of the padded
+    visible ones: modeling_gpt.py:88-93): logits, loss and every gradient of that case."""
+    from CleanTransformer.models import modeling_gpt as rg
+    V, H, L, nh, P, B, S = 173, 64, 2, 4, 64, 3, 24
+    cfg = rg.GPTConfig(vocab_size=V, n_embd=H, n_positions=P, n_layer=L, n_head=nh, n_ctx=P, embd_pdrop=0.0, attn_pdrop=0.0, resid_pdrop=0.0)
+    m = rg.GPTLMHeadModel(cfg, version="gpt2")
+    with torch.no_grad():
+        for i, (name, prm) in enumerate(m.named_parameters()):
+            r = torch.randn(prm.shape, generator=torch.Generator().manual_seed(1000 + i))
+            if prm.dim() > 1:
+                prm.copy_(r * 0.02)
+            elif ("norm" in name or "ln_f" in name) and name.endswith("weight"):
+                prm.copy_(1 + 0.1 * r)
+            else:
+                prm.copy_(0.02 * r)
+    for blk in m.gpt.blocks:
+        blk.mlp[3].p = 0.0
+    m.train()
+    ids = torch.randint(0, V, (B, S), generator=torch.Generator().manual_seed(7))
+    am = torch.ones(B, S, dtype=torch.long)
+    am[0, :5] = 0                                           # left padding
+    am[2, :9] = 0
+    am[2, 20:] = 0                                          # ... and a right-padded tail on the same row
+    (logits, hidden), _ = m(ids, attention_mask=am)
+    loss = torch.nn.CrossEntropyLoss()(logits[:, :-1, :].reshape(-1, V), ids[:, 1:].reshape(-1))
+    loss.backward()
+    out = dict(cfg=np.array([V, H, L, nh, P, B, S]), ids=npy(ids), mask=npy(am), logits0=npy(logits), loss0=npy(loss), gnorm0=np.array(gnorm(m)))
+    for n, prm in m.named_parameters():
+        out["g0_" + n] = npy(prm.grad)
+    np.savez_compressed(os.path.join(HERE, "tiny_gpt_leftpad.npz"), **out)
+    print("gpt leftpad loss", float(loss), "gnorm", gnorm(m))
+
+
 def gen_soft_ce():
     """Probability-target branch of the reference's CrossEntropyLoss (loss.py:43-46): losses and input gradients for normalised and
     un-normalised targets, both reductions, plus the inputs of the reference's own printed self-check (seed 999, loss.py:76-91)."""
@@ -557,6 +592,8 @@ if __name__ == "__main__":
         gen_c5()
     if "gpt" in which:
         gen_gpt()
+    if "gpt_leftpad" in which:
+        gen_gpt_leftpad()
     if "soft_ce" in which:
         gen_soft_ce()
     if "decode" in which:

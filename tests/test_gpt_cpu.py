@@ -117,3 +117,28 @@ def test_gpt_host_logic_greedy_decode_bit_exact(monkeypatch):
     out = m.generate(T(GPT["greedy_prompt"]), attention_mask=torch.ones(2, 7, dtype=torch.long),
                      generation_configs=dict(beam_size=1, max_gen_len=6, do_sample=False, end_ids=None, pad_id=3))
     assert np.array_equal(out.numpy(), GPT["greedy_out"])
+
+
+LP = np.load(os.path.join(G, "tiny_gpt_leftpad.npz"))
+
+
+def test_gpt_left_padding_oracle_and_host_logic_vs_reference_golden(monkeypatch):
+    """LEFT-padded batch (tests/golden/make_golden.py gpt_leftpad): rows whose whole causal window is padding attend to the FUTURE
+    in the reference (``w*b - 1e4*(1-b)`` leaves -1e4 on future keys, modeling_gpt.py:88-93).  Round 1 documented this as a
+    deviation; the attention entry points now take the fill value (ctmi_attn_desc.future_fill = -1e4)."""
+    s = shape("gpt2")
+    ids, am = T(LP["ids"]), T(LP["mask"])
+    p = GR.det_init(s)
+    loss, logits, _, grads = GR.loss_and_grads(p, s, ids, am)
+    close("oracle.loss", loss, LP["loss0"], 1e-6)
+    close("oracle.logits", logits, LP["logits0"], 1e-5, 1e-6)
+    for n, g in grads.items():
+        close("oracle.g0_" + n, g, LP["g0_" + n], 1e-4, 1e-8)
+    emu.install(monkeypatch)
+    m = build("gpt2")
+    (l2, lg2, _), _ = m(ids, attention_mask=am, labels=ids.clone())
+    l2.backward()
+    close("host.loss", l2, LP["loss0"], 1e-5)
+    close("host.logits", lg2, LP["logits0"], 1e-4, 1e-6)
+    for n, prm in m.named_parameters():
+        close("host.g0_" + n, prm.grad, LP["g0_" + n], 1e-4, 1e-8)

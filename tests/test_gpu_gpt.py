@@ -186,3 +186,24 @@ def test_gpt2_medium_seq2048_config3():
         losses.append(float(loss))
     assert all(math.isfinite(x) for x in losses) and losses[0] > losses[1] > losses[2], losses
     assert 9.0 < losses[0] < 14.0, losses                                                  # ln 50257 = 10.8
+
+
+def test_gpt_left_padding_matches_reference_golden():
+    """LEFT-padded GPT-2 batch against values produced by the reference itself (tests/golden/tiny_gpt_leftpad.npz): the rows whose
+    whole causal window is padding attend to future keys there (-1e4 fill, modeling_gpt.py:88-93) — reproduced by the kernels
+    through ctmi_attn_desc.future_fill, forward and backward, fp32 at the parity bar and bf16 tracking it."""
+    LP = np.load(os.path.join(G, "tiny_gpt_leftpad.npz"))
+    ids, am = T(LP["ids"]).to(DEV), T(LP["mask"]).to(DEV)
+    m = build(tiny("gpt2"))
+    (loss, logits, _), _ = m(ids, attention_mask=am, labels=ids.clone())
+    loss.backward()
+    assert abs(float(loss) - float(LP["loss0"])) <= 1e-5 * float(LP["loss0"])
+    close("logits", logits, LP["logits0"], 1e-4, 1e-5)
+    assert abs(gnorm(m) - float(LP["gnorm0"])) <= 1e-4 * float(LP["gnorm0"])
+    for n, p in m.named_parameters():
+        close("g0_" + n, p.grad, LP["g0_" + n], 2e-4, 5e-7)
+    mb = build(tiny("gpt2"), cd="bf16")
+    (lb, _, _), _ = mb(ids, attention_mask=am, labels=ids.clone())
+    lb.backward()
+    assert abs(float(lb) - float(LP["loss0"])) <= 5e-3 * float(LP["loss0"])
+    assert abs(gnorm(mb) - float(LP["gnorm0"])) <= 3e-2 * float(LP["gnorm0"])

@@ -40,7 +40,7 @@ def pmc(counter):
     return v
 
 
-steps = 13                                                                # bench.py default: 3 warm-up + 10 timed
+steps = 15                                                                # bench.py default: 3 warm-up + 2 (idle-queue host timing) + 10 timed
 a = kernel_table("prof_bench", steps, f"{rnd}: python bench.py --no-cpu-baseline (default: weight-gradient GEMMs on a side stream, kernels overlap)",
                  f"{rnd}_bench_kernel_summary.txt")
 b = kernel_table("prof_bench_1stream", steps, f"{rnd}: CTMI_WGRAD_STREAM=0 python bench.py --no-cpu-baseline (single stream: clean per-kernel durations)",
@@ -63,7 +63,7 @@ json.dump(traffic, open(os.path.join(dst, f"{rnd}_lmhead_traffic.json"), "w"), i
 # the plain result files of the collection travel as they are
 import shutil
 for name in (f"{rnd}_bench_default.json", f"{rnd}_bench_under_rocprof.json", f"{rnd}_bench_1stream_under_rocprof.json",
-             f"{rnd}_microbench.txt", f"{rnd}_gemm_tile_sweep.txt"):
+             f"{rnd}_microbench.txt", f"{rnd}_gemm_tile_sweep.txt", f"{rnd}_vendor_gemm_reference.txt"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, name))
 shutil.copy(one("prof_bench/*/*_kernel_stats.csv"), os.path.join(dst, f"{rnd}_bench_kernel_stats.csv"))
