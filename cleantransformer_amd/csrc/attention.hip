@@ -273,6 +273,28 @@ __device__ __forceinline__ float group_max4(float v) {
 #endif
 }
 
+// sum over the 4 lane groups, same idiom
+__device__ __forceinline__ float group_sum4(float v) {
+#if CTMI_ATTN_SWAPRED
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    float c = a + b, d = c;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(c), "+v"(d));
+    return c + d;
+#else
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+#endif
+}
+// dot product of two operand fragments (the lane's KL consecutive head-dim elements of two rows)
+__device__ __forceinline__ float frag_dot(short8 a, short8 b) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += bf2f((bf16_t)a[j]) * bf2f((bf16_t)b[j]);
+    return s;
+}
+__device__ __forceinline__ float frag_dot(float a, float b) { return a * b; }
+
 // Per-key additive bias staged once per tile (one float per key):
 //    slope * ALiBi position            for a key that may be attended            (modeling_bloom.py:328-330)
 //    FINFO_MIN                          for a padding key (attention_mask == 0): fma(dot, scale, FINFO_MIN) == FINFO_MIN
@@ -474,75 +496,6 @@ __global__ __launch_bounds__(256, CTMI_ATTN_MINW) void attn_fwd_kernel(AttnP p) 
             p.stat_m[(b * p.nh + h) * p.Sq + my_q] = m;
             p.stat_l[(b * p.nh + h) * p.Sq + my_q] = lsum;
         }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ delta = rowsum(dO * O)
-template <typename T>
-__global__ __launch_bounds__(256) void attn_delta_kernel(AttnP p) {
-    constexpr int VEC = 16 / sizeof(T);
-    const int64_t rows = p.B * p.nh * p.Sq;
-    const bool fast = p.vec_ok && (p.hd % VEC == 0) && (64 % (p.hd / VEC) == 0) && (p.hd / VEC) <= 16;
-    if (fast && p.o_hs == p.hd && p.o_rs == p.nh * p.hd && p.o_bs == p.Sq * p.o_rs) {
-        // merged-head layout [B*Sq, nh*hd] (the training path): one wave walks one token row, 64 lanes x 16 B = 1 KiB of
-        // consecutive heads per step — fully coalesced (the per-(b,h,q) row order reads hd-sized pieces nh*hd apart:
-        // measured 0.5 TB/s at H = 4096), and no per-lane 64-bit div/mod
-        const int lpr = (int)p.hd / VEC, hps = 64 / lpr;                      // lanes per head, heads per 1-KiB step
-        const int lane = threadIdx.x & 63, sub = lane % lpr, hin = lane / lpr;
-        const int64_t tokens = p.B * p.Sq, rowlen = p.nh * p.hd;
-        const T* O = reinterpret_cast<const T*>(p.o);
-        const T* G = reinterpret_cast<const T*>(p.d_o);
-        for (int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); tok < tokens; tok += (int64_t)gridDim.x * 4) {
-            const int64_t b = tok / p.Sq, q = tok - b * p.Sq;                 // wave-uniform
-            for (int64_t h0 = 0; h0 < p.nh; h0 += hps) {
-                const int64_t h = h0 + hin;
-                float s = 0.f;
-                if (h < p.nh) {
-                    const int64_t off = tok * rowlen + h * p.hd + sub * VEC;
-                    float a[VEC], c[VEC];
-                    unpack16<T>(*reinterpret_cast<const uint4*>(O + off), a);
-                    unpack16<T>(*reinterpret_cast<const uint4*>(G + off), c);
-#pragma unroll
-                    for (int j = 0; j < VEC; ++j) s += a[j] * c[j];
-                }
-                for (int o = lpr >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-                if (h < p.nh && sub == 0) p.delta[(b * p.nh + h) * p.Sq + q] = s;
-            }
-        }
-        return;
-    }
-    if (fast) {
-        // hd/VEC lanes per row (8 for hd = 64 bf16), 16-byte loads, xor-shuffle reduce inside the lane group
-        const int lpr = (int)p.hd / VEC, rpw = 64 / lpr;
-        const int lane = threadIdx.x & 63, sub = lane % lpr, rin = lane / lpr;
-        const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
-        for (int64_t r0 = wave0 * rpw; r0 < rows; r0 += nw * rpw) {
-            const int64_t row = r0 + rin;
-            float s = 0.f;
-            if (row < rows) {
-                const int64_t q = row % p.Sq, bh = row / p.Sq, h = bh % p.nh, b = bh / p.nh;
-                const int64_t base = b * p.o_bs + h * p.o_hs + q * p.o_rs + sub * VEC;
-                float a[VEC], c[VEC];
-                unpack16<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.o) + base), a);
-                unpack16<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.d_o) + base), c);
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) s += a[j] * c[j];
-            }
-            for (int o = lpr >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-            if (row < rows && sub == 0) p.delta[row] = s;
-        }
-        return;
-    }
-    const int lane = threadIdx.x & 63;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
-        const int64_t q = row % p.Sq, bh = row / p.Sq, h = bh % p.nh, b = bh / p.nh;
-        const int64_t base = b * p.o_bs + h * p.o_hs + q * p.o_rs;
-        const T* o = reinterpret_cast<const T*>(p.o) + base;
-        const T* go = reinterpret_cast<const T*>(p.d_o) + base;
-        float s = 0.f;
-        for (int d = lane; d < p.hd; d += 64) s += Cvt<T>::to_f(o[d]) * Cvt<T>::to_f(go[d]);
-        s = wave_sum(s);
-        if (lane == 0) p.delta[row] = s;
     }
 }
 
@@ -760,7 +713,18 @@ __global__ __launch_bounds__(256, CTMI_ATTN_MINW) void attn_bwd_dq_kernel(AttnP 
     const int64_t srow = (b * p.nh + h) * p.Sq + my_q;
     const float m = live ? p.stat_m[srow] : 0.f;
     const float il = live ? 1.0f / p.stat_l[srow] : 0.f;
-    const float dl = live ? p.delta[srow] : 0.f;
+    // delta = rowsum(dO * O) of the lane's own query row, formed here from the dO fragments the kernel holds anyway plus the
+    // matching O fragments (the 4 lane groups own the 4 quarters of every 32-wide k-step), and published for the dK/dV kernel,
+    // which runs after this one: the separate attn_delta launch (one per layer and step) is gone.
+    float dl = 0.f;
+    {
+        const T* orow = reinterpret_cast<const T*>(p.o) + b * p.o_bs + h * p.o_hs + my_q * p.o_rs;
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk)
+            dl += frag_dot(frag_global<T, FAST>(live ? orow : nullptr, kk * MK + g * KL, hd_, vok), gf[kk]);
+        dl = group_sum4(dl);
+        if (live && g == 0) p.delta[srow] = dl;
+    }
     const float* am_base = AM ? p.add_mask + b * p.am_b + h * p.am_h : nullptr;
     const int q_eff = live ? (int)my_q : 0;
 
@@ -895,10 +859,13 @@ static int fwd_launch(AttnP& p, hipStream_t st) {
 template <typename T, int HDP>
 static int bwd_launch(AttnP& p, hipStream_t st) {
     using A = AT<T, HDP>;
-    {
-        const int64_t rows = p.B * p.nh * p.Sq;
-        hipLaunchKernelGGL((attn_delta_kernel<T>), dim3((unsigned)std::min<int64_t>(cdiv64(rows, 4), 8192)), dim3(256), 0, st, p);
-        CTMI_CHECK_LAUNCH("attn_delta");
+    {   // dQ first: it also publishes delta = rowsum(dO * O) for the dK/dV kernel below (same stream: ordered)
+        const size_t lds = (size_t)DqStage<T, HDP>::BYTES * nbuf_for(DqStage<T, HDP>::BYTES);
+        const int64_t grid = ((p.Sq + 63) / 64) * p.B * p.nh;
+        if (p.add_mask) launch_k(&attn_bwd_dq_kernel<T, HDP, true, false>, grid, lds, st, p);
+        else if (p.vec_ok && p.hd == HDP) launch_k(&attn_bwd_dq_kernel<T, HDP, false, true>, grid, lds, st, p);
+        else launch_k(&attn_bwd_dq_kernel<T, HDP, false, false>, grid, lds, st, p);
+        CTMI_CHECK_LAUNCH("attn_bwd_dq");
     }
     {
         const size_t lds = (size_t)DkdvStage<T, HDP>::BYTES * nbuf_for(DkdvStage<T, HDP>::BYTES);
@@ -907,14 +874,6 @@ static int bwd_launch(AttnP& p, hipStream_t st) {
         else if (p.vec_ok && p.hd == HDP) launch_k(&attn_bwd_dkdv_kernel<T, HDP, false, true>, grid, lds, st, p);
         else launch_k(&attn_bwd_dkdv_kernel<T, HDP, false, false>, grid, lds, st, p);
         CTMI_CHECK_LAUNCH("attn_bwd_dkdv");
-    }
-    {
-        const size_t lds = (size_t)DqStage<T, HDP>::BYTES * nbuf_for(DqStage<T, HDP>::BYTES);
-        const int64_t grid = ((p.Sq + 63) / 64) * p.B * p.nh;
-        if (p.add_mask) launch_k(&attn_bwd_dq_kernel<T, HDP, true, false>, grid, lds, st, p);
-        else if (p.vec_ok && p.hd == HDP) launch_k(&attn_bwd_dq_kernel<T, HDP, false, true>, grid, lds, st, p);
-        else launch_k(&attn_bwd_dq_kernel<T, HDP, false, false>, grid, lds, st, p);
-        CTMI_CHECK_LAUNCH("attn_bwd_dq");
     }
     return CTMI_OK;
 }
