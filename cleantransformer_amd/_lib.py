@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("CTMI_LIB_PATH") or _DEFAULT_LIB_PATH
 F32, BF16 = 0, 1
 EPI_NONE, EPI_GELU, EPI_DGELU, EPI_RELU, EPI_DRELU, EPI_GELUG, EPI_MUL = 0, 1, 2, 3, 4, 5, 6
 MT_MAX = 24
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 
@@ -31,7 +31,7 @@ class AttnDesc(C.Structure):
     _fields_ = [(n, i64) for n in ("B", "nh", "Sq", "Sk", "hd",
                                    "q_bs", "q_hs", "q_rs", "k_bs", "k_hs", "k_rs",
                                    "v_bs", "v_hs", "v_rs", "o_bs", "o_hs", "o_rs",
-                                   "am_b", "am_h", "am_q", "am_k")] + [("scale", f32), ("causal", i32), ("future_fill", f32), ("reserved_", i32)]
+                                   "am_b", "am_h", "am_q", "am_k")] + [("scale", f32), ("causal", i32), ("future_fill", f32), ("dropout_seed", C.c_uint32), ("dropout_p", f32), ("reserved_", i32)]
 
 
 class ReduceJob(C.Structure):
@@ -83,6 +83,9 @@ PROTOTYPES = {
     "ctmi_bloom_block_bwd": (i32, [C.POINTER(BloomBlock), C.POINTER(BloomBlockGrads), vp]),
     "ctmi_ce_soft_fwd": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, i64, i32, i64, i32, vp]),
     "ctmi_ce_soft_bwd": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, vp, i64, i64, i64, i32, vp]),
+    "ctmi_dropout_hash": (C.c_uint32, [C.c_uint32]),
+    "ctmi_dropout_threshold": (C.c_uint32, [f32]),
+    "ctmi_dropout": (i32, [vp, vp, vp, i64, f32, C.c_uint32, i32, vp]),
     "ctmi_adamw_step": (i32, [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64),
                               i32, f32, f32, f32, f32, f32, i32, i32, i32, f32, vp]),
     "ctmi_sgd_step": (i32, [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64),

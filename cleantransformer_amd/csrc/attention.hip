@@ -38,6 +38,8 @@ struct AttnP {
     int64_t q_bs, q_hs, q_rs, k_bs, k_hs, k_rs, v_bs, v_hs, v_rs, o_bs, o_hs, o_rs;
     int64_t am_b, am_h, am_q, am_k;
     float scale;
+    uint32_t drop_thr, drop_seed;  // attention-probability dropout: keep(b,h,q,k) = hash32(counter ^ seed) >= thr (0 = off)
+    float drop_scale;        // 1 / (1 - p)
     float future_fill;       // score of a (query, key) pair in the causal future whose key may be attended: FINFO_MIN (Bloom masked_fill) or GPT's -1e4
     int causal, off, vec_ok;
     int dbg;                 // timing experiments only (CTMI_ATTN_DBG): 1 = no steady-state global loads, 2 = no LDS restage
@@ -356,7 +358,7 @@ template <typename T, int HDP> struct DkdvStage { static constexpr int BYTES = 2
 template <typename T, int HDP> struct DqStage { static constexpr int BYTES = 2 * AT<T, HDP>::RM_ELEMS * (int)sizeof(T) + 256; };
 constexpr int nbuf_for(int stage_bytes) { return CTMI_ATTN_NBUF ? CTMI_ATTN_NBUF : (2 * stage_bytes <= 80 * 1024 ? 2 : 1); }
 
-template <typename T, int HDP, bool AM, bool FAST>
+template <typename T, int HDP, bool AM, bool FAST, bool DROP = false>
 __global__ __launch_bounds__(256, CTMI_ATTN_MINW) void attn_fwd_kernel(AttnP p) {
     using A = AT<T, HDP>;
     constexpr int MK = Mma<T>::K, KL = Mma<T>::KL, NKK = HDP / MK, NDT = HDP / 16;
@@ -471,6 +473,16 @@ __global__ __launch_bounds__(256, CTMI_ATTN_MINW) void attn_fwd_kernel(AttnP p) 
         }
         const float rs = (rs4[0] + rs4[1]) + (rs4[2] + rs4[3]);
         lsum = lsum * alpha + rs;
+        if constexpr (DROP) {
+            // torch.nn.Dropout on the NORMALISED probabilities (modeling_bloom.py:111, modeling_gpt.py:96, transformer.py:46-47): the
+            // row sum above stays undropped, the values that meet V are masked and scaled by 1/(1-p)
+            const uint32_t c0 = (uint32_t)(((b * p.nh + h) * p.Sq + q_eff) * p.Sk + kv0 + g * 4);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    x[nt][r] = ctmi_hash32((c0 + (uint32_t)(nt * 16 + r)) ^ p.drop_seed) >= p.drop_thr ? x[nt][r] * p.drop_scale : 0.f;
+        }
         if (__any(m_new > m)) {                                              // wave-uniform: rescale only when some row max moved
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) acc[dt] *= alpha;
@@ -502,7 +514,7 @@ __global__ __launch_bounds__(256, CTMI_ATTN_MINW) void attn_fwd_kernel(AttnP p) 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
 // own rows = keys.  Per query tile: S = Q K^T and dP = dO V^T (own key in the accumulator column), P = exp(S-m)/l,
 // dS = P (dP - delta); dV^T += dO^T P, dK^T += Q^T dS  (Q, dO staged both row-major and transposed).
-template <typename T, int HDP, bool AM, bool FAST>
+template <typename T, int HDP, bool AM, bool FAST, bool DROP = false>
 __global__ __launch_bounds__(256, CTMI_ATTN_MINW) void attn_bwd_dkdv_kernel(AttnP p) {
     using A = AT<T, HDP>;
     constexpr int MK = Mma<T>::K, KL = Mma<T>::KL, NKK = HDP / MK, NDT = HDP / 16;
@@ -542,6 +554,7 @@ __global__ __launch_bounds__(256, CTMI_ATTN_MINW) void attn_bwd_dkdv_kernel(Attn
     const bool key_live = my_kb > -INFINITY;
     const bool key_pad = my_kb <= FINFO_MIN;
     const float lane_fill = key_pad ? FINFO_MIN : p.future_fill;            // what a masked score of this lane's key is replaced by
+    const uint32_t drop_c0 = (uint32_t)((b * p.nh + h) * p.Sq * p.Sk + my_k);                  // dropout counter of (q, my_k) = drop_c0 + q * Sk
     const float* am_base = AM ? p.add_mask + b * p.am_b + h * p.am_h : nullptr;
 
     int qt_begin = 0;
@@ -635,12 +648,21 @@ __global__ __launch_bounds__(256, CTMI_ATTN_MINW) void attn_bwd_dkdv_kernel(Attn
 #pragma unroll
                 for (int r = 0; r < 4; ++r) p4[r] = ((nt * 16 + r) < thr_v) ? p4[r] : 0.f;
             }
-            f32x4 d4 = p4 * (y[nt] - dl);                                         // already 0 where the row / key does not exist
+            f32x4 pv4 = p4, dp4 = y[nt];
+            if constexpr (DROP) {                                                 // O = dropout(P) V:  dV uses dropout(P), dP = mask/(1-p) * (dO V^T)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool keep = ctmi_hash32((drop_c0 + (uint32_t)(qbase + nt * 16 + r) * (uint32_t)p.Sk) ^ p.drop_seed) >= p.drop_thr;
+                    pv4[r] = keep ? p4[r] * p.drop_scale : 0.f;
+                    dp4[r] = keep ? dp4[r] * p.drop_scale : 0.f;
+                }
+            }
+            f32x4 d4 = p4 * (dp4 - dl);                                           // already 0 where the row / key does not exist
             if constexpr (MASKED) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) d4[r] = msk[r] ? 0.f : d4[r];        // masked entries: P kept (uniform rows), dS = 0
             }
-            x[nt] = p4;
+            x[nt] = pv4;
             y[nt] = d4;
         }
         contract64<T, HDP>(dv, GS(cur), x, lane);                            // dV^T[d][my_k] += sum_q dO[q][d] P[q][my_k]
@@ -676,7 +698,7 @@ __global__ __launch_bounds__(256, CTMI_ATTN_MINW) void attn_bwd_dkdv_kernel(Attn
 
 // ------------------------------------------------------------------------------------------------ backward: dQ
 // own rows = queries.  Per key tile: S^T = K Q^T, dP^T = V dO^T, dS^T = P^T (dP^T - delta); dQ^T += K^T dS^T.
-template <typename T, int HDP, bool AM, bool FAST>
+template <typename T, int HDP, bool AM, bool FAST, bool DROP = false>
 __global__ __launch_bounds__(256, CTMI_ATTN_MINW) void attn_bwd_dq_kernel(AttnP p) {
     using A = AT<T, HDP>;
     constexpr int MK = Mma<T>::K, KL = Mma<T>::KL, NKK = HDP / MK, NDT = HDP / 16;
@@ -783,7 +805,14 @@ __global__ __launch_bounds__(256, CTMI_ATTN_MINW) void attn_bwd_dq_kernel(AttnP 
             f32x4 p4;
 #pragma unroll
             for (int r = 0; r < 4; ++r) p4[r] = __builtin_amdgcn_exp2f(e4[r]);
-            f32x4 d4 = (p4 * il) * (y[nt] - dl);
+            f32x4 dp4 = y[nt];
+            if constexpr (DROP) {
+                const uint32_t c0 = (uint32_t)(((b * p.nh + h) * p.Sq + q_eff) * p.Sk + k0t);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    dp4[r] = ctmi_hash32((c0 + (uint32_t)r) ^ p.drop_seed) >= p.drop_thr ? dp4[r] * p.drop_scale : 0.f;
+            }
+            f32x4 d4 = (p4 * il) * (dp4 - dl);
             if constexpr (MASKED) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -826,6 +855,9 @@ static int fill_params(AttnP& p, const ctmi_attn_desc* d, int dtype, const char*
     p.v_bs = d->v_bs; p.v_hs = d->v_hs; p.v_rs = d->v_rs; p.o_bs = d->o_bs; p.o_hs = d->o_hs; p.o_rs = d->o_rs;
     p.am_b = d->am_b; p.am_h = d->am_h; p.am_q = d->am_q; p.am_k = d->am_k;
     p.scale = d->scale; p.causal = d->causal; p.off = (int)(d->Sk - d->Sq);
+    CTMI_REQUIRE(d->dropout_p >= 0.0f && d->dropout_p < 1.0f, "%s: dropout_p must be in [0, 1)", who);
+    p.drop_thr = ctmi_drop_threshold(d->dropout_p); p.drop_seed = d->dropout_seed;
+    p.drop_scale = 1.0f / (1.0f - d->dropout_p);
     p.future_fill = d->future_fill == 0.0f ? FINFO_MIN : d->future_fill;
     CTMI_REQUIRE(p.future_fill < 0.0f && p.future_fill >= FINFO_MIN, "%s: future_fill must be 0 (= finfo.min) or a negative finite value", who);
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("CTMI_ATTN_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
@@ -850,9 +882,12 @@ static int fwd_launch(AttnP& p, hipStream_t st) {
     using A = AT<T, HDP>;
     const size_t lds = (size_t)FwdStage<T, HDP>::BYTES * nbuf_for(FwdStage<T, HDP>::BYTES);
     const int64_t grid = ((p.Sq + 63) / 64) * p.B * p.nh;
-    if (p.add_mask) launch_k(&attn_fwd_kernel<T, HDP, true, false>, grid, lds, st, p);
-    else if (p.vec_ok && p.hd == HDP) launch_k(&attn_fwd_kernel<T, HDP, false, true>, grid, lds, st, p);
-    else launch_k(&attn_fwd_kernel<T, HDP, false, false>, grid, lds, st, p);
+    if (p.drop_thr != 0) {                                             // dropout instantiations: general kernels only (not the measured path)
+            if (p.add_mask) launch_k(&attn_fwd_kernel<T, HDP, true, false, true>, grid, lds, st, p);
+            else launch_k(&attn_fwd_kernel<T, HDP, false, false, true>, grid, lds, st, p);
+        } else if (p.add_mask) launch_k(&attn_fwd_kernel<T, HDP, true, false>, grid, lds, st, p);
+        else if (p.vec_ok && p.hd == HDP) launch_k(&attn_fwd_kernel<T, HDP, false, true>, grid, lds, st, p);
+        else launch_k(&attn_fwd_kernel<T, HDP, false, false>, grid, lds, st, p);
     CTMI_CHECK_LAUNCH("attn_fwd");
     return CTMI_OK;
 }
@@ -862,7 +897,10 @@ static int bwd_launch(AttnP& p, hipStream_t st) {
     {   // dQ first: it also publishes delta = rowsum(dO * O) for the dK/dV kernel below (same stream: ordered)
         const size_t lds = (size_t)DqStage<T, HDP>::BYTES * nbuf_for(DqStage<T, HDP>::BYTES);
         const int64_t grid = ((p.Sq + 63) / 64) * p.B * p.nh;
-        if (p.add_mask) launch_k(&attn_bwd_dq_kernel<T, HDP, true, false>, grid, lds, st, p);
+        if (p.drop_thr != 0) {                                             // dropout instantiations: general kernels only (not the measured path)
+            if (p.add_mask) launch_k(&attn_bwd_dq_kernel<T, HDP, true, false, true>, grid, lds, st, p);
+            else launch_k(&attn_bwd_dq_kernel<T, HDP, false, false, true>, grid, lds, st, p);
+        } else if (p.add_mask) launch_k(&attn_bwd_dq_kernel<T, HDP, true, false>, grid, lds, st, p);
         else if (p.vec_ok && p.hd == HDP) launch_k(&attn_bwd_dq_kernel<T, HDP, false, true>, grid, lds, st, p);
         else launch_k(&attn_bwd_dq_kernel<T, HDP, false, false>, grid, lds, st, p);
         CTMI_CHECK_LAUNCH("attn_bwd_dq");
@@ -870,7 +908,10 @@ static int bwd_launch(AttnP& p, hipStream_t st) {
     {
         const size_t lds = (size_t)DkdvStage<T, HDP>::BYTES * nbuf_for(DkdvStage<T, HDP>::BYTES);
         const int64_t grid = ((p.Sk + 63) / 64) * p.B * p.nh;
-        if (p.add_mask) launch_k(&attn_bwd_dkdv_kernel<T, HDP, true, false>, grid, lds, st, p);
+        if (p.drop_thr != 0) {                                             // dropout instantiations: general kernels only (not the measured path)
+            if (p.add_mask) launch_k(&attn_bwd_dkdv_kernel<T, HDP, true, false, true>, grid, lds, st, p);
+            else launch_k(&attn_bwd_dkdv_kernel<T, HDP, false, false, true>, grid, lds, st, p);
+        } else if (p.add_mask) launch_k(&attn_bwd_dkdv_kernel<T, HDP, true, false>, grid, lds, st, p);
         else if (p.vec_ok && p.hd == HDP) launch_k(&attn_bwd_dkdv_kernel<T, HDP, false, true>, grid, lds, st, p);
         else launch_k(&attn_bwd_dkdv_kernel<T, HDP, false, false>, grid, lds, st, p);
         CTMI_CHECK_LAUNCH("attn_bwd_dkdv");

@@ -92,5 +92,18 @@ __device__ __forceinline__ f32x2 gelu_tanh_grad_pk(f32x2 x) {
 __device__ __forceinline__ float gelu_tanh_f(float x) { return gelu_tanh_pk(f32x2{x, x})[0]; }
 __device__ __forceinline__ float gelu_tanh_grad_f(float x) { return gelu_tanh_grad_pk(f32x2{x, x})[0]; }
 
+// ---------------------------------------------------------------- dropout: counter-based keep mask
+// keep(i) = hash32(i ^ seed) >= thr with thr = p * 2^32: a pure function of the element's 32-bit counter and a per-call seed,
+// so the backward regenerates the mask instead of storing it (no [S,S] or [T,H] mask tensor ever exists).  hash32 = the "lowbias32"
+// integer finaliser (two multiplies, three xor-shifts); seeds come well mixed from the host (cleantransformer_amd/rng.py).
+__host__ __device__ __forceinline__ uint32_t ctmi_hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x21f0aaadu; x ^= x >> 15; x *= 0x735a2d97u; x ^= x >> 15;
+    return x;
+}
+static inline uint32_t ctmi_drop_threshold(float p) {                  // p in [0, 1): P(hash < thr) = p to 2^-32
+    const double t = (double)p * 4294967296.0;
+    return t <= 0.0 ? 0u : (t >= 4294967295.0 ? 4294967295u : (uint32_t)t);
+}
+
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -616,6 +616,50 @@ extern "C" int ctmi_colsum(const void* x, int64_t ld, float* out, int accumulate
 }
 
 // ------------------------------------------------------------------------------------------------
+// activation dropout (hidden / embedding / residual-branch dropout of the reference's modules)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_k(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y, int64_t n,
+                                                 uint32_t thr, uint32_t seed, float scale, int vec_ok) {
+    constexpr int VEC = 16 / sizeof(T);
+    const int64_t nv = vec_ok ? n / VEC : 0;
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nv; v += (int64_t)gridDim.x * 256) {
+        float a[VEC], r[VEC];
+        unpack16<T>(*reinterpret_cast<const uint4*>(x + v * VEC), a);
+        if (res != nullptr) unpack16<T>(*reinterpret_cast<const uint4*>(res + v * VEC), r);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const bool keep = ctmi_hash32((uint32_t)(v * VEC + j) ^ seed) >= thr;
+            a[j] = keep ? a[j] * scale : 0.f;
+            if (res != nullptr) a[j] += r[j];
+        }
+        *reinterpret_cast<uint4*>(y + v * VEC) = pack16<T>(a);
+    }
+    for (int64_t i = nv * VEC + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const bool keep = ctmi_hash32((uint32_t)i ^ seed) >= thr;
+        float a = keep ? Cvt<T>::to_f(x[i]) * scale : 0.f;
+        if (res != nullptr) a += Cvt<T>::to_f(res[i]);
+        y[i] = Cvt<T>::from_f(a);
+    }
+}
+extern "C" uint32_t ctmi_dropout_hash(uint32_t x) { return ctmi_hash32(x); }
+extern "C" uint32_t ctmi_dropout_threshold(float p) { return ctmi_drop_threshold(p); }
+extern "C" int ctmi_dropout(const void* x, const void* residual, void* y, int64_t n, float p, uint32_t seed, int dtype, void* stream) {
+    CTMI_REQUIRE(x && y && n >= 0, "dropout: bad args");
+    CTMI_REQUIRE(p >= 0.0f && p < 1.0f, "dropout: p must be in [0, 1)");
+    if (n == 0) return CTMI_OK;
+    const uint32_t thr = ctmi_drop_threshold(p);
+    const float scale = 1.0f / (1.0f - p);
+    const unsigned grid = (unsigned)std::min<int64_t>(cdiv64(n, 256 * 8), 8192);
+    const int vec_ok = aligned16(x) && aligned16(y) && (residual == nullptr || aligned16(residual));
+    if (dtype == CTMI_F32) hipLaunchKernelGGL((dropout_k<float>), dim3(grid), dim3(256), 0, as_stream(stream), (const float*)x, (const float*)residual, (float*)y, n, thr, seed, scale, vec_ok);
+    else if (dtype == CTMI_BF16) hipLaunchKernelGGL((dropout_k<bf16_t>), dim3(grid), dim3(256), 0, as_stream(stream), (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, n, thr, seed, scale, vec_ok);
+    else { ctmi_set_error("dropout: unsupported dtype %d", dtype); return CTMI_ERR_UNSUPPORTED; }
+    CTMI_CHECK_LAUNCH("dropout");
+    return CTMI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // multi-job partial-row reduction: dst[c] (+)= alpha * sum_p src[p * part_stride + c], c < n, for up to CTMI_REDUCE_MAX_JOBS
 // independent jobs in ONE launch (fixed summation order: deterministic).  A transformer block's backward leaves the partial
 // rows of its two LayerNorm backward passes and its bias column sums in workspaces and reduces them all here, instead of one

@@ -140,6 +140,87 @@ class BloomBlockFn(torch.autograd.Function):
         return (dx.view(B, S, H), *g, None, None, None, None)
 
 
+class BloomBlockDropoutFn(torch.autograd.Function):
+    """The same block with dropout (modeling_bloom.py:111 attention_dropout on the softmax output, :122 and :270 hidden_dropout on
+    the two projections before their residual adds), training mode, p > 0.  Per-op launches from Python: no Bloom checkpoint of
+    the SFT path uses dropout (bloom-560m / 7b1: 0.0), so this is the complete-but-unmeasured variant; the measured path is the
+    one-call BloomBlockFn above.  The masks are the kernels' counter-based ones (ops.dropout, ctmi_attn_desc.dropout_*): three
+    seeds per block and forward, nothing but the seeds is saved for the backward."""
+
+    @staticmethod
+    def forward(ctx, x, ln1_w, ln1_b, wqkv, bqkv, wd, bd, ln2_w, ln2_b, w1, b1, w2, b2, actx: _AttnCtx, eps: float,
+                post_ln_res: bool, p_hidden: float, p_attn: float, seeds, kv_out: list):
+        B, S, H = x.shape
+        T = B * S
+        nh = actx.nh
+        hd = H // nh
+        cd = x.dtype
+        x2 = x.reshape(T, H)
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        wqkv_c, wd_c = ops.compute_weight(wqkv, cd), ops.compute_weight(wd, cd)
+        w1_c, w2_c = ops.compute_weight(w1, cd), ops.compute_weight(w2, cd)
+        s_attn, s_h1, s_h2 = seeds
+        ln1, mean1, rstd1 = ops.layernorm_fwd(x2, ln1_w.detach(), ln1_b.detach(), eps)
+        qkv = ops.linear_fwd(ln1, wqkv_c, bqkv.detach())
+        desc = ops.fused_qkv_desc(B, S, nh, hd, causal=S > 1, dropout_p=p_attn, dropout_seed=s_attn)
+        att = torch.empty((T, H), dtype=cd, device=x.device)
+        stat_m, stat_l = ops.attn_fwd(qkv, qkv[:, hd:], qkv[:, 2 * hd:], att, desc, actx.slopes, actx.mask)
+        res1 = ln1 if post_ln_res else x2
+        if p_hidden > 0.0:
+            h1 = ops.dropout(ops.linear_fwd(att, wd_c, bd.detach()), p_hidden, s_h1, residual=res1)
+        else:
+            h1 = ops.linear_fwd(att, wd_c, bd.detach(), residual=res1)
+        ln2, mean2, rstd2 = ops.layernorm_fwd(h1, ln2_w.detach(), ln2_b.detach(), eps)
+        u = torch.empty((T, 4 * H), dtype=cd, device=x.device)
+        g = ops.linear_fwd(ln2, w1_c, b1.detach(), epilogue=_lib.EPI_GELU, aux_out=u)
+        res2 = ln2 if post_ln_res else h1
+        if p_hidden > 0.0:
+            out = ops.dropout(ops.linear_fwd(g, w2_c, b2.detach()), p_hidden, s_h2, residual=res2)
+        else:
+            out = ops.linear_fwd(g, w2_c, b2.detach(), residual=res2)
+        ctx.save_for_backward(x2, ln1_w, wqkv, wd, ln2_w, w1, w2, mean1, rstd1, ln1, qkv, att, stat_m, stat_l, h1, mean2, rstd2, ln2, u, g)
+        ctx.actx, ctx.desc, ctx.post_ln_res, ctx.shape = actx, desc, post_ln_res, (B, S, H)
+        ctx.p_hidden, ctx.seeds = p_hidden, seeds
+        qv = qkv.view(B, S, nh, 3, hd)
+        kv_out.append((qv[:, :, :, 1, :].transpose(1, 2), qv[:, :, :, 2, :].transpose(1, 2)))
+        return out.view(B, S, H)
+
+    @staticmethod
+    def backward(ctx, dout):
+        if dout is None:
+            return (None,) * 20
+        (x2, ln1_w, wqkv, wd, ln2_w, w1, w2, mean1, rstd1, ln1, qkv, att, stat_m, stat_l, h1, mean2, rstd2, ln2, u, g) = ctx.saved_tensors
+        B, S, H = ctx.shape
+        T = B * S
+        hd = H // ctx.actx.nh
+        cd = x2.dtype
+        post, ph = ctx.post_ln_res, ctx.p_hidden
+        _, s_h1, s_h2 = ctx.seeds
+        wqkv_c, wd_c = ops.compute_weight(wqkv, cd), ops.compute_weight(wd, cd)
+        w1_c, w2_c = ops.compute_weight(w1, cd), ops.compute_weight(w2, cd)
+        dout2 = dout.reshape(T, H)
+        dout2 = dout2 if dout2.is_contiguous() else dout2.contiguous()
+        # MLP: out = res2 + drop(W2 gelu(W1 ln2 + b1) + b2)
+        dm = ops.dropout(dout2, ph, s_h2) if ph > 0.0 else dout2              # gradient of the projection output: same mask as the forward
+        dw2, db2 = ops.linear_wgrad(dm, g), ops.colsum(dm)
+        du = ops.linear_dgrad(dm, w2_c, epilogue=_lib.EPI_DGELU, aux_in=u)
+        dw1, db1 = ops.linear_wgrad(du, ln2), ops.colsum(du)
+        dln2 = ops.linear_dgrad(du, w1_c, residual=dout2 if post else None)
+        dh1, dln2_w, dln2_b = ops.layernorm_bwd(dln2, h1, ln2_w.detach(), mean2, rstd2, dres=None if post else dout2)
+        # attention: h1 = res1 + drop(Wd att + bd)
+        dd = ops.dropout(dh1, ph, s_h1) if ph > 0.0 else dh1
+        dwd, dbd = ops.linear_wgrad(dd, att), ops.colsum(dd)
+        datt = ops.linear_dgrad(dd, wd_c)
+        dqkv = torch.empty_like(qkv)
+        ops.attn_bwd(qkv, qkv[:, hd:], qkv[:, 2 * hd:], att, datt, stat_m, stat_l, dqkv, dqkv[:, hd:], dqkv[:, 2 * hd:], ctx.desc,
+                     ctx.actx.slopes, ctx.actx.mask)
+        dwqkv, dbqkv = ops.linear_wgrad(dqkv, ln1), ops.colsum(dqkv)
+        dln1 = ops.linear_dgrad(dqkv, wqkv_c, residual=dh1 if post else None)
+        dx, dln1_w, dln1_b = ops.layernorm_bwd(dln1, x2, ln1_w.detach(), mean1, rstd1, dres=None if post else dh1)
+        return (dx.view(B, S, H), dln1_w, dln1_b, dwqkv, dbqkv, dwd, dbd, dln2_w, dln2_b, dw1, db1, dw2, db2,
+                None, None, None, None, None, None, None)
+
+
 class _LazyKV:
     """``(present_k, present_v)`` of one block (modeling_bloom.py:88-92 returns them on every call): [B,nh,S,hd] views of the fused
     QKV activation, built when first indexed — a training step never looks at them."""
@@ -408,8 +489,6 @@ class BloomBlock(torch.nn.Module):
         the alibi tensor; both are folded into the attention kernel, so `alibi` is unused)."""
         if head_mask is not None:
             raise NotImplementedError("head_mask is not supported (SURVEY Q11: callers always pass None)")
-        if self.training and (self.hidden_dropout > 0.0 or self.self_attention.attention_dropout.p > 0.0):
-            raise NotImplementedError("dropout > 0 is not built into the fused Bloom block (bloom-560m/7b1 configs use 0.0)")
         if self.self_attention.pretraining_tp > 1 and self.self_attention.slow_but_exact:
             raise Exception("pretraining_tp and slow_but_exact not supported yet")        # modeling_bloom.py:118-119
         actx: _AttnCtx = attention_mask
@@ -418,6 +497,19 @@ class BloomBlock(torch.nn.Module):
             if torch.is_grad_enabled() and hidden_states.requires_grad:
                 raise NotImplementedError("training through a KV cache is not supported")
             return _decode_block(self, hidden_states, actx, k_v_past, self.eps, self.apply_residual_connection_post_layernorm)
+        p_hidden = float(self.hidden_dropout) if self.training else 0.0
+        p_attn = float(self.self_attention.attention_dropout.p) if self.training else 0.0
+        if p_hidden > 0.0 or p_attn > 0.0:
+            from .. import rng
+            kv = []
+            out = BloomBlockDropoutFn.apply(
+                hidden_states, self.input_layernorm.weight, self.input_layernorm.bias,
+                sa.query_key_value.weight, sa.query_key_value.bias, sa.dense.weight, sa.dense.bias,
+                self.post_attention_layernorm.weight, self.post_attention_layernorm.bias,
+                mlp.dense_h_to_4h.weight, mlp.dense_h_to_4h.bias, mlp.dense_4h_to_h.weight, mlp.dense_4h_to_h.bias,
+                actx, self.eps, self.apply_residual_connection_post_layernorm, p_hidden, p_attn,
+                (rng.next_seed(), rng.next_seed(), rng.next_seed()), kv)
+            return out, kv[0]
         kv = []
         out = BloomBlockFn.apply(
             hidden_states, self.input_layernorm.weight, self.input_layernorm.bias,

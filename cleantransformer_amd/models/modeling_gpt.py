@@ -27,7 +27,7 @@ from typing import Optional
 
 import torch
 
-from .. import _lib, ops
+from .. import _lib, ops, rng
 from ..generation.generation_util import GenerationMixin
 from ..transformer import LayerNorm, LayerNormFn
 from .modeling_bloom import EmbedFn, LMHeadFn, ShiftedCrossEntropyFn, _TieCtx, _torch_dtype
@@ -92,8 +92,11 @@ class GPTMLPFn(torch.autograd.Function):
         H = w_fc.shape[0]
         x2 = x.reshape(-1, H)
         x2 = x2 if x2.is_contiguous() else x2.contiguous()
-        r2 = residual.reshape(-1, H)
-        r2 = r2 if r2.is_contiguous() else r2.contiguous()
+        r2 = None
+        if residual is not None:                                            # None: the caller adds it after dropout (mlp[3].p > 0)
+            r2 = residual.reshape(-1, H)
+            r2 = r2 if r2.is_contiguous() else r2.contiguous()
+        ctx.has_res = residual is not None
         u = torch.empty((x2.shape[0], w_fc.shape[1]), dtype=x.dtype, device=x.device)
         g = ops.linear_fwd(x2, ops.compute_weight_t(w_fc, x.dtype), b_fc.detach(), epilogue=_lib.EPI_GELU, aux_out=u)
         y = ops.linear_fwd(g, ops.compute_weight_t(w_proj, x.dtype), b_proj.detach(), residual=r2)
@@ -112,21 +115,22 @@ class GPTMLPFn(torch.autograd.Function):
         dw_fc = ops.linear_wgrad(x2, du)
         db_fc = ops.colsum(du)
         dx = ops.linear_dgrad(du, ops.compute_weight_t(w_fc, x2.dtype))
-        return dx.view(dy.shape), dw_fc, db_fc, dw_proj, db_proj, dy
+        return dx.view(dy.shape), dw_fc, db_fc, dw_proj, db_proj, (dy if ctx.has_res else None)
 
 
 class GPTAttnFn(torch.autograd.Function):
     """softmax(causal(q k^T / sqrt(hd)) + key mask) v on the fused [B,S,3H] = q | k | v activation (modeling_gpt.py:69-101)."""
 
     @staticmethod
-    def forward(ctx, qkv: Tensor, mask: ops.MaskInfo, nh: int, scale: float):
+    def forward(ctx, qkv: Tensor, mask: ops.MaskInfo, nh: int, scale: float, drop_p: float = 0.0, drop_seed: int = 0):
         B, S, H3 = qkv.shape
         H = H3 // 3
         hd = H // nh
         qkv = qkv if qkv.is_contiguous() else qkv.contiguous()
         q2 = qkv.view(B * S, H3)
         st = (S * H3, hd, H3)
-        desc = ops._strided_desc(B, nh, S, S, hd, st, st, st, (S * H, hd, H), scale, S > 1, future_fill=-1e4)
+        desc = ops._strided_desc(B, nh, S, S, hd, st, st, st, (S * H, hd, H), scale, S > 1, future_fill=-1e4, dropout_p=drop_p,
+                                 dropout_seed=drop_seed)
         out = torch.empty((B, S, H), dtype=qkv.dtype, device=qkv.device)
         stat_m, stat_l = ops.attn_fwd(q2, q2[:, H:], q2[:, 2 * H:], out, desc, None, mask)
         ctx.save_for_backward(q2, out, stat_m, stat_l)
@@ -141,10 +145,10 @@ class GPTAttnFn(torch.autograd.Function):
         dqkv = torch.empty_like(q2)
         ops.attn_bwd(q2, q2[:, H:], q2[:, 2 * H:], out, dout, stat_m, stat_l, dqkv, dqkv[:, H:], dqkv[:, 2 * H:],
                      ctx.desc, None, ctx.mask)
-        return dqkv.view(out.shape[0], out.shape[1], 3 * H), None, None, None
+        return dqkv.view(out.shape[0], out.shape[1], 3 * H), None, None, None, None, None
 
 
-def _attend_cached(qkv: Tensor, past, mask: ops.MaskInfo, nh: int, scale: float):
+def _attend_cached(qkv: Tensor, past, mask: ops.MaskInfo, nh: int, scale: float, drop_p: float = 0.0, drop_seed: int = 0):
     """Inference with a KV cache (modeling_gpt.py:75-80): returns the context and the concatenated (k, v) [B,nh,Sk,hd]."""
     B, S, H3 = qkv.shape
     H = H3 // 3
@@ -156,7 +160,8 @@ def _attend_cached(qkv: Tensor, past, mask: ops.MaskInfo, nh: int, scale: float)
     Sk = k.shape[-2]
     q2 = qkv.reshape(B * S, H3)
     cs = (nh * Sk * hd, Sk * hd, hd)
-    desc = ops._strided_desc(B, nh, S, Sk, hd, (S * H3, hd, H3), cs, cs, (S * H, hd, H), scale, S > 1, future_fill=-1e4)
+    desc = ops._strided_desc(B, nh, S, Sk, hd, (S * H3, hd, H3), cs, cs, (S * H, hd, H), scale, S > 1, future_fill=-1e4,
+                             dropout_p=drop_p, dropout_seed=drop_seed)
     out = torch.empty((B, S, H), dtype=qkv.dtype, device=qkv.device)
     ops.attn_fwd(q2, k, v, out, desc, None, mask)
     return out, (k, v)
@@ -194,18 +199,22 @@ class AttentionLayer(torch.nn.Module):
         """`attention_mask` is the per-forward ops.MaskInfo built by GPTModel.  Returns c_proj(context) (+ residual)."""
         if head_mask is not None:
             raise NotImplementedError("head_mask is not supported (the reference's `if head_mask:` is only safe for None)")
-        if self.training and (self.attn_dropout.p > 0.0 or self.resid_dropout.p > 0.0):
-            raise NotImplementedError("dropout > 0 is not built (attn_pdrop / resid_pdrop must be 0 for training)")
+        # dropout (modeling_gpt.py:96 on the softmax output, :100 on the projected context): the kernels' counter-based masks
+        pa = float(self.attn_dropout.p) if self.training else 0.0
+        pr = float(self.resid_dropout.p) if self.training else 0.0
+        sa = rng.next_seed() if pa > 0.0 else 0
         hd = self.n_state // self.n_head
         scale = 1.0 / math.sqrt(hd) if self.scale else 1.0
         qkv = self.c_attn(hidden_states)
         B, S, _ = qkv.shape
         if k_v_past is not None or not (torch.is_grad_enabled() and qkv.requires_grad):
-            ctxv, kv = _attend_cached(qkv, k_v_past, attention_mask, self.n_head, scale)
+            ctxv, kv = _attend_cached(qkv, k_v_past, attention_mask, self.n_head, scale, pa, sa)
         else:
-            ctxv = GPTAttnFn.apply(qkv, attention_mask, self.n_head, scale)
+            ctxv = GPTAttnFn.apply(qkv, attention_mask, self.n_head, scale, pa, sa)
             qv = qkv.view(B, S, 3, self.n_head, hd)
             kv = (qv[:, :, 1].transpose(1, 2), qv[:, :, 2].transpose(1, 2))           # views, like the reference's k_v_past
+        if pr > 0.0:                                                    # residual + dropout(c_proj(a)): the add moves out of the GEMM epilogue
+            return ops.DropoutFn.apply(self.c_proj(ctxv), pr, rng.next_seed(), residual), kv
         return self.c_proj(ctxv, residual=residual), kv
 
 
@@ -237,10 +246,10 @@ class TransformerBlock(torch.nn.Module):
         self.norm2 = LayerNorm(n_embd, eps=config.layer_norm_epsilon)
 
     def _mlp(self, x, residual):
-        if self.training and self.mlp[3].p > 0.0:
-            raise NotImplementedError("the MLP's trailing torch.nn.Dropout() (p=0.5 in the reference) must be disabled "
-                                      "(set .p = 0 or use eval()) — RNG-driven masks cannot be parity-checked")
         fc, proj = self.mlp[0], self.mlp[2]
+        pm = float(self.mlp[3].p) if self.training else 0.0             # the trailing torch.nn.Dropout() — p = 0.5 in the reference
+        if pm > 0.0:
+            return ops.DropoutFn.apply(GPTMLPFn.apply(x, fc.weight, fc.bias, proj.weight, proj.bias, None), pm, rng.next_seed(), residual)
         return GPTMLPFn.apply(x, fc.weight, fc.bias, proj.weight, proj.bias, residual)
 
     def forward(self, x, attn_output=None, attention_mask=None, head_mask=None, k_v_past=None):
@@ -270,8 +279,6 @@ class GPTModel(torch.nn.Module):
         self._tie: Optional[_TieCtx] = None
 
     def forward(self, input_ids, attention_mask=None, position_ids=None, segment_ids=None, k_v_pasts=None):
-        if self.training and self.drop.p > 0.0:
-            raise NotImplementedError("embd_pdrop must be 0 for training (dropout is not built)")
         if k_v_pasts is None:
             k_v_pasts = [None] * len(self.blocks)
         else:
@@ -293,6 +300,8 @@ class GPTModel(torch.nn.Module):
         hidden_states = tok + pos
         if segment_ids is not None:
             hidden_states = hidden_states + EmbedFn.apply(segment_ids.view(-1, segment_ids.size(-1)), self.tokens_embed.weight, cd, None)
+        if self.training and self.drop.p > 0.0:                          # embd_pdrop (modeling_gpt.py:190)
+            hidden_states = ops.DropoutFn.apply(hidden_states, float(self.drop.p), rng.next_seed(), None)
         for i, block in enumerate(self.blocks):
             hidden_states, k_v_pasts[i] = block(hidden_states, attention_mask=minfo, k_v_past=k_v_pasts[i])
         if self.version == 'gpt':

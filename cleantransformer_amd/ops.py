@@ -193,7 +193,8 @@ class MaskInfo:
               "mask_prep")
 
 
-def _strided_desc(B, nh, Sq, Sk, hd, q_str, k_str, v_str, o_str, scale, causal, am_str=(0, 0, 0, 0), future_fill: float = 0.0) -> AttnDesc:
+def _strided_desc(B, nh, Sq, Sk, hd, q_str, k_str, v_str, o_str, scale, causal, am_str=(0, 0, 0, 0), future_fill: float = 0.0,
+                  dropout_p: float = 0.0, dropout_seed: int = 0) -> AttnDesc:
     d = AttnDesc()
     d.B, d.nh, d.Sq, d.Sk, d.hd = B, nh, Sq, Sk, hd
     d.q_bs, d.q_hs, d.q_rs = q_str
@@ -204,6 +205,7 @@ def _strided_desc(B, nh, Sq, Sk, hd, q_str, k_str, v_str, o_str, scale, causal, 
     d.scale = float(scale)
     d.causal = int(causal)
     d.future_fill = float(future_fill)                                # 0 = finfo.min (Bloom); GPT-2 passes -1e4 (modeling_gpt.py:88-89)
+    d.dropout_p, d.dropout_seed = float(dropout_p), int(dropout_seed) & 0xFFFFFFFF     # attention-probability dropout (0 = off)
     return d
 
 
@@ -236,12 +238,13 @@ def attn_bwd(q, k, v, o, d_o, stat_m, stat_l, dq, dk, dv, desc: AttnDesc, slopes
                                     _p(add_mask), C.byref(desc), dt_code(q.dtype), _stream()), "attn_bwd")
 
 
-def fused_qkv_desc(B: int, S: int, nh: int, hd: int, causal: bool) -> AttnDesc:
+def fused_qkv_desc(B: int, S: int, nh: int, hd: int, causal: bool, dropout_p: float = 0.0, dropout_seed: int = 0) -> AttnDesc:
     """Strides of the head-interleaved fused QKV activation [B,S,nh,3,hd] (modeling_bloom.py:81-82) and of the
     merged-head context [B,S,nh*hd]."""
     H = nh * hd
     qkv = (S * 3 * H, 3 * hd, 3 * H)
-    return _strided_desc(B, nh, S, S, hd, qkv, qkv, qkv, (S * H, hd, H), 1.0 / math.sqrt(hd), causal)
+    return _strided_desc(B, nh, S, S, hd, qkv, qkv, qkv, (S * H, hd, H), 1.0 / math.sqrt(hd), causal, dropout_p=dropout_p,
+                         dropout_seed=dropout_seed)
 
 
 # ------------------------------------------------------------------------------------------------ embedding / CE
@@ -449,6 +452,33 @@ def bloom_block_bwd(acts: BlockActs, x2: Tensor, params, mask: Optional[MaskInfo
         g.side_splitk_ws, g.side_splitk_ws_bytes = sk2.data_ptr(), sk2.numel() * 4
     check(_lib.load().ctmi_bloom_block_bwd(C.byref(d), C.byref(g), _stream()), "bloom_block_bwd")
     return dx, grads
+
+
+def dropout(x: Tensor, p: float, seed: int, residual: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
+    """(keep ? x/(1-p) : 0) (+ residual), keep(i) = hash32(i ^ seed) >= p*2^32 over the flat element index — and, applied to a gradient
+    with the same seed, its own backward."""
+    _need_cuda(x, residual)
+    x = _c(x)
+    if residual is not None:
+        residual = _c(residual)
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.load().ctmi_dropout(_p(x), _p(residual), _p(out), x.numel(), float(p), int(seed) & 0xFFFFFFFF, dt_code(x.dtype), _stream()),
+          "dropout")
+    return out
+
+
+class DropoutFn(torch.autograd.Function):
+    """torch.nn.functional.dropout(x, p, training=True) (+ residual) on the counter-based mask; nothing but the seed is saved."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed, residual=None):
+        ctx.p, ctx.seed, ctx.has_res = p, seed, residual is not None
+        return dropout(x, p, seed, residual)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dropout(dy, ctx.p, ctx.seed), None, None, (dy if ctx.has_res else None)
 
 
 # ------------------------------------------------------------------------------------------------ utilities

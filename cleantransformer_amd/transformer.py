@@ -95,7 +95,8 @@ class MHAFn(torch.autograd.Function):
     """softmax(q k^T / sqrt(hd) + additive_mask) v on [B,S,H] tensors split into heads (transformer.py:25-57)."""
 
     @staticmethod
-    def forward(ctx, q: Tensor, k: Tensor, v: Tensor, add_mask: Optional[Tensor], nh: int, scale: float):
+    def forward(ctx, q: Tensor, k: Tensor, v: Tensor, add_mask: Optional[Tensor], nh: int, scale: float, drop_p: float = 0.0,
+                drop_seed: int = 0):
         B, S, H = q.shape
         hd = H // nh
         q, k, v = (t if t.is_contiguous() else t.contiguous() for t in (q, k, v))
@@ -105,7 +106,7 @@ class MHAFn(torch.autograd.Function):
             am = add_mask.to(torch.float32)
             am = am.expand(B, nh, S, S) if am.dim() == 4 else am.reshape((1,) * (4 - am.dim()) + tuple(am.shape)).expand(B, nh, S, S)
             am_str = tuple(am.stride())
-        desc = ops._strided_desc(B, nh, S, S, hd, st, st, st, st, scale, False, am_str)
+        desc = ops._strided_desc(B, nh, S, S, hd, st, st, st, st, scale, False, am_str, dropout_p=drop_p, dropout_seed=drop_seed)
         out = torch.empty_like(q)
         stat_m, stat_l = ops.attn_fwd(q, k, v, out, desc, None, None, am)
         ctx.save_for_backward(q, k, v, out, stat_m, stat_l, am)
@@ -118,15 +119,16 @@ class MHAFn(torch.autograd.Function):
         dout = dout if dout.is_contiguous() else dout.contiguous()
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         ops.attn_bwd(q, k, v, out, dout, stat_m, stat_l, dq, dk, dv, ctx.desc, None, None, am)
-        return dq, dk, dv, None, None, None
+        return dq, dk, dv, None, None, None, None, None
 
 
-def _dropout(x: Tensor, p: float, training: bool) -> Tensor:
+def _dropout(x: Tensor, p: float, training: bool, residual: Optional[Tensor] = None) -> Tensor:
+    """torch.nn.Dropout(p)(x) (+ residual) in training mode on the kernels' counter-based mask (ctmi_dropout): a fresh seed per call
+    from torch's CPU generator (rng.next_seed), the backward regenerates the mask.  p = 0 or eval(): identity (+ residual)."""
     if p > 0.0 and training:
-        # RNG-driven masks cannot be parity-checked against torch's generator anyway; hidden dropout of the generic
-        # block uses torch's own op (not on the measured Bloom path, where every dropout p is 0.0).
-        return torch.nn.functional.dropout(x, p=p, training=True)
-    return x
+        from . import rng
+        return ops.DropoutFn.apply(x, float(p), rng.next_seed(), residual)
+    return x if residual is None else _AddFn.apply(residual, x)
 
 
 # ------------------------------------------------------------------------------------------------ modules
@@ -166,13 +168,15 @@ class AttentionLayer(torch.nn.Module):
         if head_mask is not None:
             raise NotImplementedError("head_mask is not supported (the reference's `if head_mask:` is ill-defined for tensors; "
                                       "every caller passes None) — SURVEY Q11")
-        if self.training and self.dropout.p > 0.0:
-            raise NotImplementedError("attention-probability dropout > 0 in training mode is not built into the fused attention "
-                                      "kernel; set attention_probs_dropout_prob=0 (Bloom-560M uses 0.0) or call .eval()")
         q = LinearFn.apply(hidden_states, self.q_linear.weight, self.q_linear.bias)
         k = LinearFn.apply(hidden_states, self.k_linear.weight, self.k_linear.bias)
         v = LinearFn.apply(hidden_states, self.v_linear.weight, self.v_linear.bias)
-        return MHAFn.apply(q, k, v, attention_mask, self.m_head, 1.0 / math.sqrt(self.dim / self.m_head))
+        drop_p = float(self.dropout.p) if self.training else 0.0                  # transformer.py:46-47: dropout on the softmax output
+        seed = 0
+        if drop_p > 0.0:
+            from . import rng
+            seed = rng.next_seed()
+        return MHAFn.apply(q, k, v, attention_mask, self.m_head, 1.0 / math.sqrt(self.dim / self.m_head), drop_p, seed)
 
 
 class TransformerBlock(torch.nn.Module):
@@ -192,11 +196,9 @@ class TransformerBlock(torch.nn.Module):
         self.dropout = torch.nn.Dropout(config.hidden_dropout_prob)
 
     def forward(self, x):
-        att_out = _dropout(self.attention(x), self.dropout.p, self.training)
-        y = self.norm1(_AddFn.apply(x, att_out))
+        y = self.norm1(_dropout(self.attention(x), self.dropout.p, self.training, residual=x))
         f = FFNFn.apply(y, self.ffw[0].weight, self.ffw[0].bias, self.ffw[2].weight, self.ffw[2].bias)
-        f = _dropout(f, self.dropout.p, self.training)
-        return self.norm2(_AddFn.apply(y, f))
+        return self.norm2(_dropout(f, self.dropout.p, self.training, residual=y))
 
 
 class _AddFn(torch.autograd.Function):

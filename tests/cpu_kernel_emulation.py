@@ -126,6 +126,31 @@ def _scores(q, k, desc, slopes, mask, add_mask):
     return s, masked
 
 
+def _attn_keep(desc):
+    """[B,nh,Sq,Sk] keep mask and scale of the attention-probability dropout, as the kernels define it (include/ctmi355.h)."""
+    from cleantransformer_amd import rng
+    p = float(getattr(desc, "dropout_p", 0.0))
+    if p == 0.0:
+        return None, 1.0
+    B, nh, Sq, Sk = desc.B, desc.nh, desc.Sq, desc.Sk
+    c = torch.arange(B * nh * Sq * Sk, dtype=torch.int64).view(B, nh, Sq, Sk)
+    keep = rng.hash32(c ^ int(desc.dropout_seed)) >= rng.drop_threshold(p)
+    return keep, 1.0 / (1.0 - p)
+
+
+def dropout(x, p, seed, residual=None, out=None):
+    from cleantransformer_amd import rng
+    keep = rng.hash32(torch.arange(x.numel(), dtype=torch.int64) ^ (int(seed) & 0xFFFFFFFF)) >= rng.drop_threshold(p)
+    y = torch.where(keep.view(x.shape), x.float() * torch.tensor(1.0 / (1.0 - p), dtype=torch.float32), torch.zeros(()))
+    if residual is not None:
+        y = y + residual.float()
+    y = y.to(x.dtype)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
 def attn_fwd(q, k, v, out, desc, slopes, mask, add_mask=None):
     B, nh, Sq, Sk, hd = desc.B, desc.nh, desc.Sq, desc.Sk, desc.hd
     qv = _strided(q, B, nh, Sq, hd, desc.q_bs, desc.q_hs, desc.q_rs)
@@ -135,7 +160,11 @@ def attn_fwd(q, k, v, out, desc, slopes, mask, add_mask=None):
     m = s.max(-1).values
     p = torch.exp(s - m[..., None])
     l = p.sum(-1)
-    o = torch.einsum("bhqk,bhkd->bhqd", p / l[..., None], vv.float())
+    pn = p / l[..., None]
+    keep, ds = _attn_keep(desc)
+    if keep is not None:
+        pn = torch.where(keep, pn * ds, torch.zeros(()))
+    o = torch.einsum("bhqk,bhkd->bhqd", pn, vv.float())
     _strided(out, B, nh, Sq, hd, desc.o_bs, desc.o_hs, desc.o_rs).copy_(o.to(out.dtype))
     return m, l
 
@@ -151,8 +180,13 @@ def attn_bwd(q, k, v, o, d_o, stat_m, stat_l, dq, dk, dv, desc, slopes, mask, ad
     p = torch.exp(s - stat_m[..., None]) / stat_l[..., None]
     delta = (ov * gv).sum(-1)
     dp = torch.einsum("bhqd,bhkd->bhqk", gv, vv.float())
+    keep, dsc = _attn_keep(desc)
+    pd = p
+    if keep is not None:
+        dp = torch.where(keep, dp * dsc, torch.zeros(()))
+        pd = torch.where(keep, p * dsc, torch.zeros(()))
     ds = torch.where(masked, torch.zeros(()), p * (dp - delta[..., None]))
-    _strided(dv, B, nh, Sk, hd, desc.v_bs, desc.v_hs, desc.v_rs).copy_(torch.einsum("bhqk,bhqd->bhkd", p, gv).to(dv.dtype))
+    _strided(dv, B, nh, Sk, hd, desc.v_bs, desc.v_hs, desc.v_rs).copy_(torch.einsum("bhqk,bhqd->bhkd", pd, gv).to(dv.dtype))
     _strided(dk, B, nh, Sk, hd, desc.k_bs, desc.k_hs, desc.k_rs).copy_((desc.scale * torch.einsum("bhqk,bhqd->bhkd", ds, qv.float())).to(dk.dtype))
     _strided(dq, B, nh, Sq, hd, desc.q_bs, desc.q_hs, desc.q_rs).copy_((desc.scale * torch.einsum("bhqk,bhkd->bhqd", ds, kv.float())).to(dq.dtype))
 
@@ -436,7 +470,7 @@ def install(monkeypatch):
     """Patch cleantransformer_amd.ops in place (pytest's monkeypatch undoes it after the test)."""
     from cleantransformer_amd import ops
     for name in ("layernorm_fwd", "layernorm_bwd", "gemm", "colsum", "MaskInfo", "attn_fwd", "attn_bwd", "embed_fwd", "embed_bwd",
-                 "ce_fwd", "ce_bwd", "ce_fwd_bwd", "ce_fused_ok", "scale_if_", "bloom_block_fwd", "bloom_block_bwd", "ce_soft_fwd", "ce_soft_bwd", "cast", "transpose_cast", "sumsq", "scale_", "scale_copy", "argmax_lastdim", "row_lse", "group_topk",
+                 "dropout", "ce_fwd", "ce_bwd", "ce_fwd_bwd", "ce_fused_ok", "scale_if_", "bloom_block_fwd", "bloom_block_bwd", "ce_soft_fwd", "ce_soft_bwd", "cast", "transpose_cast", "sumsq", "scale_", "scale_copy", "argmax_lastdim", "row_lse", "group_topk",
                  "scores_filter", "amp_unscale", "amp_update", "adamw_step", "sgd_step"):
         monkeypatch.setattr(ops, name, globals()[name])
     monkeypatch.setattr(ops, "_need_cuda", lambda *a: None)

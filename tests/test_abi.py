@@ -14,7 +14,7 @@ def _declared():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     decls = {}
-    for m in re.finditer(r"\b(int64_t|int|const char\*)\s+(ctmi_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(int64_t|int|uint32_t|const char\*)\s+(ctmi_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         args = m.group(3).strip()
         n = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
         decls[m.group(2)] = n
