@@ -28,6 +28,14 @@
 #define CTMI_ATTN_NBUF 0         // 0: two LDS stages whenever they fit (one barrier per tile); 1: force one stage (more workgroups per CU)
 #endif
 
+#ifndef CTMI_ATTN_DBG_BUILD
+#define CTMI_ATTN_DBG_BUILD 0    // 1: timing-ablation switches driven by CTMI_ATTN_DBG exist (A/B builds only); 0: compiled out
+#endif
+#if CTMI_ATTN_DBG_BUILD
+#define ATTN_DBG(p) ((p).dbg)
+#else
+#define ATTN_DBG(p) 0
+#endif
 struct AttnP {
     const void *q, *k, *v, *o, *d_o;
     void *out, *dq, *dk, *dv;
@@ -421,7 +429,7 @@ __global__ __launch_bounds__(256, CTMI_ATTN_MINW) void attn_fwd_kernel(AttnP p) 
     const float* am_base = AM ? p.add_mask + b * p.am_b + h * p.am_h : nullptr;
 
     for (int t = 0; t < ntiles; ++t) {
-        if (t + 1 < ntiles && !(p.dbg & 1)) {
+        if (t + 1 < ntiles && !(ATTN_DBG(p) & 1)) {
             if (tid < 64) kbr.load(p, b, (int64_t)(t + 1) * 64 + tid);
             A::stream_load(rk, pk, kp, p.k_rs, (int64_t)(t + 1) * 64, p.Sk, hd_, fast, tid);
             A::stream_load(rv, pv, vp, p.v_rs, (int64_t)(t + 1) * 64, p.Sk, hd_, fast, tid);
@@ -490,14 +498,14 @@ __global__ __launch_bounds__(256, CTMI_ATTN_MINW) void attn_fwd_kernel(AttnP p) 
         m = m_new;
         contract64<T, HDP>(acc, VS(cur), x, lane);                          // acc[dt][r] = O^T[d][my_q]
         if (NBUF == 1) __syncthreads();
-        if (t + 1 < ntiles && !(p.dbg & 2)) {
+        if (t + 1 < ntiles && !(ATTN_DBG(p) & 2)) {
             const int nx = NBUF == 2 ? cur ^ 1 : 0;
             A::store_rm(rk, KS(nx), tid);
             A::store_rm(rv, VS(nx), tid);
             if (tid < 64) KB(nx)[tid] = kbr.value(p, (int64_t)(t + 1) * 64 + tid, slope);
             cur = nx;
         }
-        if (!(p.dbg & 4)) __syncthreads();
+        if (!(ATTN_DBG(p) & 4)) __syncthreads();
     }
     lsum += __shfl_xor(lsum, 16, 64);
     lsum += __shfl_xor(lsum, 32, 64);
@@ -605,7 +613,7 @@ __global__ __launch_bounds__(256, CTMI_ATTN_MINW) void attn_bwd_dkdv_kernel(Attn
     const bool general = AM || !CTMI_ATTN_FASTBODY || (p.kvalid != nullptr && p.first_valid[b] - p.off > 0);
     auto body = [&](auto masked_c, const int t) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_c)::value;
-        if (t + 1 < qt_end && !(p.dbg & 1)) {
+        if (t + 1 < qt_end && !(ATTN_DBG(p) & 1)) {
             load_stats(t + 1);
             A::stream_load(rq, pq, qp, p.q_rs, (int64_t)(t + 1) * 64, p.Sq, hd_, fast, tid);
             A::stream_load(rg, pg, gp, p.o_rs, (int64_t)(t + 1) * 64, p.Sq, hd_, fast, tid);
@@ -668,7 +676,7 @@ __global__ __launch_bounds__(256, CTMI_ATTN_MINW) void attn_bwd_dkdv_kernel(Attn
         contract64<T, HDP>(dv, GS(cur), x, lane);                            // dV^T[d][my_k] += sum_q dO[q][d] P[q][my_k]
         contract64<T, HDP>(dk, QS(cur), y, lane);                            // dK^T[d][my_k] += sum_q Q[q][d] dS[q][my_k]
         if (NBUF == 1) __syncthreads();
-        if (t + 1 < qt_end && !(p.dbg & 2)) {
+        if (t + 1 < qt_end && !(ATTN_DBG(p) & 2)) {
             const int nx = NBUF == 2 ? cur ^ 1 : 0;
             A::store_rm(rq, QS(nx), tid);
             A::store_rm(rg, GS(nx), tid);
@@ -789,7 +797,7 @@ __global__ __launch_bounds__(256, CTMI_ATTN_MINW) void attn_bwd_dq_kernel(AttnP 
     const bool general = AM || !CTMI_ATTN_FASTBODY || (p.kvalid != nullptr && p.first_valid[b] - p.off > 0) || (q0 + 64 > p.Sq);
     auto body = [&](auto masked_c, const int t) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_c)::value;
-        if (t + 1 < ntiles && !(p.dbg & 1)) {
+        if (t + 1 < ntiles && !(ATTN_DBG(p) & 1)) {
             if (tid < 64) kbr.load(p, b, (int64_t)(t + 1) * 64 + tid);
             A::stream_load(rk, pk, kp, p.k_rs, (int64_t)(t + 1) * 64, p.Sk, hd_, fast, tid);
             A::stream_load(rv, pv, vp, p.v_rs, (int64_t)(t + 1) * 64, p.Sk, hd_, fast, tid);
@@ -833,7 +841,7 @@ __global__ __launch_bounds__(256, CTMI_ATTN_MINW) void attn_bwd_dq_kernel(AttnP 
         }
         contract64<T, HDP>(dq, KS(cur), y, lane);                            // dQ^T[d][my_q] += sum_key K[key][d] dS[my_q][key]
         if (NBUF == 1) __syncthreads();
-        if (t + 1 < ntiles && !(p.dbg & 2)) {
+        if (t + 1 < ntiles && !(ATTN_DBG(p) & 2)) {
             const int nx = NBUF == 2 ? cur ^ 1 : 0;
             A::store_rm(rk, KS(nx), tid);
             A::store_rm(rv, VS(nx), tid);

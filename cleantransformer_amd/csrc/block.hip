@@ -15,6 +15,7 @@
 //   join;  ONE reduce launch turns all partial rows into the 8 small gradient vectors.
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 #include <mutex>
 
 int ctmi_ln_bwd_parts_internal(const void* dy, const void* x, const float* w, const float* mean, const float* rstd,
@@ -96,6 +97,8 @@ int linear_dgrad(const void* dy, const void* w, void* dx, int64_t T, int64_t Nou
 // dW[Nout,Kin] (fp32) = dy[T,Nout]^T x[T,Kin]
 int linear_wgrad(const void* dy, const void* x, float* dw, int64_t T, int64_t Nout, int64_t Kin, int dtype, void* ws, int64_t ws_bytes,
                  hipStream_t st) {
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("CTMI_BLOCK_DBG"); dbg = e ? atoi(e) : 0; }
+      if (dbg & 1) return CTMI_OK; }                                    // timing experiments only: 1 = skip the layer weight-gradient GEMMs
     return ctmi_gemm(dy, Nout, 1, x, Kin, 1, dw, Kin, Nout, Kin, T, 1.0f, 0, nullptr, nullptr, CTMI_EPI_NONE, nullptr, nullptr, 1, dtype,
                      ws, ws_bytes, st);
 }

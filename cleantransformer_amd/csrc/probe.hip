@@ -1,4 +1,4 @@
-// Hardware layout probes (diagnostics only; exercised by tests/test_gpu_probe.py, never by the product path).
+// Hardware layout probes (diagnostics only; exercised by tests/test_gpu_ops.py::test_probe_*, never by the product path).
 //   which = 0: ds_read_b64_tr_b16.  LDS holds u16[i] = i (4096 entries); lane l reads at byte address in[l]
 //              (host-supplied, as floats) and dumps its four 16-bit results to out[l*4 .. l*4+3].
 //   which = 1: v_mfma_f32_16x16x32_bf16 with A[i][k] = in[i*32+k], B[k][j] = in[512 + k*16 + j] loaded under the

@@ -89,6 +89,7 @@ def alibi_slopes(num_heads: int) -> Tensor:
 import os as _os
 
 _WGRAD_SIDE_STREAM = _os.environ.get("CTMI_WGRAD_STREAM", "1") != "0"
+_CHECK_IDS = _os.environ.get("CTMI_CHECK_IDS", "0") == "1"
 
 
 class _AttnCtx:
@@ -294,10 +295,15 @@ class EmbedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, ids: Tensor, weight: Tensor, cd: torch.dtype, tie: Optional[_TieCtx]):
         table = ops.compute_weight(weight, cd)
-        err = torch.zeros(1, dtype=torch.int32, device=weight.device)
-        out = ops.embed_fwd(table, ids, err)
+        if _CHECK_IDS:
+            # torch.nn.Embedding faults on ids outside [0, V); the gather kernel clamps them to row 0 (and the scatter skips them)
+            # rather than fault asynchronously.  CTMI_CHECK_IDS=1 validates on the host (one device synchronisation per forward).
+            lo, hi = int(ids.min()), int(ids.max())
+            if lo < 0 or hi >= weight.shape[0]:
+                raise IndexError(f"token id out of range: min {lo}, max {hi}, vocabulary {weight.shape[0]}")
+        out = ops.embed_fwd(table, ids, None)
         ctx.save_for_backward(ids)
-        ctx.vh, ctx.tie, ctx.err = tuple(weight.shape), tie, err
+        ctx.vh, ctx.tie = tuple(weight.shape), tie
         if tie is not None:
             tie.embed_wants = weight.requires_grad
             sync = getattr(weight, "_ct_tied_sync", None)               # set by trainer/ddp.py on the shared [V,H] parameter

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import threading
 from typing import Optional, Tuple
 
 import torch
@@ -661,9 +662,25 @@ def pad_rows(n: int) -> int:
     return (n + PAD_ROWS - 1) // PAD_ROWS * PAD_ROWS
 
 
-# dlogits buffers whose columns [V, pad) are known to be zero: data_ptr -> (padded column count, the buffer) — set by the loss
-# backward, consumed by the LM-head backward of the same step
-ZERO_PADDED = {}
+class _ZeroPadded(threading.local):
+    """dlogits buffers whose columns [V, pad) are known to be zero: data_ptr -> (padded column count, the buffer) — set by the loss
+    backward and consumed by the LM-head backward of the same step.  Both run back to back on ONE autograd worker thread, so the
+    hand-off is thread-local (no cross-thread aliasing of a recycled data_ptr), and holds at most one entry (it pins its buffer)."""
+
+    def __init__(self):
+        self.d = {}
+
+    def clear(self):
+        self.d.clear()
+
+    def __setitem__(self, k, v):
+        self.d[k] = v
+
+    def pop(self, k, default=None):
+        return self.d.pop(k, default)
+
+
+ZERO_PADDED = _ZeroPadded()
 
 def compute_weight(p: Tensor, dtype: torch.dtype) -> Tensor:
     """The matrix `p` (an fp32 master parameter) in the compute dtype.  fp32 -> p itself.  bf16 -> a cached shadow,
