@@ -115,6 +115,28 @@ def bench_adamw(n=559_214_592):
     print(f"--- AdamW {n} params (+bf16 shadow)\nstep: {t:8.3f} ms  {30.0 * n / t / 1e6:8.1f} GB/s (30 B/param)")
 
 
+def bench_epi(T=8192, H=1024):
+    """The epilogue-carrying layer GEMMs: h->4h forward with GELU / GELUG (+ pre-activation or derivative out) and the 4h->h
+    data gradient with dGELU / MUL (second [T,4H] operand in), next to their plain forms."""
+    x, w1, b1 = rnd(T, H), rnd(4 * H, H), torch.randn(4 * H, device=DEV)
+    u = torch.empty(T, 4 * H, dtype=BF, device=DEV)
+    fl = 2.0 * T * 4 * H * H
+    for name, epi in (("plain+bias", _lib.EPI_NONE), ("GELU", _lib.EPI_GELU), ("GELUG", _lib.EPI_GELUG)):
+        t = timeit(lambda: ops.linear_fwd(x, w1, b1, epilogue=epi, aux_out=None if epi == _lib.EPI_NONE else u))
+        print(f"h4h fwd  {name:10s}: {t * 1e3:7.1f} us {fl / t / 1e9:8.1f} TF/s")
+    dy, w2 = rnd(T, H), rnd(H, 4 * H)
+    for name, epi in (("plain", _lib.EPI_NONE), ("DGELU", _lib.EPI_DGELU), ("MUL", _lib.EPI_MUL)):
+        t = timeit(lambda: ops.linear_dgrad(dy, w2, epilogue=epi, aux_in=None if epi == _lib.EPI_NONE else u))
+        print(f"4hh dgrad {name:9s}: {t * 1e3:7.1f} us {fl / t / 1e9:8.1f} TF/s")
+    res = rnd(T, H)
+    att, wd, bd = rnd(T, H), rnd(H, H), torch.randn(H, device=DEV)
+    t = timeit(lambda: ops.linear_fwd(att, wd, bd, residual=res))
+    print(f"dense fwd +res     : {t * 1e3:7.1f} us {2.0 * T * H * H / t / 1e9:8.1f} TF/s")
+    g = rnd(T, 4 * H)
+    t = timeit(lambda: ops.linear_fwd(g, w2, bd, residual=res))
+    print(f"4hh fwd +res       : {t * 1e3:7.1f} us {fl / t / 1e9:8.1f} TF/s")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemm", "attn", "ln", "ce", "adamw"]
     if "gemm" in which:
@@ -127,3 +149,5 @@ if __name__ == "__main__":
         bench_ce()
     if "adamw" in which:
         bench_adamw()
+    if "epi" in which:
+        bench_epi()
