@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("CTMI_LIB_PATH") or _DEFAULT_LIB_PATH
 F32, BF16 = 0, 1
 EPI_NONE, EPI_GELU, EPI_DGELU, EPI_RELU, EPI_DRELU, EPI_GELUG, EPI_MUL = 0, 1, 2, 3, 4, 5, 6
 MT_MAX = 24
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 
@@ -39,12 +39,14 @@ class ReduceJob(C.Structure):
 
 
 BLK_SLOTS = ("ln1", "mean1", "rstd1", "qkv", "att", "stat_m", "stat_l", "h1", "mean2", "rstd2", "ln2", "u", "g", "out")
+BLK_QKV_BLOCKED, BLK_WGRAD_IN_OUT = 1, 2
 BLK_PARAMS = ("ln1_w", "ln1_b", "wqkv", "bqkv", "wd", "bd", "ln2_w", "ln2_b", "w1", "b1", "w2", "b2")
 
 
 class BloomBlock(C.Structure):
     """ctmi_bloom_block (include/ctmi355.h)."""
-    _fields_ = [("B", i64), ("S", i64), ("H", i64), ("nh", i64), ("eps", f32), ("post_ln_res", i32), ("dtype", i32), ("pad_", i32)] + \
+    _fields_ = [("B", i64), ("S", i64), ("H", i64), ("nh", i64), ("eps", f32), ("post_ln_res", i32), ("dtype", i32), ("flags", i32),
+                ("attn_scale", f32), ("future_fill", f32)] + \
                [(n, vp) for n in BLK_PARAMS] + [(n, vp) for n in ("slopes", "kpos", "kvalid", "first_valid", "x", "slab")]
 
 

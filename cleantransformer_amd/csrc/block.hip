@@ -71,15 +71,23 @@ int check_block(const ctmi_bloom_block* b, const char* who) {
 }
 
 ctmi_attn_desc fused_qkv_desc(const ctmi_bloom_block* b) {
-    // head-interleaved fused QKV activation [B,S,nh,3,hd] (modeling_bloom.py:81-82), merged-head context [B,S,nh*hd]
+    // fused QKV activation: head-interleaved [B,S,nh,3,hd] (modeling_bloom.py:81-82) or GPT-2's q | k | v [B,S,3,nh,hd]
+    // (modeling_gpt.py:69-72); merged-head context [B,S,nh*hd]
     const int64_t H = b->H, hd = H / b->nh, S = b->S;
+    const bool blocked = (b->flags & CTMI_BLK_QKV_BLOCKED) != 0;
     ctmi_attn_desc d = {};
     d.B = b->B; d.nh = b->nh; d.Sq = S; d.Sk = S; d.hd = hd;
-    d.q_bs = d.k_bs = d.v_bs = S * 3 * H; d.q_hs = d.k_hs = d.v_hs = 3 * hd; d.q_rs = d.k_rs = d.v_rs = 3 * H;
+    d.q_bs = d.k_bs = d.v_bs = S * 3 * H; d.q_hs = d.k_hs = d.v_hs = blocked ? hd : 3 * hd; d.q_rs = d.k_rs = d.v_rs = 3 * H;
     d.o_bs = S * H; d.o_hs = hd; d.o_rs = H;
-    d.scale = 1.0f / sqrtf((float)hd);
+    d.scale = b->attn_scale != 0.0f ? b->attn_scale : 1.0f / sqrtf((float)hd);
     d.causal = S > 1 ? 1 : 0;
+    d.future_fill = b->future_fill;
     return d;
+}
+// element offset of the k (which = 1) / v (which = 2) part of row 0 inside the fused activation
+int64_t qkv_part(const ctmi_bloom_block* b, int which) {
+    const int64_t H = b->H, hd = H / b->nh;
+    return (b->flags & CTMI_BLK_QKV_BLOCKED) ? which * H : which * hd;
 }
 
 // y[T,N] = epi(x[T,K] W[N,K]^T + bias) (+ residual)
@@ -94,11 +102,14 @@ int linear_dgrad(const void* dy, const void* w, void* dx, int64_t T, int64_t Nou
     return ctmi_gemm(dy, Nout, 0, w, Kin, 1, dx, Kin, T, Kin, Nout, 1.0f, 0, nullptr, residual, epi, aux_in, nullptr, 0, dtype,
                      plain ? ws : nullptr, plain ? ws_bytes : 0, st);
 }
-// dW[Nout,Kin] (fp32) = dy[T,Nout]^T x[T,Kin]
+// dW[Nout,Kin] (fp32) = dy[T,Nout]^T x[T,Kin]   — or, in_out: dW[Kin,Nout] = x^T dy (a Conv1D weight is stored [in,out])
 int linear_wgrad(const void* dy, const void* x, float* dw, int64_t T, int64_t Nout, int64_t Kin, int dtype, void* ws, int64_t ws_bytes,
-                 hipStream_t st) {
+                 hipStream_t st, bool in_out = false) {
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("CTMI_BLOCK_DBG"); dbg = e ? atoi(e) : 0; }
       if (dbg & 1) return CTMI_OK; }                                    // timing experiments only: 1 = skip the layer weight-gradient GEMMs
+    if (in_out)
+        return ctmi_gemm(x, Kin, 1, dy, Nout, 1, dw, Nout, Kin, Nout, T, 1.0f, 0, nullptr, nullptr, CTMI_EPI_NONE, nullptr, nullptr, 1, dtype,
+                         ws, ws_bytes, st);
     return ctmi_gemm(dy, Nout, 1, x, Kin, 1, dw, Kin, Nout, Kin, T, 1.0f, 0, nullptr, nullptr, CTMI_EPI_NONE, nullptr, nullptr, 1, dtype,
                      ws, ws_bytes, st);
 }
@@ -142,7 +153,7 @@ extern "C" int ctmi_bloom_block_fwd(const ctmi_bloom_block* b, void* stream) {
     RC(linear_fwd(s.at(CTMI_BLK_LN1), b->wqkv, s.at(CTMI_BLK_QKV), T, 3 * H, H, b->bqkv, nullptr, CTMI_EPI_NONE, nullptr, dt, st));
     const ctmi_attn_desc d = fused_qkv_desc(b);
     char* qkv = s.at<char>(CTMI_BLK_QKV);
-    RC(ctmi_attn_fwd(qkv, qkv + hd * e, qkv + 2 * hd * e, s.at(CTMI_BLK_ATT), s.at<float>(CTMI_BLK_STAT_M), s.at<float>(CTMI_BLK_STAT_L),
+    RC(ctmi_attn_fwd(qkv, qkv + qkv_part(b, 1) * e, qkv + qkv_part(b, 2) * e, s.at(CTMI_BLK_ATT), s.at<float>(CTMI_BLK_STAT_M), s.at<float>(CTMI_BLK_STAT_L),
                      b->slopes, b->kpos, b->kvalid, b->first_valid, nullptr, &d, dt, st));
     RC(linear_fwd(s.at(CTMI_BLK_ATT), b->wd, s.at(CTMI_BLK_H1), T, H, H, b->bd, post ? s.at(CTMI_BLK_LN1) : b->x, CTMI_EPI_NONE, nullptr, dt, st));
     RC(ctmi_layernorm_fwd(s.at(CTMI_BLK_H1), b->ln2_w, b->ln2_b, s.at(CTMI_BLK_LN2), s.at<float>(CTMI_BLK_MEAN2), s.at<float>(CTMI_BLK_RSTD2), T, H, b->eps, dt, st));
@@ -194,6 +205,7 @@ extern "C" int ctmi_bloom_block_bwd(const ctmi_bloom_block* b, const ctmi_bloom_
     auto W = [&](int slot) { return reinterpret_cast<void*>(wsb + woff[slot]); };
     auto WF = [&](int slot) { return reinterpret_cast<float*>(wsb + woff[slot]); };
     const bool post = b->post_ln_res != 0;
+    const bool wio = (b->flags & CTMI_BLK_WGRAD_IN_OUT) != 0;
     hipStream_t main_st = as_stream(stream);
     hipStream_t side = gr->side_stream ? as_stream(gr->side_stream) : nullptr;
     const bool two = side != nullptr && side != main_st;
@@ -225,10 +237,10 @@ extern "C" int ctmi_bloom_block_bwd(const ctmi_bloom_block* b, const ctmi_bloom_
     const void* dout = gr->dout;
     // ---- MLP: out = res2 + W2 gelu(W1 ln2 + b1) + b2
     RC(fork());
-    RC(linear_wgrad(dout, s.at(CTMI_BLK_G), gr->dw2, T, H, 4 * H, dt, pws, pws_bytes, pst));
+    RC(linear_wgrad(dout, s.at(CTMI_BLK_G), gr->dw2, T, H, 4 * H, dt, pws, pws_bytes, pst, wio));
     RC(linear_dgrad(dout, b->w2, W(W_DU), T, H, 4 * H, CTMI_BLOCK_GELUG ? CTMI_EPI_MUL : CTMI_EPI_DGELU, s.at(CTMI_BLK_U), nullptr, dt, nullptr, 0, main_st));        // modeling_bloom.py:348-363 fused
     RC(fork());
-    RC(linear_wgrad(W(W_DU), s.at(CTMI_BLK_LN2), gr->dw1, T, 4 * H, H, dt, pws, pws_bytes, pst));
+    RC(linear_wgrad(W(W_DU), s.at(CTMI_BLK_LN2), gr->dw1, T, 4 * H, H, dt, pws, pws_bytes, pst, wio));
     RC(colsum_job(W(W_DU), 4 * H, W_CS_DU, gr->db1));
     RC(linear_dgrad(W(W_DU), b->w1, W(W_DLN2), T, 4 * H, H, CTMI_EPI_NONE, nullptr, post ? dout : nullptr, dt, gr->splitk_ws, gr->splitk_ws_bytes, main_st));
     int np2 = 0, ns2 = 2;
@@ -243,15 +255,15 @@ extern "C" int ctmi_bloom_block_bwd(const ctmi_bloom_block* b, const ctmi_bloom_
     else RC(colsum_job(dout, H, W_CS_DOUT, gr->db2));
     if (ns2 == 4) job(WF(W_LNP2) + 3 * H, ns2 * H, np2, gr->dbd, H);
     else RC(colsum_job(W(W_DH1), H, W_CS_DH1, gr->dbd));
-    RC(linear_wgrad(W(W_DH1), s.at(CTMI_BLK_ATT), gr->dwd, T, H, H, dt, pws, pws_bytes, pst));
+    RC(linear_wgrad(W(W_DH1), s.at(CTMI_BLK_ATT), gr->dwd, T, H, H, dt, pws, pws_bytes, pst, wio));
     RC(linear_dgrad(W(W_DH1), b->wd, W(W_DATT), T, H, H, CTMI_EPI_NONE, nullptr, nullptr, dt, gr->splitk_ws, gr->splitk_ws_bytes, main_st));
     const ctmi_attn_desc d = fused_qkv_desc(b);
     char* qkv = s.at<char>(CTMI_BLK_QKV);
     char* dqkv = reinterpret_cast<char*>(W(W_DQKV));
-    RC(ctmi_attn_bwd(qkv, qkv + hd * e, qkv + 2 * hd * e, s.at(CTMI_BLK_ATT), W(W_DATT), s.at<float>(CTMI_BLK_STAT_M), s.at<float>(CTMI_BLK_STAT_L),
-                     dqkv, dqkv + hd * e, dqkv + 2 * hd * e, WF(W_DELTA), b->slopes, b->kpos, b->kvalid, b->first_valid, nullptr, &d, dt, main_st));
+    RC(ctmi_attn_bwd(qkv, qkv + qkv_part(b, 1) * e, qkv + qkv_part(b, 2) * e, s.at(CTMI_BLK_ATT), W(W_DATT), s.at<float>(CTMI_BLK_STAT_M), s.at<float>(CTMI_BLK_STAT_L),
+                     dqkv, dqkv + qkv_part(b, 1) * e, dqkv + qkv_part(b, 2) * e, WF(W_DELTA), b->slopes, b->kpos, b->kvalid, b->first_valid, nullptr, &d, dt, main_st));
     RC(fork());
-    RC(linear_wgrad(dqkv, s.at(CTMI_BLK_LN1), gr->dwqkv, T, 3 * H, H, dt, pws, pws_bytes, pst));
+    RC(linear_wgrad(dqkv, s.at(CTMI_BLK_LN1), gr->dwqkv, T, 3 * H, H, dt, pws, pws_bytes, pst, wio));
     RC(colsum_job(dqkv, 3 * H, W_CS_DQKV, gr->dbqkv));
     RC(linear_dgrad(dqkv, b->wqkv, W(W_DLN1), T, 3 * H, H, CTMI_EPI_NONE, nullptr, post ? W(W_DH1) : nullptr, dt, gr->splitk_ws, gr->splitk_ws_bytes, main_st));
     int np1 = 0, ns1 = 2;

@@ -148,6 +148,66 @@ class GPTAttnFn(torch.autograd.Function):
         return dqkv.view(out.shape[0], out.shape[1], 3 * H), None, None, None, None, None
 
 
+class GPT2BlockFn(torch.autograd.Function):
+    """One pre-LN GPT-2/3 block (modeling_gpt.py:144-149 with AttentionLayer :52-101 and the MLP :122-133) as ONE autograd node and ONE
+    library call per direction — the block-level entry point of the C ABI (ctmi_bloom_block_fwd/bwd) with the GPT-2 flags: q | k | v
+    blocked QKV activation, -1e4 future fill, optional score scaling, weight gradients written in Conv1D's [in,out] layout.  Used
+    for training steps without dropout; everything else (GPT-1's post-LN order, dropout, KV-cache decode) keeps the per-op path."""
+
+    @staticmethod
+    def forward(ctx, x, n1w, n1b, wa, ba, wp, bp, n2w, n2b, wf, bf, wo, bo, mask: ops.MaskInfo, nh: int, eps: float, scale: float, kv_out: list):
+        B, S, H = x.shape
+        cd = x.dtype
+        x2 = x.reshape(B * S, H)
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        params = (n1w.detach(), n1b.detach(), ops.compute_weight_t(wa, cd), ba.detach(), ops.compute_weight_t(wp, cd), bp.detach(),
+                  n2w.detach(), n2b.detach(), ops.compute_weight_t(wf, cd), bf.detach(), ops.compute_weight_t(wo, cd), bo.detach())
+        acts = ops.bloom_block_fwd(x2, params, mask, None, eps, False, B, S, nh, flags=_lib.BLK_QKV_BLOCKED | _lib.BLK_WGRAD_IN_OUT,
+                                   attn_scale=scale, future_fill=-1e4)
+        ctx.save_for_backward(x2, n1w, n1b, wa, ba, wp, bp, n2w, n2b, wf, bf, wo, bo)
+        ctx.acts, ctx.mask, ctx.eps, ctx.shape = acts, mask, eps, (B, S, H)
+        kv_out.append(_LazyKVBlocked(acts, B, S, nh))
+        return acts.out.view(B, S, H)
+
+    @staticmethod
+    def backward(ctx, dout):
+        if dout is None:
+            return (None,) * 18
+        x2, n1w, n1b, wa, ba, wp, bp, n2w, n2b, wf, bf, wo, bo = ctx.saved_tensors
+        B, S, H = ctx.shape
+        cd = x2.dtype
+        dout2 = dout.reshape(B * S, H)
+        dout2 = dout2 if dout2.is_contiguous() else dout2.contiguous()
+        params = (n1w.detach(), n1b.detach(), ops.compute_weight_t(wa, cd), ba.detach(), ops.compute_weight_t(wp, cd), bp.detach(),
+                  n2w.detach(), n2b.detach(), ops.compute_weight_t(wf, cd), bf.detach(), ops.compute_weight_t(wo, cd), bo.detach())
+        dx, g = ops.bloom_block_bwd(ctx.acts, x2, params, ctx.mask, None, ctx.eps, False, dout2)
+        return (dx.view(B, S, H), *g, None, None, None, None, None)
+
+
+class _LazyKVBlocked:
+    """(k, v) [B,nh,S,hd] views of the q | k | v activation kept by GPT2BlockFn, built when first indexed."""
+    __slots__ = ("_acts", "_geo", "_kv")
+
+    def __init__(self, acts, B, S, nh):
+        self._acts, self._geo, self._kv = acts, (B, S, nh), None
+
+    def _make(self):
+        if self._kv is None:
+            B, S, nh = self._geo
+            qv = self._acts.qkv.view(B, S, 3, nh, -1)
+            self._kv = (qv[:, :, 1].transpose(1, 2), qv[:, :, 2].transpose(1, 2))
+        return self._kv
+
+    def __getitem__(self, i):
+        return self._make()[i]
+
+    def __iter__(self):
+        return iter(self._make())
+
+    def __len__(self):
+        return 2
+
+
 def _attend_cached(qkv: Tensor, past, mask: ops.MaskInfo, nh: int, scale: float, drop_p: float = 0.0, drop_seed: int = 0):
     """Inference with a KV cache (modeling_gpt.py:75-80): returns the context and the concatenated (k, v) [B,nh,Sk,hd]."""
     B, S, H3 = qkv.shape
@@ -259,7 +319,17 @@ class TransformerBlock(torch.nn.Module):
             s1, k_v_past = self.attn(x, attention_mask=attention_mask, head_mask=head_mask, k_v_past=k_v_past, residual=x)
             n1 = self.norm1(s1)
             output = self.norm2(self._mlp(n1, residual=n1))
-        else:                                                                        # GPT-2/3: pre-LN (:144-149)
+        elif (k_v_past is None and torch.is_grad_enabled() and x.requires_grad
+              and not (self.training and (self.attn.attn_dropout.p > 0.0 or self.attn.resid_dropout.p > 0.0 or self.mlp[3].p > 0.0))):
+            # GPT-2/3 pre-LN training step without dropout: one autograd node, one library call per direction
+            a, fc, proj = self.attn, self.mlp[0], self.mlp[2]
+            hd = a.n_state // a.n_head
+            kv = []
+            output = GPT2BlockFn.apply(x, self.norm1.weight, self.norm1.bias, a.c_attn.weight, a.c_attn.bias, a.c_proj.weight, a.c_proj.bias,
+                                       self.norm2.weight, self.norm2.bias, fc.weight, fc.bias, proj.weight, proj.bias,
+                                       attention_mask, a.n_head, self.norm1.eps, (1.0 / math.sqrt(hd)) if a.scale else 1.0, kv)
+            k_v_past = kv[0]
+        else:                                                                        # GPT-2/3: pre-LN (:144-149), per-op
             x, k_v_past = self.attn(self.norm1(x), attention_mask=attention_mask, head_mask=head_mask, k_v_past=k_v_past, residual=x)
             output = self._mlp(self.norm2(x), residual=x)
         return output, k_v_past

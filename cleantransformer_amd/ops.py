@@ -380,7 +380,7 @@ def _block_ws(device, nbytes: int) -> Tensor:
 
 class BlockActs:
     """Activations one block keeps for its backward: ONE slab (layout: ctmi_bloom_block_layout) plus the geometry."""
-    __slots__ = ("slab", "lay", "B", "S", "H", "nh", "dtype")
+    __slots__ = ("slab", "lay", "B", "S", "H", "nh", "dtype", "flags", "attn_scale", "future_fill")
 
     def view(self, slot: str, rows: int, cols: int, dtype=None) -> Tensor:
         dtype = dtype or self.dtype
@@ -398,9 +398,11 @@ class BlockActs:
 
 
 def _fill_block_desc(d: "_lib.BloomBlock", x2: Tensor, params, mask: Optional[MaskInfo], slopes: Optional[Tensor], eps: float,
-                     post_ln_res: bool, B: int, S: int, H: int, nh: int, slab: Tensor) -> None:
+                     post_ln_res: bool, B: int, S: int, H: int, nh: int, slab: Tensor, flags: int = 0, attn_scale: float = 0.0,
+                     future_fill: float = 0.0) -> None:
     d.B, d.S, d.H, d.nh = B, S, H, nh
     d.eps, d.post_ln_res, d.dtype = float(eps), int(post_ln_res), dt_code(x2.dtype)
+    d.flags, d.attn_scale, d.future_fill = int(flags), float(attn_scale), float(future_fill)
     for name, t in zip(_lib.BLK_PARAMS, params):
         setattr(d, name, t.data_ptr())
     d.slopes = None if slopes is None else slopes.data_ptr()
@@ -412,17 +414,19 @@ def _fill_block_desc(d: "_lib.BloomBlock", x2: Tensor, params, mask: Optional[Ma
 
 
 def bloom_block_fwd(x2: Tensor, params, mask: Optional[MaskInfo], slopes: Optional[Tensor], eps: float, post_ln_res: bool,
-                    B: int, S: int, nh: int) -> BlockActs:
+                    B: int, S: int, nh: int, flags: int = 0, attn_scale: float = 0.0, future_fill: float = 0.0) -> BlockActs:
     """modeling_bloom.py:142-159 for x2 [B*S, H]; `params` = the 12 block parameters in _lib.BLK_PARAMS order, weight
-    matrices already in the compute dtype.  One library call; returns the saved activations (whose `.out` is the result)."""
+    matrices already in the compute dtype ([out,in]).  One library call; returns the saved activations (whose `.out` is the result).
+    flags / attn_scale / future_fill spell the same pre-LN block the way GPT-2 lays it out (modeling_gpt.py:144-149)."""
     _need_cuda(x2, *params)
     H = x2.shape[1]
     acts = BlockActs()
     acts.B, acts.S, acts.H, acts.nh, acts.dtype = B, S, H, nh, x2.dtype
+    acts.flags, acts.attn_scale, acts.future_fill = flags, attn_scale, future_fill
     acts.lay = block_layout(B, S, H, nh, x2.dtype)
     acts.slab = torch.empty(acts.lay.bytes, dtype=torch.uint8, device=x2.device)
     d = _lib.BloomBlock()
-    _fill_block_desc(d, x2, params, mask, slopes, eps, post_ln_res, B, S, H, nh, acts.slab)
+    _fill_block_desc(d, x2, params, mask, slopes, eps, post_ln_res, B, S, H, nh, acts.slab, flags, attn_scale, future_fill)
     check(_lib.load().ctmi_bloom_block_fwd(C.byref(d), _stream()), "bloom_block_fwd")
     return acts
 
@@ -434,10 +438,11 @@ def bloom_block_bwd(acts: BlockActs, x2: Tensor, params, mask: Optional[MaskInfo
     B, S, H, nh = acts.B, acts.S, acts.H, acts.nh
     dev = x2.device
     d = _lib.BloomBlock()
-    _fill_block_desc(d, x2, params, mask, slopes, eps, post_ln_res, B, S, H, nh, acts.slab)
+    _fill_block_desc(d, x2, params, mask, slopes, eps, post_ln_res, B, S, H, nh, acts.slab, acts.flags, acts.attn_scale, acts.future_fill)
     g = _lib.BloomBlockGrads()
     dx = torch.empty_like(x2)
-    grads = [torch.empty(p.shape, dtype=torch.float32, device=dev) for p in params]
+    wio = bool(acts.flags & _lib.BLK_WGRAD_IN_OUT)                     # Conv1D weights: gradients in the parameter's own [in,out] layout
+    grads = [torch.empty(tuple(reversed(p.shape)) if (wio and p.dim() == 2) else p.shape, dtype=torch.float32, device=dev) for p in params]
     g.dout, g.dx = dout2.data_ptr(), dx.data_ptr()
     for name, t in zip(_lib.BLK_PARAMS, grads):
         setattr(g, "d" + name, t.data_ptr())

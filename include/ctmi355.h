@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CTMI_ABI_VERSION 4
+#define CTMI_ABI_VERSION 5
 
 enum ctmi_dtype { CTMI_F32 = 0, CTMI_BF16 = 1 };
 enum ctmi_status { CTMI_OK = 0, CTMI_ERR_ARG = -1, CTMI_ERR_LAUNCH = -2, CTMI_ERR_UNSUPPORTED = -3 };
@@ -249,10 +249,18 @@ enum ctmi_block_slot {                  /* index into the offsets[] array filled
     CTMI_BLK_LN1 = 0, CTMI_BLK_MEAN1, CTMI_BLK_RSTD1, CTMI_BLK_QKV, CTMI_BLK_ATT, CTMI_BLK_STAT_M, CTMI_BLK_STAT_L,
     CTMI_BLK_H1, CTMI_BLK_MEAN2, CTMI_BLK_RSTD2, CTMI_BLK_LN2, CTMI_BLK_U, CTMI_BLK_G, CTMI_BLK_OUT, CTMI_BLK_NSLOTS
 };
+/* flags: the GPT-2 spelling of the same block (modeling_gpt.py:52-101, 122-149).  QKV_BLOCKED: the fused activation is q | k | v
+ * ([T, 3, nh, hd], c_attn of modeling_gpt.py:69-72) instead of Bloom's head-interleaved [T, nh, 3, hd]; WGRAD_IN_OUT: the four weight
+ * gradients are written [in, out] (Conv1D stores its weight that way, modeling_gpt.py:32-46; the weights passed in are still the
+ * [out, in] compute copies). */
+enum ctmi_block_flags { CTMI_BLK_QKV_BLOCKED = 1, CTMI_BLK_WGRAD_IN_OUT = 2 };
 typedef struct ctmi_bloom_block {
     int64_t B, S, H, nh;
     float eps; int32_t post_ln_res;     /* apply_residual_connection_post_layernorm (modeling_bloom.py:145-148,157) */
-    int32_t dtype; int32_t pad_;
+    int32_t dtype;
+    int32_t flags;                      /* CTMI_BLK_* below: the same pre-LN block as GPT-2 lays it out (modeling_gpt.py:144-149) */
+    float attn_scale;                   /* 0: 1/sqrt(head_dim); GPT-1/2 pass 1 or 1/sqrt(hd) (modeling_gpt.py:83-84 `scale`) */
+    float future_fill;                  /* ctmi_attn_desc.future_fill: 0 = finfo.min (Bloom), -1e4 for GPT-2 */
     const float *ln1_w, *ln1_b; const void* wqkv; const float* bqkv; const void* wd; const float* bd;
     const float *ln2_w, *ln2_b; const void* w1; const float* b1; const void* w2; const float* b2;
     const float* slopes;                /* [nh] ALiBi slopes */

@@ -407,7 +407,19 @@ def _fused_desc(B, S, nh, hd):
     return ops.fused_qkv_desc(B, S, nh, hd, causal=S > 1)
 
 
-def bloom_block_fwd(x2, params, mask, slopes, eps, post_ln_res, B, S, nh, K=None):
+def _block_desc(B, S, nh, hd, flags, attn_scale, future_fill):
+    from cleantransformer_amd import ops
+    H = nh * hd
+    if flags & 1:                                          # q | k | v blocked (GPT-2)
+        st = (S * 3 * H, hd, 3 * H)
+        return ops._strided_desc(B, nh, S, S, hd, st, st, st, (S * H, hd, H), attn_scale or 1.0 / math.sqrt(hd), S > 1, future_fill=future_fill), H
+    d = ops.fused_qkv_desc(B, S, nh, hd, causal=S > 1)
+    d.scale = attn_scale or d.scale
+    d.future_fill = future_fill
+    return d, hd
+
+
+def bloom_block_fwd(x2, params, mask, slopes, eps, post_ln_res, B, S, nh, flags=0, attn_scale=0.0, future_fill=0.0, K=None):
     """The kernel sequence ctmi_bloom_block_fwd issues (csrc/block.hip), on the emulated kernels — or, with K =
     cleantransformer_amd.ops, on the individually verified HIP kernels (the -m gpu tests check the one-call form against it)."""
     K = K or _THIS
@@ -418,15 +430,15 @@ def bloom_block_fwd(x2, params, mask, slopes, eps, post_ln_res, B, S, nh, K=None
     cd = x2.dtype
     ln1, mean1, rstd1 = layernorm_fwd(x2, ln1_w, ln1_b, eps)
     qkv = gemm(ln1, H, False, wqkv, H, False, T, 3 * H, H, bias=bqkv)
-    desc = _fused_desc(B, S, nh, hd)
+    desc, part = _block_desc(B, S, nh, hd, flags, attn_scale, future_fill)
     att = torch.empty((T, H), dtype=cd, device=x2.device)
-    stat_m, stat_l = attn_fwd(qkv, qkv[:, hd:], qkv[:, 2 * hd:], att, desc, slopes, mask)
+    stat_m, stat_l = attn_fwd(qkv, qkv[:, part:], qkv[:, 2 * part:], att, desc, slopes, mask)
     h1 = gemm(att, H, False, wd, H, False, T, H, H, bias=bd, residual=ln1 if post_ln_res else x2)
     ln2, mean2, rstd2 = layernorm_fwd(h1, ln2_w, ln2_b, eps)
     u = torch.empty((T, 4 * H), dtype=cd, device=x2.device)
     g = gemm(ln2, H, False, w1, H, False, T, 4 * H, H, bias=b1, epilogue=1, aux_out=u)
     out = gemm(g, 4 * H, False, w2, 4 * H, False, T, H, 4 * H, bias=b2, residual=ln2 if post_ln_res else h1)
-    return BlockActs(B=B, S=S, H=H, nh=nh, dtype=cd, desc=desc, ln1=ln1, mean1=mean1, rstd1=rstd1, qkv=qkv, att=att, stat_m=stat_m,
+    return BlockActs(B=B, S=S, H=H, nh=nh, dtype=cd, desc=desc, part=part, flags=flags, ln1=ln1, mean1=mean1, rstd1=rstd1, qkv=qkv, att=att, stat_m=stat_m,
                      stat_l=stat_l, h1=h1, mean2=mean2, rstd2=rstd2, ln2=ln2, u=u, g=g, out=out)
 
 
@@ -443,6 +455,8 @@ def bloom_block_bwd(a, x2, params, mask, slopes, eps, post_ln_res, dout2, use_si
         return gemm(dy, dy.shape[1], False, w, w.shape[1], True, T, w.shape[1], dy.shape[1], **kw)
 
     def wgrad(dy, x):
+        if a.flags & 2:                                    # Conv1D weights: gradient in [in, out]
+            return gemm(x, x.shape[1], True, dy, dy.shape[1], True, x.shape[1], dy.shape[1], T, out_f32=True)
         return gemm(dy, dy.shape[1], True, x, x.shape[1], True, dy.shape[1], x.shape[1], T, out_f32=True)
 
     dw2, db2 = wgrad(dout2, a.g), colsum(dout2)
@@ -453,7 +467,8 @@ def bloom_block_bwd(a, x2, params, mask, slopes, eps, post_ln_res, dout2, use_si
     dwd, dbd = wgrad(dh1, a.att), colsum(dh1)
     datt = dgrad(dh1, wd)
     dqkv = torch.empty_like(a.qkv)
-    attn_bwd(a.qkv, a.qkv[:, hd:], a.qkv[:, 2 * hd:], a.att, datt, a.stat_m, a.stat_l, dqkv, dqkv[:, hd:], dqkv[:, 2 * hd:], a.desc,
+    pt = a.part
+    attn_bwd(a.qkv, a.qkv[:, pt:], a.qkv[:, 2 * pt:], a.att, datt, a.stat_m, a.stat_l, dqkv, dqkv[:, pt:], dqkv[:, 2 * pt:], a.desc,
              slopes, mask)
     dwqkv, dbqkv = wgrad(dqkv, a.ln1), colsum(dqkv)
     dln1 = dgrad(dqkv, wqkv, residual=dh1 if post else None)
