@@ -163,7 +163,7 @@ def test_layernorm_module_golden_and_multidim():
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-GEMM_SHAPES = [(128, 128, 64), (256, 384, 128), (100, 72, 40), (64, 211, 64), (37, 19, 211), (130, 260, 1000), (512, 1024, 1024)]
+GEMM_SHAPES = [(128, 128, 64), (256, 384, 128), (100, 72, 40), (64, 211, 64), (37, 19, 211), (130, 260, 1000), (512, 1024, 1024), (512, 768, 256)]
 
 
 @pytest.mark.parametrize("dtype,rtol,atol", [(torch.float32, 1e-5, 1e-5), (torch.bfloat16, 1.2e-2, 1.2e-2)])
@@ -532,6 +532,29 @@ def test_scale_and_scale_copy_bit_exact():
         assert torch.equal(y.cpu(), want)
 
 
+def test_gemm_more_tiles_than_slots():
+    """Persistent launches: more output tiles than resident workgroups, so workgroups walk several tiles and the DMA stream, the
+    cross-tile prefetch run across tile boundaries.  All three operand layouts,
+    bf16, against torch on the same device in fp32."""
+    o = ops()
+    M, N, K = 4096, 4352, 192                                 # 16 x 17 = 272 tiles of 256 x 256 (> 256 CUs), 3 K-step pairs
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(N, K, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    dy = (torch.randn(M, N, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    y = o.linear_fwd(x, w, None)
+    ref = x.float() @ w.float().t()
+    assert torch.allclose(y.float(), ref, rtol=1.2e-2, atol=1.2e-2 * math.sqrt(K)), (y.float() - ref).abs().max()
+    dx = o.linear_dgrad(dy, w)                                # [M, K]: small output, long K
+    ref = dy.float() @ w.float()
+    assert torch.allclose(dx.float(), ref, rtol=1.2e-2, atol=1.2e-2 * math.sqrt(N)), (dx.float() - ref).abs().max()
+    x2 = (torch.randn(1024, N, generator=g) * 0.5).to(torch.bfloat16).to(DEV)      # wgrad with a [4096, 4352] output: dy2^T x2
+    dy2 = (torch.randn(1024, M, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    dw = o.linear_wgrad(dy2, x2)
+    ref = dy2.float().t() @ x2.float()
+    assert torch.allclose(dw.float(), ref, rtol=1e-3, atol=1e-2), (dw.float() - ref).abs().max()
+
+
 @pytest.mark.parametrize("env", [{"CTMI_GEMM_TILE": "0"}, {"CTMI_GEMM_TILE": "1"}, {"CTMI_GEMM_TILE": "2"}, {"CTMI_GEMM_TILE": "3"},
                                  {"CTMI_GEMM_TILE": "4"}, {"CTMI_GEMM_SHARED": "1"}, {"CTMI_GEMM_PERSIST": "0"},
                                  {"CTMI_GEMM_TILE": "3", "CTMI_GEMM_SPLIT": "1"}, {"CTMI_GEMM_GLDS": "0"}],
@@ -546,7 +569,7 @@ def test_gemm_every_tile_schedule_and_policy(env):
     e = dict(os.environ)
     e.update(env)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k",
-                        "test_gemm_forward_dgrad_wgrad or test_gemm_transpose_detecting_identity or test_linear"],
+                        "test_gemm_forward_dgrad_wgrad or test_gemm_transpose_detecting_identity or test_linear or test_gemm_more_tiles_than_slots"],
                        env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:]
