@@ -39,7 +39,7 @@ class ReduceJob(C.Structure):
 
 
 BLK_SLOTS = ("ln1", "mean1", "rstd1", "qkv", "att", "stat_m", "stat_l", "h1", "mean2", "rstd2", "ln2", "u", "g", "out")
-BLK_QKV_BLOCKED, BLK_WGRAD_IN_OUT = 1, 2
+BLK_QKV_BLOCKED, BLK_WGRAD_IN_OUT, BLK_W_IN_OUT = 1, 2, 4
 BLK_PARAMS = ("ln1_w", "ln1_b", "wqkv", "bqkv", "wd", "bd", "ln2_w", "ln2_b", "w1", "b1", "w2", "b2")
 
 

@@ -90,17 +90,19 @@ int64_t qkv_part(const ctmi_bloom_block* b, int which) {
     return (b->flags & CTMI_BLK_QKV_BLOCKED) ? which * H : which * hd;
 }
 
-// y[T,N] = epi(x[T,K] W[N,K]^T + bias) (+ residual)
+// y[T,N] = epi(x[T,K] W[N,K]^T + bias) (+ residual); w_in_out: the weight is stored [K,N] (GPT-2's Conv1D, modeling_gpt.py:32-46) and
+// is read K-major — no transposed copy of it exists
 int linear_fwd(const void* x, const void* w, void* y, int64_t T, int64_t N, int64_t K, const float* bias, const void* residual,
-               int epi, void* aux_out, int dtype, hipStream_t st) {
-    return ctmi_gemm(x, K, 0, w, K, 0, y, N, T, N, K, 1.0f, 0, bias, residual, epi, nullptr, aux_out, 0, dtype, nullptr, 0, st);
+               int epi, void* aux_out, int dtype, hipStream_t st, bool w_in_out = false) {
+    return ctmi_gemm(x, K, 0, w, w_in_out ? N : K, w_in_out ? 1 : 0, y, N, T, N, K, 1.0f, 0, bias, residual, epi, nullptr, aux_out, 0, dtype,
+                     nullptr, 0, st);
 }
-// dx[T,Kin] = epi(dy[T,Nout] W[Nout,Kin]) (+ residual)
+// dx[T,Kin] = epi(dy[T,Nout] W[Nout,Kin]) (+ residual); w_in_out: W stored [Kin,Nout], read as the row-major B operand
 int linear_dgrad(const void* dy, const void* w, void* dx, int64_t T, int64_t Nout, int64_t Kin, int epi, const void* aux_in,
-                 const void* residual, int dtype, void* ws, int64_t ws_bytes, hipStream_t st) {
+                 const void* residual, int dtype, void* ws, int64_t ws_bytes, hipStream_t st, bool w_in_out = false) {
     const bool plain = epi == CTMI_EPI_NONE && residual == nullptr;
-    return ctmi_gemm(dy, Nout, 0, w, Kin, 1, dx, Kin, T, Kin, Nout, 1.0f, 0, nullptr, residual, epi, aux_in, nullptr, 0, dtype,
-                     plain ? ws : nullptr, plain ? ws_bytes : 0, st);
+    return ctmi_gemm(dy, Nout, 0, w, w_in_out ? Nout : Kin, w_in_out ? 0 : 1, dx, Kin, T, Kin, Nout, 1.0f, 0, nullptr, residual, epi, aux_in,
+                     nullptr, 0, dtype, plain ? ws : nullptr, plain ? ws_bytes : 0, st);
 }
 // dW[Nout,Kin] (fp32) = dy[T,Nout]^T x[T,Kin]   — or, in_out: dW[Kin,Nout] = x^T dy (a Conv1D weight is stored [in,out])
 int linear_wgrad(const void* dy, const void* x, float* dw, int64_t T, int64_t Nout, int64_t Kin, int dtype, void* ws, int64_t ws_bytes,
@@ -148,17 +150,18 @@ extern "C" int ctmi_bloom_block_fwd(const ctmi_bloom_block* b, void* stream) {
     Slab s; s.base = reinterpret_cast<char*>(b->slab);
     ctmi_bloom_block_layout(b->B, b->S, H, b->nh, dt, s.off);
     const bool post = b->post_ln_res != 0;
+    const bool w_io = (b->flags & CTMI_BLK_W_IN_OUT) != 0;
 
     RC(ctmi_layernorm_fwd(b->x, b->ln1_w, b->ln1_b, s.at(CTMI_BLK_LN1), s.at<float>(CTMI_BLK_MEAN1), s.at<float>(CTMI_BLK_RSTD1), T, H, b->eps, dt, st));
-    RC(linear_fwd(s.at(CTMI_BLK_LN1), b->wqkv, s.at(CTMI_BLK_QKV), T, 3 * H, H, b->bqkv, nullptr, CTMI_EPI_NONE, nullptr, dt, st));
+    RC(linear_fwd(s.at(CTMI_BLK_LN1), b->wqkv, s.at(CTMI_BLK_QKV), T, 3 * H, H, b->bqkv, nullptr, CTMI_EPI_NONE, nullptr, dt, st, w_io));
     const ctmi_attn_desc d = fused_qkv_desc(b);
     char* qkv = s.at<char>(CTMI_BLK_QKV);
     RC(ctmi_attn_fwd(qkv, qkv + qkv_part(b, 1) * e, qkv + qkv_part(b, 2) * e, s.at(CTMI_BLK_ATT), s.at<float>(CTMI_BLK_STAT_M), s.at<float>(CTMI_BLK_STAT_L),
                      b->slopes, b->kpos, b->kvalid, b->first_valid, nullptr, &d, dt, st));
-    RC(linear_fwd(s.at(CTMI_BLK_ATT), b->wd, s.at(CTMI_BLK_H1), T, H, H, b->bd, post ? s.at(CTMI_BLK_LN1) : b->x, CTMI_EPI_NONE, nullptr, dt, st));
+    RC(linear_fwd(s.at(CTMI_BLK_ATT), b->wd, s.at(CTMI_BLK_H1), T, H, H, b->bd, post ? s.at(CTMI_BLK_LN1) : b->x, CTMI_EPI_NONE, nullptr, dt, st, w_io));
     RC(ctmi_layernorm_fwd(s.at(CTMI_BLK_H1), b->ln2_w, b->ln2_b, s.at(CTMI_BLK_LN2), s.at<float>(CTMI_BLK_MEAN2), s.at<float>(CTMI_BLK_RSTD2), T, H, b->eps, dt, st));
-    RC(linear_fwd(s.at(CTMI_BLK_LN2), b->w1, s.at(CTMI_BLK_G), T, 4 * H, H, b->b1, nullptr, CTMI_BLOCK_GELUG ? CTMI_EPI_GELUG : CTMI_EPI_GELU, s.at(CTMI_BLK_U), dt, st));
-    RC(linear_fwd(s.at(CTMI_BLK_G), b->w2, s.at(CTMI_BLK_OUT), T, H, 4 * H, b->b2, post ? s.at(CTMI_BLK_LN2) : s.at(CTMI_BLK_H1), CTMI_EPI_NONE, nullptr, dt, st));
+    RC(linear_fwd(s.at(CTMI_BLK_LN2), b->w1, s.at(CTMI_BLK_G), T, 4 * H, H, b->b1, nullptr, CTMI_BLOCK_GELUG ? CTMI_EPI_GELUG : CTMI_EPI_GELU, s.at(CTMI_BLK_U), dt, st, w_io));
+    RC(linear_fwd(s.at(CTMI_BLK_G), b->w2, s.at(CTMI_BLK_OUT), T, H, 4 * H, b->b2, post ? s.at(CTMI_BLK_LN2) : s.at(CTMI_BLK_H1), CTMI_EPI_NONE, nullptr, dt, st, w_io));
     return CTMI_OK;
 }
 
@@ -206,6 +209,7 @@ extern "C" int ctmi_bloom_block_bwd(const ctmi_bloom_block* b, const ctmi_bloom_
     auto WF = [&](int slot) { return reinterpret_cast<float*>(wsb + woff[slot]); };
     const bool post = b->post_ln_res != 0;
     const bool wio = (b->flags & CTMI_BLK_WGRAD_IN_OUT) != 0;
+    const bool w_io = (b->flags & CTMI_BLK_W_IN_OUT) != 0;
     hipStream_t main_st = as_stream(stream);
     hipStream_t side = gr->side_stream ? as_stream(gr->side_stream) : nullptr;
     const bool two = side != nullptr && side != main_st;
@@ -238,11 +242,11 @@ extern "C" int ctmi_bloom_block_bwd(const ctmi_bloom_block* b, const ctmi_bloom_
     // ---- MLP: out = res2 + W2 gelu(W1 ln2 + b1) + b2
     RC(fork());
     RC(linear_wgrad(dout, s.at(CTMI_BLK_G), gr->dw2, T, H, 4 * H, dt, pws, pws_bytes, pst, wio));
-    RC(linear_dgrad(dout, b->w2, W(W_DU), T, H, 4 * H, CTMI_BLOCK_GELUG ? CTMI_EPI_MUL : CTMI_EPI_DGELU, s.at(CTMI_BLK_U), nullptr, dt, nullptr, 0, main_st));        // modeling_bloom.py:348-363 fused
+    RC(linear_dgrad(dout, b->w2, W(W_DU), T, H, 4 * H, CTMI_BLOCK_GELUG ? CTMI_EPI_MUL : CTMI_EPI_DGELU, s.at(CTMI_BLK_U), nullptr, dt, nullptr, 0, main_st, w_io));        // modeling_bloom.py:348-363 fused
     RC(fork());
     RC(linear_wgrad(W(W_DU), s.at(CTMI_BLK_LN2), gr->dw1, T, 4 * H, H, dt, pws, pws_bytes, pst, wio));
     RC(colsum_job(W(W_DU), 4 * H, W_CS_DU, gr->db1));
-    RC(linear_dgrad(W(W_DU), b->w1, W(W_DLN2), T, 4 * H, H, CTMI_EPI_NONE, nullptr, post ? dout : nullptr, dt, gr->splitk_ws, gr->splitk_ws_bytes, main_st));
+    RC(linear_dgrad(W(W_DU), b->w1, W(W_DLN2), T, 4 * H, H, CTMI_EPI_NONE, nullptr, post ? dout : nullptr, dt, gr->splitk_ws, gr->splitk_ws_bytes, main_st, w_io));
     int np2 = 0, ns2 = 2;
     RC(ctmi_ln_bwd_parts_internal(W(W_DLN2), s.at(CTMI_BLK_H1), b->ln2_w, s.at<float>(CTMI_BLK_MEAN2), s.at<float>(CTMI_BLK_RSTD2),
                                   post ? nullptr : dout, W(W_DH1), WF(W_LNP2), T, H, dt, 1, &np2, &ns2, main_st));
@@ -256,7 +260,7 @@ extern "C" int ctmi_bloom_block_bwd(const ctmi_bloom_block* b, const ctmi_bloom_
     if (ns2 == 4) job(WF(W_LNP2) + 3 * H, ns2 * H, np2, gr->dbd, H);
     else RC(colsum_job(W(W_DH1), H, W_CS_DH1, gr->dbd));
     RC(linear_wgrad(W(W_DH1), s.at(CTMI_BLK_ATT), gr->dwd, T, H, H, dt, pws, pws_bytes, pst, wio));
-    RC(linear_dgrad(W(W_DH1), b->wd, W(W_DATT), T, H, H, CTMI_EPI_NONE, nullptr, nullptr, dt, gr->splitk_ws, gr->splitk_ws_bytes, main_st));
+    RC(linear_dgrad(W(W_DH1), b->wd, W(W_DATT), T, H, H, CTMI_EPI_NONE, nullptr, nullptr, dt, gr->splitk_ws, gr->splitk_ws_bytes, main_st, w_io));
     const ctmi_attn_desc d = fused_qkv_desc(b);
     char* qkv = s.at<char>(CTMI_BLK_QKV);
     char* dqkv = reinterpret_cast<char*>(W(W_DQKV));
@@ -265,7 +269,7 @@ extern "C" int ctmi_bloom_block_bwd(const ctmi_bloom_block* b, const ctmi_bloom_
     RC(fork());
     RC(linear_wgrad(dqkv, s.at(CTMI_BLK_LN1), gr->dwqkv, T, 3 * H, H, dt, pws, pws_bytes, pst, wio));
     RC(colsum_job(dqkv, 3 * H, W_CS_DQKV, gr->dbqkv));
-    RC(linear_dgrad(dqkv, b->wqkv, W(W_DLN1), T, 3 * H, H, CTMI_EPI_NONE, nullptr, post ? W(W_DH1) : nullptr, dt, gr->splitk_ws, gr->splitk_ws_bytes, main_st));
+    RC(linear_dgrad(dqkv, b->wqkv, W(W_DLN1), T, 3 * H, H, CTMI_EPI_NONE, nullptr, post ? W(W_DH1) : nullptr, dt, gr->splitk_ws, gr->splitk_ws_bytes, main_st, w_io));
     int np1 = 0, ns1 = 2;
     RC(ctmi_ln_bwd_parts_internal(W(W_DLN1), b->x, b->ln1_w, s.at<float>(CTMI_BLK_MEAN1), s.at<float>(CTMI_BLK_RSTD1),
                                   post ? nullptr : W(W_DH1), gr->dx, WF(W_LNP1), T, H, dt, 0, &np1, &ns1, main_st));

@@ -1230,6 +1230,7 @@ int ctmi_gemm_bf16_nt(GemmArgs& g, int epi, bool fast, hipStream_t st) {
     if (epi == CTMI_EPI_GELU) return gemm_launch<bf16_t, bf16_t, false, false, CTMI_EPI_GELU>(g, fast, st);
     if (epi == CTMI_EPI_GELUG) return gemm_launch<bf16_t, bf16_t, false, false, CTMI_EPI_GELUG>(g, fast, st);
     if (epi == CTMI_EPI_RELU) return gemm_launch<bf16_t, bf16_t, false, false, CTMI_EPI_RELU>(g, fast, st);
+    if (epi == CTMI_EPI_DGELU) return gemm_launch<bf16_t, bf16_t, false, false, CTMI_EPI_DGELU>(g, fast, st);   // data gradient through an [in,out] (Conv1D) weight
     return gemm_unsupported(0, 0, epi, 0);
 }
 #endif
@@ -1239,6 +1240,7 @@ int ctmi_gemm_bf16_nn(GemmArgs& g, int epi, bool fast, hipStream_t st) {
     if (epi == CTMI_EPI_DGELU) return gemm_launch<bf16_t, bf16_t, false, true, CTMI_EPI_DGELU>(g, fast, st);
     if (epi == CTMI_EPI_MUL) return gemm_launch<bf16_t, bf16_t, false, true, CTMI_EPI_MUL>(g, fast, st);
     if (epi == CTMI_EPI_DRELU) return gemm_launch<bf16_t, bf16_t, false, true, CTMI_EPI_DRELU>(g, fast, st);
+    if (epi == CTMI_EPI_GELU) return gemm_launch<bf16_t, bf16_t, false, true, CTMI_EPI_GELU>(g, fast, st);     // forward through an [in,out] (Conv1D) weight
     return gemm_unsupported(0, 1, epi, 0);
 }
 #endif
@@ -1264,12 +1266,14 @@ static int gemm_dispatch_f32(GemmArgs& g, int ak, int bk, int epi, bool fast, hi
         if (epi == CTMI_EPI_GELU) return gemm_launch<T, float, false, false, CTMI_EPI_GELU>(g, fast, st);
         if (epi == CTMI_EPI_GELUG) return gemm_launch<T, float, false, false, CTMI_EPI_GELUG>(g, fast, st);
         if (epi == CTMI_EPI_RELU) return gemm_launch<T, float, false, false, CTMI_EPI_RELU>(g, fast, st);
+        if (epi == CTMI_EPI_DGELU) return gemm_launch<T, float, false, false, CTMI_EPI_DGELU>(g, fast, st);
     }
     if (!ak && bk) {
         if (epi == CTMI_EPI_NONE) return gemm_launch<T, float, false, true, CTMI_EPI_NONE>(g, fast, st);
         if (epi == CTMI_EPI_DGELU) return gemm_launch<T, float, false, true, CTMI_EPI_DGELU>(g, fast, st);
         if (epi == CTMI_EPI_MUL) return gemm_launch<T, float, false, true, CTMI_EPI_MUL>(g, fast, st);
         if (epi == CTMI_EPI_DRELU) return gemm_launch<T, float, false, true, CTMI_EPI_DRELU>(g, fast, st);
+        if (epi == CTMI_EPI_GELU) return gemm_launch<T, float, false, true, CTMI_EPI_GELU>(g, fast, st);
     }
     if (ak && bk && epi == CTMI_EPI_NONE) return gemm_launch<T, float, true, true, CTMI_EPI_NONE>(g, fast, st);
     return gemm_unsupported(ak, bk, epi, 1);

@@ -151,7 +151,8 @@ class GPTAttnFn(torch.autograd.Function):
 class GPT2BlockFn(torch.autograd.Function):
     """One pre-LN GPT-2/3 block (modeling_gpt.py:144-149 with AttentionLayer :52-101 and the MLP :122-133) as ONE autograd node and ONE
     library call per direction — the block-level entry point of the C ABI (ctmi_bloom_block_fwd/bwd) with the GPT-2 flags: q | k | v
-    blocked QKV activation, -1e4 future fill, optional score scaling, weight gradients written in Conv1D's [in,out] layout.  Used
+    blocked QKV activation, -1e4 future fill, optional score scaling, weights read AND weight gradients written in Conv1D's own
+    [in,out] layout (the bf16 shadows the optimizer maintains are used as they are: no transposed compute copies on this path).  Used
     for training steps without dropout; everything else (GPT-1's post-LN order, dropout, KV-cache decode) keeps the per-op path."""
 
     @staticmethod
@@ -160,9 +161,9 @@ class GPT2BlockFn(torch.autograd.Function):
         cd = x.dtype
         x2 = x.reshape(B * S, H)
         x2 = x2 if x2.is_contiguous() else x2.contiguous()
-        params = (n1w.detach(), n1b.detach(), ops.compute_weight_t(wa, cd), ba.detach(), ops.compute_weight_t(wp, cd), bp.detach(),
-                  n2w.detach(), n2b.detach(), ops.compute_weight_t(wf, cd), bf.detach(), ops.compute_weight_t(wo, cd), bo.detach())
-        acts = ops.bloom_block_fwd(x2, params, mask, None, eps, False, B, S, nh, flags=_lib.BLK_QKV_BLOCKED | _lib.BLK_WGRAD_IN_OUT,
+        params = (n1w.detach(), n1b.detach(), ops.compute_weight(wa, cd), ba.detach(), ops.compute_weight(wp, cd), bp.detach(),
+                  n2w.detach(), n2b.detach(), ops.compute_weight(wf, cd), bf.detach(), ops.compute_weight(wo, cd), bo.detach())
+        acts = ops.bloom_block_fwd(x2, params, mask, None, eps, False, B, S, nh, flags=_lib.BLK_QKV_BLOCKED | _lib.BLK_WGRAD_IN_OUT | _lib.BLK_W_IN_OUT,
                                    attn_scale=scale, future_fill=-1e4)
         ctx.save_for_backward(x2, n1w, n1b, wa, ba, wp, bp, n2w, n2b, wf, bf, wo, bo)
         ctx.acts, ctx.mask, ctx.eps, ctx.shape = acts, mask, eps, (B, S, H)
@@ -178,8 +179,8 @@ class GPT2BlockFn(torch.autograd.Function):
         cd = x2.dtype
         dout2 = dout.reshape(B * S, H)
         dout2 = dout2 if dout2.is_contiguous() else dout2.contiguous()
-        params = (n1w.detach(), n1b.detach(), ops.compute_weight_t(wa, cd), ba.detach(), ops.compute_weight_t(wp, cd), bp.detach(),
-                  n2w.detach(), n2b.detach(), ops.compute_weight_t(wf, cd), bf.detach(), ops.compute_weight_t(wo, cd), bo.detach())
+        params = (n1w.detach(), n1b.detach(), ops.compute_weight(wa, cd), ba.detach(), ops.compute_weight(wp, cd), bp.detach(),
+                  n2w.detach(), n2b.detach(), ops.compute_weight(wf, cd), bf.detach(), ops.compute_weight(wo, cd), bo.detach())
         dx, g = ops.bloom_block_bwd(ctx.acts, x2, params, ctx.mask, None, ctx.eps, False, dout2)
         return (dx.view(B, S, H), *g, None, None, None, None, None)
 

@@ -441,8 +441,10 @@ def bloom_block_bwd(acts: BlockActs, x2: Tensor, params, mask: Optional[MaskInfo
     _fill_block_desc(d, x2, params, mask, slopes, eps, post_ln_res, B, S, H, nh, acts.slab, acts.flags, acts.attn_scale, acts.future_fill)
     g = _lib.BloomBlockGrads()
     dx = torch.empty_like(x2)
-    wio = bool(acts.flags & _lib.BLK_WGRAD_IN_OUT)                     # Conv1D weights: gradients in the parameter's own [in,out] layout
-    grads = [torch.empty(tuple(reversed(p.shape)) if (wio and p.dim() == 2) else p.shape, dtype=torch.float32, device=dev) for p in params]
+    # Conv1D weights: gradients in the parameter's own [in,out] layout — the transpose of an [out,in] compute copy's shape, or simply
+    # the shape of the weight when that is passed [in,out] itself (BLK_W_IN_OUT)
+    flip = bool(acts.flags & _lib.BLK_WGRAD_IN_OUT) != bool(acts.flags & _lib.BLK_W_IN_OUT)
+    grads = [torch.empty(tuple(reversed(p.shape)) if (flip and p.dim() == 2) else p.shape, dtype=torch.float32, device=dev) for p in params]
     g.dout, g.dx = dout2.data_ptr(), dx.data_ptr()
     for name, t in zip(_lib.BLK_PARAMS, grads):
         setattr(g, "d" + name, t.data_ptr())

@@ -251,9 +251,10 @@ enum ctmi_block_slot {                  /* index into the offsets[] array filled
 };
 /* flags: the GPT-2 spelling of the same block (modeling_gpt.py:52-101, 122-149).  QKV_BLOCKED: the fused activation is q | k | v
  * ([T, 3, nh, hd], c_attn of modeling_gpt.py:69-72) instead of Bloom's head-interleaved [T, nh, 3, hd]; WGRAD_IN_OUT: the four weight
- * gradients are written [in, out] (Conv1D stores its weight that way, modeling_gpt.py:32-46; the weights passed in are still the
- * [out, in] compute copies). */
-enum ctmi_block_flags { CTMI_BLK_QKV_BLOCKED = 1, CTMI_BLK_WGRAD_IN_OUT = 2 };
+ * gradients are written [in, out] (Conv1D stores its weight that way, modeling_gpt.py:32-46); W_IN_OUT: the four weights passed in
+ * are [in, out] too (the parameter's own layout — the forward GEMMs read them K-major, the data-gradient GEMMs as the row-major
+ * operand, so no transposed compute copy is made); without it they are [out, in] as for Bloom. */
+enum ctmi_block_flags { CTMI_BLK_QKV_BLOCKED = 1, CTMI_BLK_WGRAD_IN_OUT = 2, CTMI_BLK_W_IN_OUT = 4 };
 typedef struct ctmi_bloom_block {
     int64_t B, S, H, nh;
     float eps; int32_t post_ln_res;     /* apply_residual_connection_post_layernorm (modeling_bloom.py:145-148,157) */

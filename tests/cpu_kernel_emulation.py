@@ -429,15 +429,20 @@ def bloom_block_fwd(x2, params, mask, slopes, eps, post_ln_res, B, S, nh, flags=
     hd = H // nh
     cd = x2.dtype
     ln1, mean1, rstd1 = layernorm_fwd(x2, ln1_w, ln1_b, eps)
-    qkv = gemm(ln1, H, False, wqkv, H, False, T, 3 * H, H, bias=bqkv)
+    def lin(x, w, N, Kd, **kw):                            # flags & 4: the weight is stored [in, out] (Conv1D) and read K-major
+        if flags & 4:
+            return gemm(x, Kd, False, w, N, True, T, N, Kd, **kw)
+        return gemm(x, Kd, False, w, Kd, False, T, N, Kd, **kw)
+
+    qkv = lin(ln1, wqkv, 3 * H, H, bias=bqkv)
     desc, part = _block_desc(B, S, nh, hd, flags, attn_scale, future_fill)
     att = torch.empty((T, H), dtype=cd, device=x2.device)
     stat_m, stat_l = attn_fwd(qkv, qkv[:, part:], qkv[:, 2 * part:], att, desc, slopes, mask)
-    h1 = gemm(att, H, False, wd, H, False, T, H, H, bias=bd, residual=ln1 if post_ln_res else x2)
+    h1 = lin(att, wd, H, H, bias=bd, residual=ln1 if post_ln_res else x2)
     ln2, mean2, rstd2 = layernorm_fwd(h1, ln2_w, ln2_b, eps)
     u = torch.empty((T, 4 * H), dtype=cd, device=x2.device)
-    g = gemm(ln2, H, False, w1, H, False, T, 4 * H, H, bias=b1, epilogue=1, aux_out=u)
-    out = gemm(g, 4 * H, False, w2, 4 * H, False, T, H, 4 * H, bias=b2, residual=ln2 if post_ln_res else h1)
+    g = lin(ln2, w1, 4 * H, H, bias=b1, epilogue=1, aux_out=u)
+    out = lin(g, w2, H, 4 * H, bias=b2, residual=ln2 if post_ln_res else h1)
     return BlockActs(B=B, S=S, H=H, nh=nh, dtype=cd, desc=desc, part=part, flags=flags, ln1=ln1, mean1=mean1, rstd1=rstd1, qkv=qkv, att=att, stat_m=stat_m,
                      stat_l=stat_l, h1=h1, mean2=mean2, rstd2=rstd2, ln2=ln2, u=u, g=g, out=out)
 
@@ -452,6 +457,8 @@ def bloom_block_bwd(a, x2, params, mask, slopes, eps, post_ln_res, dout2, use_si
     post = post_ln_res
 
     def dgrad(dy, w, **kw):
+        if a.flags & 4:                                    # w is [in, out]: the row-major B operand of dx = dy w^T
+            return gemm(dy, dy.shape[1], False, w, w.shape[1], False, T, w.shape[0], dy.shape[1], **kw)
         return gemm(dy, dy.shape[1], False, w, w.shape[1], True, T, w.shape[1], dy.shape[1], **kw)
 
     def wgrad(dy, x):

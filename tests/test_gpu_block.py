@@ -216,6 +216,42 @@ def test_block_one_call_equals_per_op_sequence(dtype, post, B, S, H, nh):
         assert torch.equal(a, b)                                                # one stream or two: same bits
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,S,H,nh", [(2, 16, 64, 8), (2, 96, 256, 4), (2, 256, 1024, 16)])
+def test_block_gpt2_spelling_with_in_out_weights(dtype, B, S, H, nh):
+    """The GPT-2 flags of the block-level call (blocked q | k | v, -1e4 fill, [in,out] weight gradients) with the weights passed in
+    Conv1D's own [in,out] layout (CTMI_BLK_W_IN_OUT: forward GEMMs read them K-major, data gradients as the row-major operand)
+    against (a) the same call on [out,in] copies of the same values and (b) the per-op kernel sequence."""
+    o, L = ops(), lib()
+    x, dout, params, mask, _, _, _ = _block_inputs(B, S, H, nh, dtype, seed=4242 + S + H, pad="left")
+    eps, scale = 1e-5, 1.0 / math.sqrt(H // nh)
+    names = L.BLK_PARAMS
+    p_io = tuple(p.t().contiguous() if n in ("wqkv", "wd", "w1", "w2") else p for n, p in zip(names, params))
+    f_oi, f_io = L.BLK_QKV_BLOCKED | L.BLK_WGRAD_IN_OUT, L.BLK_QKV_BLOCKED | L.BLK_WGRAD_IN_OUT | L.BLK_W_IN_OUT
+    a_oi = o.bloom_block_fwd(x, params, mask, None, eps, False, B, S, nh, flags=f_oi, attn_scale=scale, future_fill=-1e4)
+    a_io = o.bloom_block_fwd(x, p_io, mask, None, eps, False, B, S, nh, flags=f_io, attn_scale=scale, future_fill=-1e4)
+    ref = EMU.bloom_block_fwd(x, p_io, mask, None, eps, False, B, S, nh, flags=f_io, attn_scale=scale, future_fill=-1e4, K=o)
+    T = B * S
+    rt = 2e-5 if dtype == torch.float32 else 2e-2
+    for slot, cols in (("qkv", 3 * H), ("att", H), ("h1", H), ("u", 4 * H), ("g", 4 * H), ("out", H)):
+        assert torch.equal(a_io.view(slot, T, cols), getattr(ref, slot)), slot                 # same kernels, one call or many
+        assert relerr(a_io.view(slot, T, cols), a_oi.view(slot, T, cols)) < rt, slot           # other operand layout, same math
+    dx_oi, g_oi = o.bloom_block_bwd(a_oi, x, params, mask, None, eps, False, dout)
+    dx_io, g_io = o.bloom_block_bwd(a_io, x, p_io, mask, None, eps, False, dout)
+    dx_ref, g_ref = EMU.bloom_block_bwd(ref, x, p_io, mask, None, eps, False, dout, K=o)
+    torch.cuda.synchronize()
+    assert relerr(dx_io, dx_oi) < rt and relerr(dx_io, dx_ref) < rt
+    for n, a, b, c in zip(names, g_io, g_oi, g_ref):
+        assert a.shape == b.shape == c.shape, n
+        if n in ("bd", "b2", "bqkv"):
+            sc = float(c.abs().max()) + 1e-30
+            assert float((a - c).abs().max()) <= rt * sc * math.sqrt(T) and float((a - b).abs().max()) <= rt * sc * math.sqrt(T), n
+        else:
+            assert relerr(a, b) < rt and relerr(a, c) < rt, n
+        if n in ("wqkv", "wd", "w1", "w2"):
+            assert a.shape == p_io[names.index(n)].shape, n                                      # [in, out], the parameter's layout
+
+
 @pytest.mark.parametrize("post", [False, True])
 def test_block_fp32_matches_oracle(post):
     """fp32: the one-call block against the CPU oracle's block (north-star bar 1e-4; achieved ~1e-6)."""
