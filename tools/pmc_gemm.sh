@@ -16,7 +16,7 @@ acc = collections.defaultdict(list)
 dur = []
 for f in glob.glob("gpurun_out/pmc_gemm/g*/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if r["Kernel_Name"].startswith("void gemm_glds_kernel<unsigned short, false, false, 0, 8, 4, true, false>"):
+        if r["Kernel_Name"].startswith("void gemm_glds_kernel<unsigned short, false, false, 0, 8, 4, true, false, false>"):
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
             dur.append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
 a = {k: sum(v) / len(v) for k, v in acc.items()}

@@ -9,7 +9,7 @@ import os
 import sys
 
 src, dst, rnd = sys.argv[1], sys.argv[2], sys.argv[3]
-LM = "gemm_glds_kernel<unsigned short, false, false, 0, 8, 4, true, false>"     # bf16 NT, no epilogue, 256x256 ping-pong
+LM = "gemm_glds_kernel<unsigned short, false, false, 0, 8, 4, true, false, false>"     # bf16 NT, no epilogue, 256x256 ping-pong, LDS-patch epilogue
 
 
 def one(pattern):
