@@ -250,6 +250,14 @@ def test_block_gpt2_spelling_with_in_out_weights(dtype, B, S, H, nh):
             assert relerr(a, b) < rt and relerr(a, c) < rt, n
         if n in ("wqkv", "wd", "w1", "w2"):
             assert a.shape == p_io[names.index(n)].shape, n                                      # [in, out], the parameter's layout
+    # [in,out] weights with [out,in] gradients (the fourth flag combination): the same numbers, transposed
+    a_x = o.bloom_block_fwd(x, p_io, mask, None, eps, False, B, S, nh, flags=L.BLK_QKV_BLOCKED | L.BLK_W_IN_OUT, attn_scale=scale, future_fill=-1e4)
+    dx_x, g_x = o.bloom_block_bwd(a_x, x, p_io, mask, None, eps, False, dout)
+    torch.cuda.synchronize()
+    assert torch.equal(a_x.out, a_io.out) and relerr(dx_x, dx_io) < rt
+    for n, a, b in zip(names, g_x, g_io):
+        if n in ("wqkv", "wd", "w1", "w2"):
+            assert a.shape == tuple(reversed(b.shape)) and relerr(a, b.t()) < rt, n
 
 
 @pytest.mark.parametrize("post", [False, True])
