@@ -15,6 +15,12 @@
 #include <type_traits>
 
 // A/B knobs for tools/ variant builds (defaults = the adopted configuration)
+#ifndef CTMI_ATTN_SADDR
+#define CTMI_ATTN_SADDR 1        // FAST kernels: stream the K/V tiles through a scalar tile origin + constant per-lane offsets (same-box A/B: forward 281 -> 285-289 TF/s, backward 267 -> 272)
+#endif
+#ifndef CTMI_ATTN_SADDR_DKDV
+#define CTMI_ATTN_SADDR_DKDV 0
+#endif
 #ifndef CTMI_ATTN_FASTBODY
 #define CTMI_ATTN_FASTBODY 1     // backward kernels: mask-free loop body for tiles that cannot contain a masked score (A/B: slower while it costs a wave per SIMD: 207 VGPRs)
 #endif
@@ -147,6 +153,34 @@ struct AT {
         }
 #pragma unroll
         for (int i = 0; i < NCH; ++i) ptrs[i] += 64 * rs;
+    }
+    // Offset form of the same stream (CTMI_ATTN_SADDR): the tile origin is wave-uniform, so it lives in SGPRs (advanced by scalar
+    // adds) and each lane keeps only a constant 32-bit byte offset — the loads become `global_load_dwordx4 v, v_off, s[base:base+1]`
+    // and the NCH 64-bit VALU pointer bumps (+ the pointer copies hipcc made in front of every load) per tile and operand disappear.
+    static __device__ __forceinline__ void stream_init_off(uint32_t (&offs)[NCH], int64_t rs, int tid) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int id = tid + 256 * i;
+            offs[i] = (uint32_t)(((int64_t)(id / CPR) * rs + (id % CPR) * VEC) * (int64_t)sizeof(T));
+        }
+    }
+    static __device__ __forceinline__ void stream_load_off(u32x4 (&regs)[NCH], const uint32_t (&offs)[NCH], const T* __restrict__ base, int64_t rs,
+                                                           int64_t row0, int64_t nrows, int tid) {
+        // base + row0 * rs: scalar arithmetic (all wave-uniform)
+        const char* origin = reinterpret_cast<const char*>(base + row0 * rs);
+        uint32_t o[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) o[i] = offs[i];
+        if (row0 + 64 > nrows) {                                             // the one tile that crosses the end: rows clamped to the last one
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int id = tid + 256 * i;
+                const int64_t r = min((int64_t)(id / CPR), nrows - 1 - row0);
+                o[i] = (uint32_t)((r * rs + (id % CPR) * VEC) * (int64_t)sizeof(T));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) regs[i] = ldg_as1<u32x4>(origin + o[i]);
     }
     static __device__ __forceinline__ void store_rm(const u32x4 (&regs)[NCH], T* __restrict__ tile, int tid) {
 #pragma unroll
@@ -418,8 +452,10 @@ __global__ __launch_bounds__(256, CTMI_ATTN_MINW) void attn_fwd_kernel(AttnP p) 
     A::load(rv, vp, p.v_rs, 0, p.Sk, hd_, fast, tid);
     const T* pk[A::NCH];
     const T* pv[A::NCH];
-    A::stream_init(pk, kp, p.k_rs, 64, tid);
-    A::stream_init(pv, vp, p.v_rs, 64, tid);
+    uint32_t ok[A::NCH], ov[A::NCH];
+    constexpr bool SADDR = CTMI_ATTN_SADDR && FAST;
+    if constexpr (SADDR) { A::stream_init_off(ok, p.k_rs, tid); A::stream_init_off(ov, p.v_rs, tid); }
+    else { A::stream_init(pk, kp, p.k_rs, 64, tid); A::stream_init(pv, vp, p.v_rs, 64, tid); }
     if (tid < 64) rkb = key_bias(p, b, tid, slope);
     A::store_rm(rk, KS(0), tid);
     A::store_rm(rv, VS(0), tid);
@@ -431,8 +467,13 @@ __global__ __launch_bounds__(256, CTMI_ATTN_MINW) void attn_fwd_kernel(AttnP p) 
     for (int t = 0; t < ntiles; ++t) {
         if (t + 1 < ntiles && !(ATTN_DBG(p) & 1)) {
             if (tid < 64) kbr.load(p, b, (int64_t)(t + 1) * 64 + tid);
-            A::stream_load(rk, pk, kp, p.k_rs, (int64_t)(t + 1) * 64, p.Sk, hd_, fast, tid);
-            A::stream_load(rv, pv, vp, p.v_rs, (int64_t)(t + 1) * 64, p.Sk, hd_, fast, tid);
+            if constexpr (SADDR) {
+                A::stream_load_off(rk, ok, kp, p.k_rs, (int64_t)(t + 1) * 64, p.Sk, tid);
+                A::stream_load_off(rv, ov, vp, p.v_rs, (int64_t)(t + 1) * 64, p.Sk, tid);
+            } else {
+                A::stream_load(rk, pk, kp, p.k_rs, (int64_t)(t + 1) * 64, p.Sk, hd_, fast, tid);
+                A::stream_load(rv, pv, vp, p.v_rs, (int64_t)(t + 1) * 64, p.Sk, hd_, fast, tid);
+            }
         }
         f32x4 x[4];
         const float* kbs = KB(cur);
@@ -593,11 +634,13 @@ __global__ __launch_bounds__(256, CTMI_ATTN_MINW) void attn_bwd_dkdv_kernel(Attn
     };
     const T* pq[A::NCH];
     const T* pg[A::NCH];
+    uint32_t oq[A::NCH], og[A::NCH];
+    constexpr bool SADDR = CTMI_ATTN_SADDR_DKDV && FAST;          // (off: with it hipcc allocates 170 instead of 163 VGPRs here — the third wave per SIMD)
     if (qt_begin < qt_end) {
         A::load(rq, qp, p.q_rs, (int64_t)qt_begin * 64, p.Sq, hd_, fast, tid);
         A::load(rg, gp, p.o_rs, (int64_t)qt_begin * 64, p.Sq, hd_, fast, tid);
-        A::stream_init(pq, qp, p.q_rs, (int64_t)(qt_begin + 1) * 64, tid);
-        A::stream_init(pg, gp, p.o_rs, (int64_t)(qt_begin + 1) * 64, tid);
+        if constexpr (SADDR) { A::stream_init_off(oq, p.q_rs, tid); A::stream_init_off(og, p.o_rs, tid); }
+        else { A::stream_init(pq, qp, p.q_rs, (int64_t)(qt_begin + 1) * 64, tid); A::stream_init(pg, gp, p.o_rs, (int64_t)(qt_begin + 1) * 64, tid); }
         load_stats(qt_begin);
         A::store_rm(rq, QS(0), tid);
         A::store_rm(rg, GS(0), tid);
@@ -615,8 +658,13 @@ __global__ __launch_bounds__(256, CTMI_ATTN_MINW) void attn_bwd_dkdv_kernel(Attn
         constexpr bool MASKED = decltype(masked_c)::value;
         if (t + 1 < qt_end && !(ATTN_DBG(p) & 1)) {
             load_stats(t + 1);
-            A::stream_load(rq, pq, qp, p.q_rs, (int64_t)(t + 1) * 64, p.Sq, hd_, fast, tid);
-            A::stream_load(rg, pg, gp, p.o_rs, (int64_t)(t + 1) * 64, p.Sq, hd_, fast, tid);
+            if constexpr (SADDR) {
+                A::stream_load_off(rq, oq, qp, p.q_rs, (int64_t)(t + 1) * 64, p.Sq, tid);
+                A::stream_load_off(rg, og, gp, p.o_rs, (int64_t)(t + 1) * 64, p.Sq, tid);
+            } else {
+                A::stream_load(rq, pq, qp, p.q_rs, (int64_t)(t + 1) * 64, p.Sq, hd_, fast, tid);
+                A::stream_load(rg, pg, gp, p.o_rs, (int64_t)(t + 1) * 64, p.Sq, hd_, fast, tid);
+            }
         }
         f32x4 x[4], y[4];
         const float* st = ST(cur);
@@ -782,8 +830,10 @@ __global__ __launch_bounds__(256, CTMI_ATTN_MINW) void attn_bwd_dq_kernel(AttnP 
     A::load(rv, vp, p.v_rs, 0, p.Sk, hd_, fast, tid);
     const T* pk[A::NCH];
     const T* pv[A::NCH];
-    A::stream_init(pk, kp, p.k_rs, 64, tid);
-    A::stream_init(pv, vp, p.v_rs, 64, tid);
+    uint32_t ok[A::NCH], ov[A::NCH];
+    constexpr bool SADDR = CTMI_ATTN_SADDR && FAST;
+    if constexpr (SADDR) { A::stream_init_off(ok, p.k_rs, tid); A::stream_init_off(ov, p.v_rs, tid); }
+    else { A::stream_init(pk, kp, p.k_rs, 64, tid); A::stream_init(pv, vp, p.v_rs, 64, tid); }
     if (tid < 64) rkb = key_bias(p, b, tid, slope);
     A::store_rm(rk, KS(0), tid);
     A::store_rm(rv, VS(0), tid);
@@ -799,8 +849,13 @@ __global__ __launch_bounds__(256, CTMI_ATTN_MINW) void attn_bwd_dq_kernel(AttnP 
         constexpr bool MASKED = decltype(masked_c)::value;
         if (t + 1 < ntiles && !(ATTN_DBG(p) & 1)) {
             if (tid < 64) kbr.load(p, b, (int64_t)(t + 1) * 64 + tid);
-            A::stream_load(rk, pk, kp, p.k_rs, (int64_t)(t + 1) * 64, p.Sk, hd_, fast, tid);
-            A::stream_load(rv, pv, vp, p.v_rs, (int64_t)(t + 1) * 64, p.Sk, hd_, fast, tid);
+            if constexpr (SADDR) {
+                A::stream_load_off(rk, ok, kp, p.k_rs, (int64_t)(t + 1) * 64, p.Sk, tid);
+                A::stream_load_off(rv, ov, vp, p.v_rs, (int64_t)(t + 1) * 64, p.Sk, tid);
+            } else {
+                A::stream_load(rk, pk, kp, p.k_rs, (int64_t)(t + 1) * 64, p.Sk, hd_, fast, tid);
+                A::stream_load(rv, pv, vp, p.v_rs, (int64_t)(t + 1) * 64, p.Sk, hd_, fast, tid);
+            }
         }
         f32x4 x[4], y[4];
         const float* kbs = KB(cur);
