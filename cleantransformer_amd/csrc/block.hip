@@ -239,6 +239,9 @@ extern "C" int ctmi_bloom_block_bwd(const ctmi_bloom_block* b, const ctmi_bloom_
     };
 
     const void* dout = gr->dout;
+    // The launches run inside a lambda so that a failure half-way still reaches the join below: the side stream may already hold
+    // work that reads the caller's buffers, and the caller (who frees them on error) only orders against the main stream.
+    const int rc_launch = [&]() -> int {
     // ---- MLP: out = res2 + W2 gelu(W1 ln2 + b1) + b2
     RC(fork());
     RC(linear_wgrad(dout, s.at(CTMI_BLK_G), gr->dw2, T, H, 4 * H, dt, pws, pws_bytes, pst, wio));
@@ -275,12 +278,17 @@ extern "C" int ctmi_bloom_block_bwd(const ctmi_bloom_block* b, const ctmi_bloom_
                                   post ? nullptr : W(W_DH1), gr->dx, WF(W_LNP1), T, H, dt, 0, &np1, &ns1, main_st));
     job(WF(W_LNP1), ns1 * H, np1, gr->dln1_w, H);
     job(WF(W_LNP1) + H, ns1 * H, np1, gr->dln1_b, H);
-    // ---- join: everything downstream (autograd accumulation, hooks, optimizer) is ordered on the main stream
+    return CTMI_OK;
+    }();
+    // ---- join (also after a failed launch): everything downstream (autograd accumulation, hooks, optimizer, the caller's frees)
+    // is ordered on the main stream
     if (two) {
         hipEvent_t ev = next_event();
-        CTMI_HIP_OK(hipEventRecord(ev, side), "bloom_block_bwd: event record");
-        CTMI_HIP_OK(hipStreamWaitEvent(main_st, ev, 0), "bloom_block_bwd: stream wait");
+        const hipError_t e1 = hipEventRecord(ev, side);
+        const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(main_st, ev, 0) : e1;
+        if (e2 != hipSuccess && rc_launch == CTMI_OK) { ctmi_set_error("bloom_block_bwd: joining the side stream: %s", hipGetErrorString(e2)); return CTMI_ERR_LAUNCH; }
     }
+    RC(rc_launch);
     RC(ctmi_reduce_jobs(jobs, nj, main_st));
     return CTMI_OK;
 }
