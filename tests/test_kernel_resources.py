@@ -1,0 +1,69 @@
+"""Register budgets of the kernels on the measured path, read from the built library's code-object metadata (no GPU needed).
+
+Several results in DESIGN.md hinge on occupancy: the attention kernels run three waves per SIMD only up to 168 VGPRs (the mask-free
+backward body and the scalar-origin tile loads were adopted / rejected per kernel on exactly that), the ping-pong GEMM tiles need
+two waves per SIMD (<= 256), the 128 x 128 GEMM tile three.  A change that silently costs a wave, or a kernel whose accumulators
+start spilling (the rejected 128 x 128-wave-tile GEMM: 350 - 480 spilled VGPRs), shows up here on the CPU box at build time.
+"""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import kernel_resources as KR  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    from cleantransformer_amd import _lib
+    if not KR.have_tools():
+        pytest.skip("llvm-objdump / llvm-readelf / c++filt not available")
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libctmi355.so not built")
+    return KR.read(_lib.LIB_PATH)
+
+
+def pick(kernels, prefix):
+    out = {n: k for n, k in kernels.items() if n.startswith(prefix)}
+    assert out, f"no kernel named {prefix}..."
+    return out
+
+
+@pytest.mark.parametrize("kernel", ["attn_fwd_kernel", "attn_bwd_dq_kernel", "attn_bwd_dkdv_kernel"])
+def test_attention_training_kernels_keep_three_waves_per_simd(kernels, kernel):
+    # bf16, head_dim 64, no additive mask, FAST (aligned) instantiation, no dropout: what Bloom-560M / GPT-2-medium training launches
+    (name, k), = pick(kernels, f"void {kernel}<unsigned short, 64, false, true, false>").items()
+    assert k["vgpr_count"] <= 168, (name, k["vgpr_count"])
+    assert k["vgpr_spill_count"] == 0, (name, k["vgpr_spill_count"])
+
+
+def test_attention_head_dim_128_fast_kernels_do_not_spill(kernels):
+    for kernel in ("attn_fwd_kernel", "attn_bwd_dq_kernel", "attn_bwd_dkdv_kernel"):
+        (name, k), = pick(kernels, f"void {kernel}<unsigned short, 128, false, true, false>").items()
+        assert k["vgpr_count"] <= 256 and k["vgpr_spill_count"] == 0, (name, k)
+
+
+def test_gemm_kernels_fit_their_occupancy(kernels):
+    gemms = pick(kernels, "void gemm_glds_kernel<")
+    for name, k in gemms.items():
+        assert k["vgpr_count"] <= 256, (name, k["vgpr_count"])                 # two waves per SIMD (eight-wave tiles: one workgroup per CU)
+        assert k["agpr_count"] == 0, (name, k["agpr_count"])
+        assert k["vgpr_spill_count"] <= 32, (name, k["vgpr_spill_count"])     # (today: 0 in every K-loop; up to 28 in the 256-row tile's epilogues)
+    # the 128 x 128 free-running tile: three workgroups per CU
+    for name, k in gemms.items():
+        if ", 4, 2, false, false, false>" in name:
+            assert k["vgpr_count"] <= 168 and k["vgpr_spill_count"] == 0, (name, k)
+    # the roofline kernel of bench.py (LM-head forward) and the two epilogue choices of the 256-row tile
+    (name, k), = pick(kernels, "void gemm_glds_kernel<unsigned short, false, false, 0, 8, 4, true, false, false>").items()
+    assert k["vgpr_spill_count"] == 0, (name, k)
+    (name, k), = pick(kernels, "void gemm_glds_kernel<unsigned short, false, false, 0, 8, 4, true, false, true>").items()
+    assert k["vgpr_spill_count"] == 0, (name, k)
+
+
+def test_streaming_kernels_do_not_spill(kernels):
+    for prefix in ("void ce_fused_k<unsigned short>", "adamw_mt_k", "void ln_fwd_vec<unsigned short", "void ln_bwd_vec<unsigned short",
+                   "reduce_jobs_k", "void colsum_part<unsigned short>", "void embed_bwd_k<unsigned short>"):
+        for name, k in pick(kernels, prefix).items():
+            assert k["vgpr_spill_count"] == 0 and k.get("private_segment_fixed_size", 0) == 0, (name, k)
