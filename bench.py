@@ -11,7 +11,6 @@ before the timed region.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time

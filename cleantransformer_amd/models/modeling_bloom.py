@@ -16,13 +16,13 @@ lazily when a parameter's version counter moves).  Parameter gradients are alway
 from __future__ import annotations
 
 import math
-from typing import List, Optional
+from typing import Optional
 
 import torch
 
 from .. import _lib, ops
 from ..generation.generation_util import GenerationMixin
-from ..transformer import LayerNorm, LayerNormFn
+from ..transformer import LayerNorm
 
 Tensor = torch.Tensor
 

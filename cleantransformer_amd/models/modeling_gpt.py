@@ -29,7 +29,7 @@ import torch
 
 from .. import _lib, ops, rng
 from ..generation.generation_util import GenerationMixin
-from ..transformer import LayerNorm, LayerNormFn
+from ..transformer import LayerNorm
 from .modeling_bloom import EmbedFn, LMHeadFn, ShiftedCrossEntropyFn, _TieCtx, _torch_dtype
 
 Tensor = torch.Tensor

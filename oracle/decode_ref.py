@@ -12,7 +12,7 @@ restated: sampled ids depend on the RNG stream.
 """
 from __future__ import annotations
 
-from typing import Callable, List, Optional, Sequence
+from typing import Callable, Optional, Sequence
 
 import torch
 

@@ -7,7 +7,6 @@
     1/(1-p) scale, mask on the normalised attention probabilities, mask reused by the backward), seeds drawn from torch's CPU
     generator (reproducible under torch.manual_seed, like the reference's modules)."""
 import math
-import os
 
 import numpy as np
 import pytest

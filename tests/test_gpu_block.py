@@ -6,9 +6,7 @@ Tolerances: fp32 <= 1e-4 relative (north star); results that come out of the SAM
 dx, weight gradients, LayerNorm affine gradients) must be bit-identical between the one-call and the per-op form; the bias
 gradients that moved into the LayerNorm backward are summed in a different order and are compared with a summation-sized
 tolerance."""
-import ctypes as C
 import math
-import os
 
 import pytest
 import torch

@@ -5,7 +5,6 @@ explicit-mask computation to rounding — not only through statistical propertie
 stream (torch.nn.Dropout), which no other implementation can reproduce; what is pinned to the reference is the semantics: Bernoulli(1-p)
 keep, 1/(1-p) scaling, mask on the NORMALISED attention probabilities, same mask in forward and backward."""
 import math
-import os
 
 import pytest
 import torch
