@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("CTMI_LIB_PATH") or _DEFAULT_LIB_PATH
 F32, BF16 = 0, 1
 EPI_NONE, EPI_GELU, EPI_DGELU, EPI_RELU, EPI_DRELU, EPI_GELUG, EPI_MUL = 0, 1, 2, 3, 4, 5, 6
 MT_MAX = 24
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 
@@ -71,6 +71,7 @@ PROTOTYPES = {
     "ctmi_colsum_ws": (i64, [i64, i64]),
     "ctmi_attn_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(AttnDesc), i32, vp]),
     "ctmi_attn_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(AttnDesc), i32, vp]),
+    "ctmi_attn_set_path": (i32, [i32]),
     "ctmi_mask_prep": (i32, [vp, vp, vp, vp, i64, i64, vp]),
     "ctmi_embed_fwd": (i32, [vp, vp, vp, i64, i64, i64, i32, vp, vp]),
     "ctmi_embed_bwd": (i32, [vp, vp, vp, i64, i64, i64, i32, f32, vp]),

@@ -42,22 +42,7 @@
 #else
 #define ATTN_DBG(p) 0
 #endif
-struct AttnP {
-    const void *q, *k, *v, *o, *d_o;
-    void *out, *dq, *dk, *dv;
-    float *stat_m, *stat_l, *delta;
-    const float *slopes, *kpos, *add_mask;
-    const int32_t *kvalid, *first_valid;
-    int64_t B, nh, Sq, Sk, hd;
-    int64_t q_bs, q_hs, q_rs, k_bs, k_hs, k_rs, v_bs, v_hs, v_rs, o_bs, o_hs, o_rs;
-    int64_t am_b, am_h, am_q, am_k;
-    float scale;
-    uint32_t drop_thr, drop_seed;  // attention-probability dropout: keep(b,h,q,k) = hash32(counter ^ seed) >= thr (0 = off)
-    float drop_scale;        // 1 / (1 - p)
-    float future_fill;       // score of a (query, key) pair in the causal future whose key may be attended: FINFO_MIN (Bloom masked_fill) or GPT's -1e4
-    int causal, off, vec_ok;
-    int dbg;                 // timing experiments only (CTMI_ATTN_DBG): 1 = no steady-state global loads, 2 = no LDS restage
-};
+#include "attn_params.h"
 
 // 64 x HDP tile staging helpers (256 threads).  Thread -> (row = id / CPR, 16-byte chunk = id % CPR): the CPR lanes of
 // one row read one contiguous run of HBM (coalesced: a head row of hd=64 bf16 is exactly one 128-byte line) and write one
@@ -1012,6 +997,7 @@ extern "C" int ctmi_attn_fwd(const void* q, const void* k, const void* v, void* 
     if (rc != CTMI_OK) return rc;
     hipStream_t st = as_stream(stream);
     if (dtype == CTMI_F32) return HDP_DISPATCH(fwd_launch, float);
+    if (ctmi_attn32_fwd(p, st)) { CTMI_CHECK_LAUNCH("attn32_fwd"); return CTMI_OK; }   // training shapes: attention_w32.hip
     return HDP_DISPATCH(fwd_launch, bf16_t);
 }
 
@@ -1030,5 +1016,6 @@ extern "C" int ctmi_attn_bwd(const void* q, const void* k, const void* v, const 
     if (rc != CTMI_OK) return rc;
     hipStream_t st = as_stream(stream);
     if (dtype == CTMI_F32) return HDP_DISPATCH(bwd_launch, float);
+    if (ctmi_attn32_bwd(p, st)) { CTMI_CHECK_LAUNCH("attn32_bwd"); return CTMI_OK; }   // training shapes: attention_w32.hip
     return HDP_DISPATCH(bwd_launch, bf16_t);
 }

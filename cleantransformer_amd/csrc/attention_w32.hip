@@ -1,0 +1,662 @@
+// Fast path of the fused attention for the TRAINING shapes (bf16, causal, Sq == Sk a multiple of 64, head_dim 64 or 128, no
+// additive mask, no probability dropout): same contract and same numerics policy as attention.hip (which keeps every other
+// case), re-tiled for matrix density.
+//   reference: modeling_bloom.py:84-116 (BloomAttentionLayer core: baddbmm(alibi, q, k^T, alpha = 1/sqrt(hd)) -> masked_fill(finfo.min)
+//              -> fp32 softmax -> bmm with v), modeling_gpt.py:76-101 (the same with the -1e4 causal replacement)
+//
+// Why a second set of kernels.  attention.hip gives each wave 16 own rows and a 64-row workgroup one K/V stage: 16 MFMAs
+// (16x16x32) per ~160 VALU + ~60 SALU instructions and one LDS restage per 64 rows — measured 17 % matrix-pipe busy.  Here
+//   * a workgroup owns 256 rows (8 waves x 32) — or 128 (4 waves) where 32 own rows need > 256 registers — and ONE K/V (or
+//     Q/dO) stage feeds all of them: 4x less staging traffic per flop, and the stage arrives by LDS-DMA
+//     (global_load_lds_dwordx4, 1 KiB per wave-instruction) into a 3-deep ring — no staging registers, no ds_write, one
+//     s_barrier per tile, counted vmcnt;
+//   * v_mfma_f32_32x32x16_bf16 with the wave's own row in the accumulator COLUMN (lane & 31): a lane owns one query (or
+//     key) row, softmax statistics are per-lane scalars, and a row's 32 scores of a key block sit in just two lanes
+//     (l, l + 32), so the row max / sum cross lanes once per tile (v_permlane32_swap);
+//   * the probabilities leave the first MFMA already in the B-operand layout of the second one: the k-slot <-> key
+//     assignment of the second contraction is CHOSEN to be the accumulator's (keys (r&3) + 8*(r>>2) + 4*(lane>>5)), and the
+//     transposed A operand (V^T, K^T, Q^T, dO^T) is gathered to match with ds_read_b64_tr_b16 from the same row-major tile;
+//   * LDS tiles are lane-linear DMA images; bank conflicts are removed by XOR-ing the 16-byte chunk index with row bits
+//     (on the SOURCE address of the DMA and on every fragment read), one permutation that is conflict-free for both the
+//     ds_read_b128 row fragments and the transposed reads;
+//   * softmax in the log2 domain (scale * log2(e) folded into the score FMA, exp2 directly), per-key bias
+//     (ALiBi slope * position, finfo.min for padding keys) precomputed once per workgroup into LDS;
+//   * causal work balance: query blocks are issued longest-first (LPT), and inside a workgroup the two waves that share a
+//     SIMD own row blocks (i, 7 - i), so every SIMD sees the same number of un-skipped diagonal tiles.
+// Masked scores take finfo.min exactly like the reference's masked_fill (all-masked rows become uniform over ALL keys);
+// row statistics are published in natural units (m, l) exactly as attention.hip does, so forward / backward kernels of the
+// two files can be mixed.
+#include "common.h"
+#include "attn_params.h"
+#include <stdlib.h>
+#include <atomic>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8_w32 __attribute__((ext_vector_type(8)));
+typedef short short4_w32 __attribute__((ext_vector_type(4)));
+
+#define LOG2E_F 1.4426950408889634f
+#define LN2_F 0.6931471805599453f
+
+namespace {
+
+__device__ __forceinline__ f32x16 mfma32(short8 a, short8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_w32, a), __builtin_bit_cast(bf16x8_w32, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ float max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// value of the partner lane (l ^ 32) combined with the own one: v_permlane32_swap exchanges the upper 32 lanes of its first
+// operand with the lower 32 of its second, so with both operands = v every lane ends up holding {own, partner} in {a, b}
+// (lower half) or {partner, own} (upper half)
+__device__ __forceinline__ float pair_max(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return max3(a, a, b);
+}
+__device__ __forceinline__ float pair_sum(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst /* wave-uniform LDS byte address */) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vm() {
+    static_assert(N == 0 || N == 2 || N == 4 || N == 8, "counted waits are spelled out");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
+template <typename V> __device__ __forceinline__ V ldg1(const void* p) {
+    typedef const __attribute__((address_space(1))) V* gptr;
+    return *(gptr)(p);
+}
+__device__ __forceinline__ uint2 lds_tr16(const unsigned char* p) {
+    typedef __attribute__((address_space(3))) short4_w32 lds_v4;
+    return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(unsigned)(size_t)p));
+}
+__device__ __forceinline__ short8 pack8(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
+    return __builtin_bit_cast(short8, make_uint4(pack_bf2(a0, a1), pack_bf2(a2, a3), pack_bf2(a4, a5), pack_bf2(a6, a7)));
+}
+
+// One streamed operand tile: 64 rows x HD bf16, row-major, rows of ROWB bytes = CPR 16-byte chunks, chunk c of row r stored at
+// chunk position c ^ g(r).
+//   ds_read_b128 row fragments (32 consecutive rows, one logical chunk): the hardware serves a wave in 16-lane groups
+//   {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} (+32); g must send the 16 rows of a group to 16 distinct 16-byte slots of the
+//   256-byte bank row.  HD = 64 (128-byte rows, two rows per bank row): g = bits 1..3 of r, permuted; HD = 128: g = bits 0..3.
+//   ds_read_b64_tr_b16 (32 lanes: 4 consecutive rows x 64 contiguous bytes): the 4 rows must land in 4 different 64-byte
+//   quarters of the bank row: HD = 64: row bit 0 picks the half of the bank row, row bit 1 must flip chunk bit 2;
+//   HD = 128: row bits 0..1 must drive chunk bits 2..3.  Both g below satisfy both.
+template <int HD, int NW>
+struct WT {
+    static constexpr int ROWB = HD * 2, CPR = HD / 8, TILE = 64 * ROWB;
+    static constexpr int NPC = TILE / 1024 / NW;                       // DMA wave-instructions per wave and operand tile
+    static_assert(NPC * NW * 1024 == TILE, "tile must split into 1-KiB pieces over the waves");
+    static __device__ __forceinline__ int g(int r) {
+        return HD == 64 ? ((((r >> 1) & 1) << 2) | ((r >> 2) & 3)) : (((r & 3) << 2) | ((r >> 2) & 3));
+    }
+    static __device__ __forceinline__ int off(int r, int c) { return r * ROWB + ((c ^ g(r)) << 4); }
+    // global source of this lane's 16 bytes of DMA piece j of wave `wid` (row0 = first row of the tile NOT included)
+    static __device__ __forceinline__ const bf16_t* src(const bf16_t* base, int64_t rs, int wid, int j, int lane) {
+        const int P = (wid * NPC + j) * 64 + lane;
+        const int row = P / CPR, cph = P % CPR;
+        return base + (int64_t)row * rs + ((cph ^ g(row)) << 3);
+    }
+    // A operand, rows = tile rows: lane (l & 31) = row, k = 8 consecutive head-dim elements of 16-byte chunk `c`
+    static __device__ __forceinline__ short8 fragA(const unsigned char* tile, int row, int c) {
+        return *reinterpret_cast<const short8*>(tile + off(row, c));
+    }
+    // A operand of the TRANSPOSED tile: m = head-dim index db*32 + (l & 31), k-slot (hi = l >> 5, j = 0..7) = tile row
+    // rbase + 4*hi + (j & 3) + 8*(j >> 2) — the accumulator's row order, see the file header.
+    static __device__ __forceinline__ short8 fragT(const unsigned char* tile, int rbase, int db, int lane) {
+        const int i = lane & 15, gi = lane >> 4;
+        const int row = rbase + 4 * (gi >> 1) + (i >> 2);
+        const int c = db * 4 + 2 * (gi & 1) + ((i >> 1) & 1);
+        const int byte = (i & 1) * 8;
+        const uint2 lo = lds_tr16(tile + off(row, c) + byte);
+        const uint2 hi = lds_tr16(tile + off(row + 8, c) + byte);
+        return __builtin_bit_cast(short8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+    }
+};
+
+// row block of wave `wid`: the two waves of a SIMD (w, w + 4) take row blocks (i, 7 - i)
+template <int NW> __device__ __forceinline__ int row_block(int wid) { return NW == 8 ? (wid < 4 ? wid : 11 - wid) : wid; }
+
+// X^T accumulators (acc[db][r] = X[own row = lane & 31][d = db*32 + (r&3) + 8*(r>>2) + 4*(lane>>5)]) -> bf16 rows in HBM, through a
+// wave-private LDS patch so that every store instruction writes whole contiguous row pieces (16 bytes per lane).
+template <int HD>
+__device__ __forceinline__ void store_tile32(const f32x16 (&acc)[HD / 32], float mul, bf16_t* g0, int64_t rs, unsigned char* scr, int lane) {
+    constexpr int PITCH = HD * 2 + 16, CPR = HD / 8;
+    const int l32 = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int db = 0; db < HD / 32; ++db)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint2 pk = make_uint2(pack_bf2(acc[db][4 * j] * mul, acc[db][4 * j + 1] * mul), pack_bf2(acc[db][4 * j + 2] * mul, acc[db][4 * j + 3] * mul));
+            *reinterpret_cast<uint2*>(scr + l32 * PITCH + (db * 32 + 8 * j + 4 * hi) * 2) = pk;
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 32 * CPR / 64; ++it) {
+        const int slot = it * 64 + lane, row = slot / CPR, ch = slot % CPR;
+        const uint4 v = *reinterpret_cast<const uint4*>(scr + row * PITCH + ch * 16);
+        *reinterpret_cast<uint4*>(g0 + (int64_t)row * rs + ch * 8) = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int HD, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void attn32_fwd_kernel(AttnP p) {
+    using W = WT<HD, NW>;
+    constexpr int NDS = HD / 16, NDB = HD / 32, TILE = W::TILE, STAGE = 2 * TILE, NPC = W::NPC, RPB = 32 * NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* kbS = reinterpret_cast<float*>(smem + 3 * STAGE);
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, hi = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rbw = row_block<NW>(wid);
+    const int BH = (int)(p.B * p.nh), nqb = (int)((p.Sq + RPB - 1) / RPB);
+    const int vid = blockIdx.x;
+    const int qb = nqb - 1 - vid / BH, bh = vid % BH;                        // longest query blocks first (LPT)
+    const int64_t h = bh % p.nh, b = bh / p.nh;
+    const int q0 = qb * RPB, q0w = q0 + 32 * rbw;
+    const bool active = q0w < (int)p.Sq;
+    // a query row whose whole causal window is padding sees only masked keys -> uniform over ALL keys
+    const bool allk = p.kvalid != nullptr && p.first_valid[b] > q0;
+    const int kv_end = allk ? (int)p.Sk : min((int)p.Sk, q0 + RPB);
+    const int ntiles = kv_end / 64;
+    const int my_last = allk ? ntiles - 1 : min(ntiles - 1, (q0w + 31) / 64);
+    const bf16_t* qp = reinterpret_cast<const bf16_t*>(p.q) + b * p.q_bs + h * p.q_hs;
+    const bf16_t* kp = reinterpret_cast<const bf16_t*>(p.k) + b * p.k_bs + h * p.k_hs;
+    const bf16_t* vp = reinterpret_cast<const bf16_t*>(p.v) + b * p.v_bs + h * p.v_hs;
+
+    const bf16_t* pk[NPC];
+    const bf16_t* pv[NPC];
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) { pk[j] = W::src(kp, p.k_rs, wid, j, lane); pv[j] = W::src(vp, p.v_rs, wid, j, lane); }
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    const int64_t kstep = 64 * p.k_rs, vstep = 64 * p.v_rs;
+    auto issue = [&](int stage) {
+        const unsigned d = lds0 + stage * STAGE + wid * NPC * 1024;
+#pragma unroll
+        for (int j = 0; j < NPC; ++j) { dma16(pk[j], d + j * 1024); pk[j] += kstep; }
+#pragma unroll
+        for (int j = 0; j < NPC; ++j) { dma16(pv[j], d + TILE + j * 1024); pv[j] += vstep; }
+    };
+    issue(0);
+    if (ntiles > 1) issue(1);
+
+    const float slope2 = p.slopes ? p.slopes[h] * LOG2E_F : 0.f;
+    for (int key = tid; key < kv_end; key += NW * 64) {
+        const int valid = p.kvalid != nullptr ? (int)p.kvalid[b * p.Sk + key] : 1;
+        const float pos = p.kpos != nullptr ? p.kpos[b * p.Sk + key] : 0.f;
+        kbS[key] = valid != 0 ? slope2 * pos : FINFO_MIN;
+    }
+    short8 qf[NDS];
+#pragma unroll
+    for (int ds = 0; ds < NDS; ++ds) {
+        qf[ds] = short8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (active) qf[ds] = ldg1<short8>(qp + (int64_t)(q0w + l32) * p.q_rs + ds * 16 + hi * 8);
+    }
+    __syncthreads();
+
+    f32x16 o[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+    float m = -INFINITY, lsum = 0.f;
+    const float c = p.scale * LOG2E_F;
+    const float ff2 = p.future_fill <= FINFO_MIN ? FINFO_MIN : p.future_fill * LOG2E_F;
+    int st = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) wait_vm<2 * NPC>(); else wait_vm<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 2 < ntiles) issue(st == 0 ? 2 : st - 1);
+        if (active && t <= my_last) {
+            const unsigned char* ks = smem + st * STAGE;
+            const unsigned char* vs = ks + TILE;
+            const int kv0 = t * 64;
+            f32x16 x[2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { x[0][r] = 0.f; x[1][r] = 0.f; }
+#pragma unroll
+            for (int ds = 0; ds < NDS; ++ds) {
+                x[0] = mfma32(W::fragA(ks, l32, ds * 2 + hi), qf[ds], x[0]);
+                x[1] = mfma32(W::fragA(ks, 32 + l32, ds * 2 + hi), qf[ds], x[1]);
+            }
+            f32x4 kb[2][4];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) kb[kk][j] = *reinterpret_cast<const f32x4*>(kbS + kv0 + kk * 32 + 8 * j + 4 * hi);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x[kk][r] = __builtin_fmaf(x[kk][r], c, kb[kk][r >> 2][r & 3]);   // padding -> finfo.min exactly
+            if (kv0 + 63 > q0w) {                                          // the tile holds (query, key) pairs in the causal future
+                const int thr = q0w + l32 - kv0 - 4 * hi;                   // key offset cc = kk*32 + 8*(r>>2) + (r&3) is in the future iff cc > thr
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float kbv = kb[kk][r >> 2][r & 3];
+                        x[kk][r] = (kk * 32 + 8 * (r >> 2) + (r & 3) > thr) ? (kbv > FINFO_MIN ? ff2 : kbv) : x[kk][r];
+                    }
+            }
+            float mx = max3(x[0][0], x[0][1], x[0][2]);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) mx = max3(mx, x[0][r], x[0][r + 1]);
+            mx = max3(mx, x[0][15], x[1][0]);
+#pragma unroll
+            for (int r = 1; r < 15; r += 2) mx = max3(mx, x[1][r], x[1][r + 1]);
+            mx = max3(mx, mx, x[1][15]);
+            mx = pair_max(mx);
+            const float m_new = max3(m, m, mx);                              // finite: every tile holds >= 1 existing key
+            const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+            float rs0 = 0.f, rs1 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                x[0][r] = __builtin_amdgcn_exp2f(x[0][r] - m_new);           // (s - m) first: finfo.min - finfo.min must be 0
+                x[1][r] = __builtin_amdgcn_exp2f(x[1][r] - m_new);
+                rs0 += x[0][r]; rs1 += x[1][r];
+            }
+            lsum = lsum * alpha + (rs0 + rs1);
+            if (__any(m_new > m)) {                                          // wave-uniform: rescale only when some row max moved
+#pragma unroll
+                for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+            }
+            m = m_new;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const short8 pb = pack8(x[kk][8 * s], x[kk][8 * s + 1], x[kk][8 * s + 2], x[kk][8 * s + 3],
+                                            x[kk][8 * s + 4], x[kk][8 * s + 5], x[kk][8 * s + 6], x[kk][8 * s + 7]);
+#pragma unroll
+                    for (int db = 0; db < NDB; ++db) o[db] = mfma32(W::fragT(vs, kk * 32 + 16 * s, db, lane), pb, o[db]);
+                }
+        }
+        st = st == 2 ? 0 : st + 1;
+    }
+    lsum = pair_sum(lsum);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                           // every wave is done with the ring: reuse it as store patches
+    if (active) {
+        bf16_t* op = reinterpret_cast<bf16_t*>(p.out) + b * p.o_bs + h * p.o_hs + (int64_t)q0w * p.o_rs;
+        store_tile32<HD>(o, 1.0f / lsum, op, p.o_rs, smem + wid * 32 * (HD * 2 + 16), lane);
+        if (hi == 0) {
+            const int64_t srow = (b * p.nh + h) * p.Sq + q0w + l32;
+            p.stat_m[srow] = m <= FINFO_MIN ? FINFO_MIN : m * LN2_F;
+            p.stat_l[srow] = lsum;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dQ
+// own rows = queries.  Per key tile: S^T = K Q^T, dP^T = V dO^T (both with the own query in the accumulator column),
+// P = exp2(s2 - m2) / l, dS^T = P (dP^T - delta), masked entries dS = 0;  dQ^T += K^T dS^T.  Also forms delta = rowsum(dO * O).
+template <int HD, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void attn32_dq_kernel(AttnP p) {
+    using W = WT<HD, NW>;
+    constexpr int NDS = HD / 16, NDB = HD / 32, TILE = W::TILE, STAGE = 2 * TILE, NPC = W::NPC, RPB = 32 * NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* kbS = reinterpret_cast<float*>(smem + 3 * STAGE);
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, hi = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rbw = row_block<NW>(wid);
+    const int BH = (int)(p.B * p.nh), nqb = (int)((p.Sq + RPB - 1) / RPB);
+    const int vid = blockIdx.x;
+    const int qb = nqb - 1 - vid / BH, bh = vid % BH;
+    const int64_t h = bh % p.nh, b = bh / p.nh;
+    const int q0 = qb * RPB, q0w = q0 + 32 * rbw;
+    const bool active = q0w < (int)p.Sq;
+    const int kv_end = min((int)p.Sk, q0 + RPB);                             // masked entries have dS = 0: nothing beyond the diagonal
+    const int ntiles = kv_end / 64;
+    const int my_last = min(ntiles - 1, (q0w + 31) / 64);
+    // a batch row with LEFT padding has all-masked query rows (P uniform, dS must still be 0): every tile keeps the select
+    const bool general = p.kvalid != nullptr && p.first_valid[b] > 0;
+    const bf16_t* qp = reinterpret_cast<const bf16_t*>(p.q) + b * p.q_bs + h * p.q_hs;
+    const bf16_t* kp = reinterpret_cast<const bf16_t*>(p.k) + b * p.k_bs + h * p.k_hs;
+    const bf16_t* vp = reinterpret_cast<const bf16_t*>(p.v) + b * p.v_bs + h * p.v_hs;
+    const bf16_t* gp = reinterpret_cast<const bf16_t*>(p.d_o) + b * p.o_bs + h * p.o_hs;
+    const bf16_t* op = reinterpret_cast<const bf16_t*>(p.o) + b * p.o_bs + h * p.o_hs;
+
+    const bf16_t* pk[NPC];
+    const bf16_t* pv[NPC];
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) { pk[j] = W::src(kp, p.k_rs, wid, j, lane); pv[j] = W::src(vp, p.v_rs, wid, j, lane); }
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    const int64_t kstep = 64 * p.k_rs, vstep = 64 * p.v_rs;
+    auto issue = [&](int stage) {
+        const unsigned d = lds0 + stage * STAGE + wid * NPC * 1024;
+#pragma unroll
+        for (int j = 0; j < NPC; ++j) { dma16(pk[j], d + j * 1024); pk[j] += kstep; }
+#pragma unroll
+        for (int j = 0; j < NPC; ++j) { dma16(pv[j], d + TILE + j * 1024); pv[j] += vstep; }
+    };
+    issue(0);
+    if (ntiles > 1) issue(1);
+
+    const float slope2 = p.slopes ? p.slopes[h] * LOG2E_F : 0.f;
+    for (int key = tid; key < kv_end; key += NW * 64) {
+        const int valid = p.kvalid != nullptr ? (int)p.kvalid[b * p.Sk + key] : 1;
+        const float pos = p.kpos != nullptr ? p.kpos[b * p.Sk + key] : 0.f;
+        kbS[key] = valid != 0 ? slope2 * pos : FINFO_MIN;
+    }
+    short8 qf[NDS], gf[NDS];
+    float m2 = 0.f, il = 0.f, dl = 0.f;
+    const int64_t srow = (b * p.nh + h) * p.Sq + q0w + l32;
+    if (active) {
+        const int64_t ro = (int64_t)(q0w + l32) * p.o_rs;
+#pragma unroll
+        for (int ds = 0; ds < NDS; ++ds) {
+            qf[ds] = ldg1<short8>(qp + (int64_t)(q0w + l32) * p.q_rs + ds * 16 + hi * 8);
+            gf[ds] = ldg1<short8>(gp + ro + ds * 16 + hi * 8);
+            const short8 of = ldg1<short8>(op + ro + ds * 16 + hi * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dl += bf2f((bf16_t)gf[ds][j]) * bf2f((bf16_t)of[j]);
+        }
+        const float mm = p.stat_m[srow];
+        m2 = mm <= FINFO_MIN ? FINFO_MIN : mm * LOG2E_F;
+        il = 1.0f / p.stat_l[srow];
+    } else {
+#pragma unroll
+        for (int ds = 0; ds < NDS; ++ds) { qf[ds] = short8{0, 0, 0, 0, 0, 0, 0, 0}; gf[ds] = qf[ds]; }
+    }
+    dl = pair_sum(dl);
+    if (active && hi == 0) p.delta[srow] = dl;
+    __syncthreads();
+
+    f32x16 dq[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
+    const float c = p.scale * LOG2E_F;
+    int st = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) wait_vm<2 * NPC>(); else wait_vm<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 2 < ntiles) issue(st == 0 ? 2 : st - 1);
+        if (active && t <= my_last) {
+            const unsigned char* ks = smem + st * STAGE;
+            const unsigned char* vs = ks + TILE;
+            const int kv0 = t * 64;
+            f32x16 x[2], y[2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { x[0][r] = 0.f; x[1][r] = 0.f; y[0][r] = 0.f; y[1][r] = 0.f; }
+#pragma unroll
+            for (int ds = 0; ds < NDS; ++ds) {
+                x[0] = mfma32(W::fragA(ks, l32, ds * 2 + hi), qf[ds], x[0]);
+                x[1] = mfma32(W::fragA(ks, 32 + l32, ds * 2 + hi), qf[ds], x[1]);
+                y[0] = mfma32(W::fragA(vs, l32, ds * 2 + hi), gf[ds], y[0]);
+                y[1] = mfma32(W::fragA(vs, 32 + l32, ds * 2 + hi), gf[ds], y[1]);
+            }
+            const bool maskt = general || (kv0 + 63 > q0w);
+            const int thr = q0w + l32 - kv0 - 4 * hi;                       // key offset cc usable iff cc <= thr (not in the causal future)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 kb4 = *reinterpret_cast<const f32x4*>(kbS + kv0 + kk * 32 + 8 * j + 4 * hi);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * j + e;
+                        const float s2 = __builtin_fmaf(x[kk][r], c, kb4[e]);
+                        const float pr = __builtin_amdgcn_exp2f(s2 - m2) * il;
+                        float d = pr * (y[kk][r] - dl);
+                        if (maskt) d = ((kb4[e] > FINFO_MIN) & (kk * 32 + 8 * j + e <= thr)) ? d : 0.f;   // padding / future keys: dS = 0
+                        y[kk][r] = d;
+                    }
+                }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const short8 db8 = pack8(y[kk][8 * s], y[kk][8 * s + 1], y[kk][8 * s + 2], y[kk][8 * s + 3],
+                                             y[kk][8 * s + 4], y[kk][8 * s + 5], y[kk][8 * s + 6], y[kk][8 * s + 7]);
+#pragma unroll
+                    for (int db = 0; db < NDB; ++db) dq[db] = mfma32(W::fragT(ks, kk * 32 + 16 * s, db, lane), db8, dq[db]);
+                }
+        }
+        st = st == 2 ? 0 : st + 1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (active) {
+        bf16_t* dqp = reinterpret_cast<bf16_t*>(p.dq) + b * p.q_bs + h * p.q_hs + (int64_t)q0w * p.q_rs;
+        store_tile32<HD>(dq, p.scale, dqp, p.q_rs, smem + wid * 32 * (HD * 2 + 16), lane);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dK, dV
+// own rows = keys.  Per query tile: S = Q K^T and dP = dO V^T (own key in the accumulator column), P = exp2(s2 - m2[q]) / l[q],
+// dS = P (dP - delta[q]); dV^T += dO^T P, dK^T += Q^T dS.  Masked entries (padding key, causal future): P keeps the fill value's
+// probability (non-zero only in all-masked rows, which are uniform), dS = 0.
+template <int HD, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void attn32_dkdv_kernel(AttnP p) {
+    using W = WT<HD, NW>;
+    constexpr int NDS = HD / 16, NDB = HD / 32, TILE = W::TILE, STAGE = 2 * TILE, NPC = W::NPC, RPB = 32 * NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* m2S = reinterpret_cast<float*>(smem + 3 * STAGE);                // [Sq] row max in log2 units | [Sq] 1/l | [Sq] delta
+    float* ilS = m2S + p.Sq;
+    float* dlS = ilS + p.Sq;
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, hi = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rbw = row_block<NW>(wid);
+    const int BH = (int)(p.B * p.nh);
+    const int vid = blockIdx.x;
+    const int kblk = vid / BH, bh = vid % BH;                                // early key blocks (most query tiles) first
+    const int64_t h = bh % p.nh, b = bh / p.nh;
+    const int k0 = kblk * RPB, k0w = k0 + 32 * rbw;
+    const bool active = k0w < (int)p.Sk;
+    // all-masked query rows (LEFT padding) are uniform over ALL keys -> they reach every key block
+    const bool allq = p.kvalid != nullptr && p.first_valid[b] > 0;
+    const int qt_end = (int)(p.Sq / 64);
+    const int qt_begin = allq ? 0 : min(k0 / 64, qt_end);
+    const int my_first = allq ? 0 : k0w / 64;
+    const int nt = qt_end - qt_begin;
+    const bf16_t* qp = reinterpret_cast<const bf16_t*>(p.q) + b * p.q_bs + h * p.q_hs + (int64_t)qt_begin * 64 * p.q_rs;
+    const bf16_t* kp = reinterpret_cast<const bf16_t*>(p.k) + b * p.k_bs + h * p.k_hs;
+    const bf16_t* vp = reinterpret_cast<const bf16_t*>(p.v) + b * p.v_bs + h * p.v_hs;
+    const bf16_t* gp = reinterpret_cast<const bf16_t*>(p.d_o) + b * p.o_bs + h * p.o_hs + (int64_t)qt_begin * 64 * p.o_rs;
+
+    const bf16_t* pq[NPC];
+    const bf16_t* pg[NPC];
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) { pq[j] = W::src(qp, p.q_rs, wid, j, lane); pg[j] = W::src(gp, p.o_rs, wid, j, lane); }
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    const int64_t qstep = 64 * p.q_rs, gstep = 64 * p.o_rs;
+    auto issue = [&](int stage) {
+        const unsigned d = lds0 + stage * STAGE + wid * NPC * 1024;
+#pragma unroll
+        for (int j = 0; j < NPC; ++j) { dma16(pq[j], d + j * 1024); pq[j] += qstep; }
+#pragma unroll
+        for (int j = 0; j < NPC; ++j) { dma16(pg[j], d + TILE + j * 1024); pg[j] += gstep; }
+    };
+    if (nt > 0) issue(0);
+    if (nt > 1) issue(1);
+
+    // row statistics of every query this workgroup will stream, converted once (m in log2 units, 1/l, delta): three floats per row
+    // in LDS for the lifetime of the workgroup instead of a per-tile restage
+    {
+        const float* sm = p.stat_m + (b * p.nh + h) * p.Sq;
+        const float* sl = p.stat_l + (b * p.nh + h) * p.Sq;
+        const float* sd = p.delta + (b * p.nh + h) * p.Sq;
+        for (int q = qt_begin * 64 + tid; q < (int)p.Sq; q += NW * 64) {
+            const float mm = sm[q];
+            m2S[q] = mm <= FINFO_MIN ? FINFO_MIN : mm * LOG2E_F;
+            ilS[q] = 1.0f / sl[q];
+            dlS[q] = sd[q];
+        }
+    }
+
+    short8 kf[NDS], vf[NDS];
+    float kb_lane = 0.f;
+    bool key_pad = false;
+    if (active) {
+        const int64_t key = k0w + l32;
+#pragma unroll
+        for (int ds = 0; ds < NDS; ++ds) {
+            kf[ds] = ldg1<short8>(kp + key * p.k_rs + ds * 16 + hi * 8);
+            vf[ds] = ldg1<short8>(vp + key * p.v_rs + ds * 16 + hi * 8);
+        }
+        const float slope2 = p.slopes ? p.slopes[h] * LOG2E_F : 0.f;
+        const int valid = p.kvalid != nullptr ? (int)p.kvalid[b * p.Sk + key] : 1;
+        const float pos = p.kpos != nullptr ? p.kpos[b * p.Sk + key] : 0.f;
+        key_pad = valid == 0;
+        kb_lane = key_pad ? FINFO_MIN : slope2 * pos;
+    } else {
+#pragma unroll
+        for (int ds = 0; ds < NDS; ++ds) { kf[ds] = short8{0, 0, 0, 0, 0, 0, 0, 0}; vf[ds] = kf[ds]; }
+    }
+    const float ff2 = p.future_fill <= FINFO_MIN ? FINFO_MIN : p.future_fill * LOG2E_F;
+    const float lane_fill = key_pad ? FINFO_MIN : ff2;                      // what a masked score of this lane's key is replaced by
+    __syncthreads();
+
+    f32x16 dk[NDB], dv[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+    const float c = p.scale * LOG2E_F;
+    int st = 0;
+    for (int i = 0; i < nt; ++i) {
+        const int t = qt_begin + i;
+        if (i + 1 < nt) wait_vm<2 * NPC>(); else wait_vm<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (i + 2 < nt) issue(st == 0 ? 2 : st - 1);
+        if (active && t >= my_first) {
+            const unsigned char* qs = smem + st * STAGE;
+            const unsigned char* gs = qs + TILE;
+            f32x16 x[2], y[2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { x[0][r] = 0.f; x[1][r] = 0.f; y[0][r] = 0.f; y[1][r] = 0.f; }
+#pragma unroll
+            for (int ds = 0; ds < NDS; ++ds) {
+                x[0] = mfma32(W::fragA(qs, l32, ds * 2 + hi), kf[ds], x[0]);
+                x[1] = mfma32(W::fragA(qs, 32 + l32, ds * 2 + hi), kf[ds], x[1]);
+                y[0] = mfma32(W::fragA(gs, l32, ds * 2 + hi), vf[ds], y[0]);
+                y[1] = mfma32(W::fragA(gs, 32 + l32, ds * 2 + hi), vf[ds], y[1]);
+            }
+            const bool maskt = allq || (t * 64 < k0w + 31);                 // some (query, key) pair of the tile is in the causal future
+            // masked(cc) for the query at offset cc = qq*32 + 8*j + e of this lane's group: padding key, or query index < key index
+            const int thr = key_pad ? 0x7fffffff : (k0w + l32 - t * 64 - 4 * hi);
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int qi = t * 64 + qq * 32 + 8 * j + 4 * hi;
+                    const f32x4 mm = *reinterpret_cast<const f32x4*>(m2S + qi);
+                    const f32x4 il4 = *reinterpret_cast<const f32x4*>(ilS + qi);
+                    const f32x4 dl4 = *reinterpret_cast<const f32x4*>(dlS + qi);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * j + e;
+                        float s2 = __builtin_fmaf(x[qq][r], c, kb_lane);
+                        bool msk = false;
+                        if (maskt) { msk = (qq * 32 + 8 * j + e) < thr; s2 = msk ? lane_fill : s2; }
+                        const float pr = __builtin_amdgcn_exp2f(s2 - mm[e]) * il4[e];
+                        float d = pr * (y[qq][r] - dl4[e]);
+                        if (maskt) d = msk ? 0.f : d;
+                        x[qq][r] = pr;
+                        y[qq][r] = d;
+                    }
+                }
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const short8 pb = pack8(x[qq][8 * s], x[qq][8 * s + 1], x[qq][8 * s + 2], x[qq][8 * s + 3],
+                                            x[qq][8 * s + 4], x[qq][8 * s + 5], x[qq][8 * s + 6], x[qq][8 * s + 7]);
+                    const short8 sb = pack8(y[qq][8 * s], y[qq][8 * s + 1], y[qq][8 * s + 2], y[qq][8 * s + 3],
+                                            y[qq][8 * s + 4], y[qq][8 * s + 5], y[qq][8 * s + 6], y[qq][8 * s + 7]);
+#pragma unroll
+                    for (int db = 0; db < NDB; ++db) {
+                        dv[db] = mfma32(W::fragT(gs, qq * 32 + 16 * s, db, lane), pb, dv[db]);
+                        dk[db] = mfma32(W::fragT(qs, qq * 32 + 16 * s, db, lane), sb, dk[db]);
+                    }
+                }
+        }
+        st = st == 2 ? 0 : st + 1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (active) {
+        if (key_pad) {                                                       // the mask-free tiles leave p = 0 there; a padding key's dK is 0 by definition
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dk[db][r] = 0.f;
+        }
+        bf16_t* dkp = reinterpret_cast<bf16_t*>(p.dk) + b * p.k_bs + h * p.k_hs + (int64_t)k0w * p.k_rs;
+        bf16_t* dvp = reinterpret_cast<bf16_t*>(p.dv) + b * p.v_bs + h * p.v_hs + (int64_t)k0w * p.v_rs;
+        unsigned char* scr = smem + wid * 32 * (HD * 2 + 16);
+        store_tile32<HD>(dk, p.scale, dkp, p.k_rs, scr, lane);
+        store_tile32<HD>(dv, 1.0f, dvp, p.v_rs, scr, lane);
+    }
+}
+
+// bit 0: forward, bit 1: backward (ctmi_attn_set_path; CTMI_ATTN_W32 gives the initial value)
+std::atomic<int> g_w32_mask{-1};
+int w32_mask() {
+    int v = g_w32_mask.load(std::memory_order_relaxed);
+    if (v < 0) { const char* e = getenv("CTMI_ATTN_W32"); v = e ? (atoi(e) & 3) : 3; g_w32_mask.store(v, std::memory_order_relaxed); }
+    return v;
+}
+bool w32_ok(const AttnP& p) {
+    return p.add_mask == nullptr && p.drop_thr == 0 && p.vec_ok && (p.hd == 64 || p.hd == 128) && p.causal &&
+           p.Sq == p.Sk && p.Sk % 64 == 0 && p.Sk >= 64 && p.Sk <= 4096 && p.B * p.nh < (1 << 20);
+}
+template <typename K>
+void launch32(K kern, int64_t grid, int threads, size_t lds, hipStream_t st, const AttnP& p) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, st, p);
+}
+template <int HD, int NW> size_t lds_kv(const AttnP& p) { return 3 * (size_t)(2 * WT<HD, NW>::TILE) + 4 * (size_t)p.Sk; }
+template <int HD, int NW> size_t lds_qg(const AttnP& p) { return 3 * (size_t)(2 * WT<HD, NW>::TILE) + 12 * (size_t)p.Sq; }
+
+}  // namespace
+
+extern "C" int ctmi_attn_set_path(int mask) {
+    const int prev = w32_mask();
+    if (mask >= 0) g_w32_mask.store(mask & 3, std::memory_order_relaxed);
+    return prev;
+}
+
+int ctmi_attn32_fwd(const AttnP& p, hipStream_t st) {
+    if (!w32_ok(p) || !(w32_mask() & 1)) return 0;
+    const int64_t BH = p.B * p.nh;
+    if (p.hd == 64) launch32(&attn32_fwd_kernel<64, 8>, ((p.Sq + 255) / 256) * BH, 512, lds_kv<64, 8>(p), st, p);
+    else launch32(&attn32_fwd_kernel<128, 8>, ((p.Sq + 255) / 256) * BH, 512, lds_kv<128, 8>(p), st, p);
+    return 1;
+}
+
+int ctmi_attn32_bwd(const AttnP& p, hipStream_t st) {
+    if (!w32_ok(p) || !(w32_mask() & 2)) return 0;
+    const int64_t BH = p.B * p.nh;
+    // dQ first: it also publishes delta = rowsum(dO * O) for the dK/dV kernel (same stream: ordered)
+    if (p.hd == 64) {
+        launch32(&attn32_dq_kernel<64, 8>, ((p.Sq + 255) / 256) * BH, 512, lds_kv<64, 8>(p), st, p);
+        launch32(&attn32_dkdv_kernel<64, 8>, ((p.Sk + 255) / 256) * BH, 512, lds_qg<64, 8>(p), st, p);
+    } else {
+        launch32(&attn32_dq_kernel<128, 4>, ((p.Sq + 127) / 128) * BH, 256, lds_kv<128, 4>(p), st, p);
+        launch32(&attn32_dkdv_kernel<128, 4>, ((p.Sk + 127) / 128) * BH, 256, lds_qg<128, 4>(p), st, p);
+    }
+    return 1;
+}

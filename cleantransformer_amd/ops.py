@@ -551,6 +551,12 @@ def set_launch_policy(shared: bool, reserve_cus: Optional[int] = None) -> None:
     check(lib.ctmi_set_launch_policy(int(bool(shared)), int(reserve_cus)), "set_launch_policy")
 
 
+def set_attn_path(mask: int) -> int:
+    """Attention kernel family for the bf16 training shapes (include/ctmi355.h ctmi_attn_set_path): bit 0 forward, bit 1 backward on the
+    256-row kernels; returns the previous value."""
+    return int(_lib.load().ctmi_attn_set_path(int(mask)))
+
+
 def get_launch_policy() -> Tuple[bool, int]:
     sh, r = C.c_int(0), C.c_int(0)
     _lib.load().ctmi_get_launch_policy(C.byref(sh), C.byref(r))

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CTMI_ABI_VERSION 6
+#define CTMI_ABI_VERSION 7
 
 enum ctmi_dtype { CTMI_F32 = 0, CTMI_BF16 = 1 };
 enum ctmi_status { CTMI_OK = 0, CTMI_ERR_ARG = -1, CTMI_ERR_LAUNCH = -2, CTMI_ERR_UNSUPPORTED = -3 };
@@ -122,6 +122,13 @@ int ctmi_attn_bwd(const void* q, const void* k, const void* v, const void* o, co
                   const float* stat_m, const float* stat_l, void* dq, void* dk, void* dv, float* delta,
                   const float* slopes, const float* kpos, const int32_t* kvalid, const int32_t* first_valid,
                   const float* add_mask, const ctmi_attn_desc* desc /* host */, int dtype, void* stream);
+/* Which kernels serve the bf16 TRAINING shapes of ctmi_attn_fwd / ctmi_attn_bwd (causal, Sq == Sk a multiple of 64 and <= 4096,
+ * head_dim 64 or 128, no additive mask, no probability dropout): bit 0 = forward, bit 1 = backward through the 256-row /
+ * 32x32-MFMA kernels of csrc/attention_w32.hip (default 3); 0 = the general 64-row kernels for everything.  Same contract and
+ * results up to bf16 rounding either way (the statistics stat_m / stat_l are interchangeable between the two families); the
+ * switch exists for A/B measurements and parity tests.  mask < 0: query only.  Returns the previous value.
+ * (modeling_bloom.py:84-116 is served by both.) */
+int ctmi_attn_set_path(int mask);
 /* attention_mask [B,S] (int64 0/1) -> kpos fp32, kvalid int32, first_valid int32[B]  (modeling_bloom.py:328, 178-179) */
 int ctmi_mask_prep(const int64_t* attention_mask, float* kpos, int32_t* kvalid, int32_t* first_valid,
                    int64_t B, int64_t S, void* stream);
