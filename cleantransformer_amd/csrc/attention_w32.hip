@@ -35,6 +35,29 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8_w32 __attribute__((ext_vector_type(8)));
 typedef short short4_w32 __attribute__((ext_vector_type(4)));
 
+// forward, head_dim 64: cap the registers at 128 so that TWO 8-wave workgroups share a CU (4 waves per SIMD from two workgroups that
+// are not coupled by a barrier)
+#ifndef CTMI_W32_FWD_2WG
+#define CTMI_W32_FWD_2WG 1
+#endif
+// forward: log2 of the growth of a row maximum that is tolerated before O / l are rescaled (0 = rescale whenever a maximum moved)
+#ifndef CTMI_W32_DEFER_MAX
+#define CTMI_W32_DEFER_MAX 0
+#endif
+// -DCTMI_W32_TIMING=1 (tools/ variant builds only): the forward kernel accumulates s_memtime deltas per wave — matrix segments,
+// vector segments, barrier waits after each — and dumps them over stat_l (which is then garbage): tools/attn_w32_timing.py
+#ifndef CTMI_W32_TIMING
+#define CTMI_W32_TIMING 0
+#endif
+#if CTMI_W32_TIMING
+#define W32_TICK(acc) do { const uint64_t now__ = __builtin_amdgcn_s_memtime(); acc += (uint32_t)(now__ - tlast); tlast = now__; } while (0)
+#else
+#define W32_TICK(acc) do { } while (0)
+#endif
+// forward: which segment raises its wave priority (0 none, 1 the matrix segment, 2 the vector segment)
+#ifndef CTMI_W32_PRIO
+#define CTMI_W32_PRIO 1
+#endif
 #define LOG2E_F 1.4426950408889634f
 #define LN2_F 0.6931471805599453f
 
@@ -73,6 +96,11 @@ template <int N> __device__ __forceinline__ void wait_vm() {
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 }
+// Pin a value loaded by an ordinary global load BEFORE the streaming loop: hipcc places the vmcnt wait of a load at its first use,
+// and a first use inside the loop is a `s_waitcnt vmcnt(0)` executed every iteration — it drains the LDS-DMA queue (the tile
+// issued a moment earlier) and serialises the whole pipeline on L2/HBM latency (measured: the loop ran at 1/4 of its speed).
+__device__ __forceinline__ void pin(short8& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
 template <typename V> __device__ __forceinline__ V ldg1(const void* p) {
     typedef const __attribute__((address_space(1))) V* gptr;
     return *(gptr)(p);
@@ -152,14 +180,52 @@ __device__ __forceinline__ void store_tile32(const f32x16 (&acc)[HD / 32], float
 }
 
 // ------------------------------------------------------------------------------------------------ forward
+// x[i] = (cc_i > thr) ? fill : x[i] for four elements: four compares into four SGPR pairs, then four selects — hipcc's own
+// v_cmp (VCC) / v_cndmask pairs need a wait state between a compare and ITS select and are emitted back to back.
+template <int R0, int C0>                                                    // elements R0..R0+3 of v, key offsets C0..C0+3
+__device__ __forceinline__ void fill4_future(f32x16& v, int thr, float fill) {
+    constexpr int C1 = C0 + 1, C2 = C0 + 2, C3 = C0 + 3;
+    static_assert(C0 >= 0 && C3 <= 64, "inline integer constants");
+    float a = v[R0], b = v[R0 + 1], c = v[R0 + 2], d = v[R0 + 3];
+    uint64_t m0, m1, m2, m3;
+    asm volatile("v_cmp_lt_i32_e64 %4, %8, %10\n\t"
+                 "v_cmp_lt_i32_e64 %5, %8, %11\n\t"
+                 "v_cmp_lt_i32_e64 %6, %8, %12\n\t"
+                 "v_cmp_lt_i32_e64 %7, %8, %13\n\t"
+                 "v_cndmask_b32_e64 %0, %0, %9, %4\n\t"
+                 "v_cndmask_b32_e64 %1, %1, %9, %5\n\t"
+                 "v_cndmask_b32_e64 %2, %2, %9, %6\n\t"
+                 "v_cndmask_b32_e64 %3, %3, %9, %7"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+                 : "v"(thr), "v"(fill), "n"(C0), "n"(C1), "n"(C2), "n"(C3));
+    v[R0] = a; v[R0 + 1] = b; v[R0 + 2] = c; v[R0 + 3] = d;
+}
+
+// Ping-pong schedule (8 waves).  Every SIMD holds one wave of group A (waves 0-3) and one of group B (waves 4-7).  A tile's work
+// of one wave is cut into a MATRIX segment X(t) = { O += P(t-1) V(t-1) ; S(t) = K(t) Q^T + key bias } (16 MFMAs + their LDS fragment
+// reads, no VALU) and a VECTOR segment Y(t) = { softmax of S(t) -> P(t), prefetch of the V(t) fragments } (no MFMA); group B runs one
+// segment behind group A and a barrier closes every segment, so while one wave of a SIMD owns the matrix pipe its partner owns
+// the VALU.  Measured anatomy that led here (tools/attn_w32_timing.py, s_memtime per wave): with one wave of a SIMD in a segment
+// nothing hides a dependent instruction or an LDS round trip of that wave, so
+//   * every fragment read of a matrix segment is issued before its first MFMA (the V fragments already at the end of the vector
+//     segment before), the per-key bias arrives as the C operand of the first score MFMA (no bias reads, no add in Y);
+//   * the vector segment is one v_pk_fma (x*c - m*c) + one exp2 per score pair, row max and row sum in four independent chains.
+//   barriers   A:      X(0) b0 Y(0) b1 X(1) b2 ... Y(n-1) b X(n) b  b          B:  b0 X(0) b1 Y(0) b2 ... X(n) b
+//   K/V ring   4 stages.  Tile t+2 is issued at the start of Y(t); tile t is read in X(t) (K), Y(t) and X(t+1) (V) of both groups, i.e.
+//              until two segments after A's Y(t) — the slot of tile t+2 (= tile t-2) was last read in B's X(t-1), one barrier earlier.
+//              Every wave waits for its own pieces of tile t+1 before the barrier that ends the segment preceding A's X(t+1).
+// Scores are kept in units of 1/scale ("raw": q.k + bias/scale) until the exponent: p = exp2(raw*c - max*c), c = scale*log2(e).
 template <int HD, int NW>
 __global__ __launch_bounds__(NW * 64, NW / 4) void attn32_fwd_kernel(AttnP p) {
+    static_assert(NW == 8, "the ping-pong schedule pairs waves w and w + 4 on one SIMD");
     using W = WT<HD, NW>;
-    constexpr int NDS = HD / 16, NDB = HD / 32, TILE = W::TILE, STAGE = 2 * TILE, NPC = W::NPC, RPB = 32 * NW;
+    constexpr int NDS = HD / 16, NDB = HD / 32, TILE = W::TILE, STAGE = 2 * TILE, NPC = W::NPC, RPB = 32 * NW, NST = 4;
+    constexpr bool PREV = HD == 64;                                          // V fragments prefetched a segment ahead (register budget)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* kbS = reinterpret_cast<float*>(smem + 3 * STAGE);
+    float* kbS = reinterpret_cast<float*>(smem + NST * STAGE);              // per-key bias / scale  (finfo.min: padding key)
     const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, hi = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wid >> 2;
     const int rbw = row_block<NW>(wid);
     const int BH = (int)(p.B * p.nh), nqb = (int)((p.Sq + RPB - 1) / RPB);
     const int vid = blockIdx.x;
@@ -171,7 +237,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn32_fwd_kernel(AttnP p) {
     const bool allk = p.kvalid != nullptr && p.first_valid[b] > q0;
     const int kv_end = allk ? (int)p.Sk : min((int)p.Sk, q0 + RPB);
     const int ntiles = kv_end / 64;
-    const int my_last = allk ? ntiles - 1 : min(ntiles - 1, (q0w + 31) / 64);
+    const int my_last = !active ? -1 : (allk ? ntiles - 1 : min(ntiles - 1, (q0w + 31) / 64));
     const bf16_t* qp = reinterpret_cast<const bf16_t*>(p.q) + b * p.q_bs + h * p.q_hs;
     const bf16_t* kp = reinterpret_cast<const bf16_t*>(p.k) + b * p.k_bs + h * p.k_hs;
     const bf16_t* vp = reinterpret_cast<const bf16_t*>(p.v) + b * p.v_bs + h * p.v_hs;
@@ -192,11 +258,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn32_fwd_kernel(AttnP p) {
     issue(0);
     if (ntiles > 1) issue(1);
 
-    const float slope2 = p.slopes ? p.slopes[h] * LOG2E_F : 0.f;
+    const float slope_r = p.slopes ? p.slopes[h] / p.scale : 0.f;
     for (int key = tid; key < kv_end; key += NW * 64) {
         const int valid = p.kvalid != nullptr ? (int)p.kvalid[b * p.Sk + key] : 1;
         const float pos = p.kpos != nullptr ? p.kpos[b * p.Sk + key] : 0.f;
-        kbS[key] = valid != 0 ? slope2 * pos : FINFO_MIN;
+        kbS[key] = valid != 0 ? slope_r * pos : FINFO_MIN;
     }
     short8 qf[NDS];
 #pragma unroll
@@ -205,71 +271,177 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn32_fwd_kernel(AttnP p) {
         if (active) qf[ds] = ldg1<short8>(qp + (int64_t)(q0w + l32) * p.q_rs + ds * 16 + hi * 8);
     }
     __syncthreads();
+#pragma unroll
+    for (int ds = 0; ds < NDS; ++ds) pin(qf[ds]);
+    if (ntiles > 1) wait_vm<2 * NPC>(); else wait_vm<0>();                  // own pieces of tile 0
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 
     f32x16 o[NDB];
 #pragma unroll
     for (int db = 0; db < NDB; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-    float m = -INFINITY, lsum = 0.f;
+    float m = -INFINITY, lsum = 0.f;                                         // m in raw units
     const float c = p.scale * LOG2E_F;
-    const float ff2 = p.future_fill <= FINFO_MIN ? FINFO_MIN : p.future_fill * LOG2E_F;
-    int st = 0;
-    for (int t = 0; t < ntiles; ++t) {
-        if (t + 1 < ntiles) wait_vm<2 * NPC>(); else wait_vm<0>();
+    const float ffr = p.future_fill <= FINFO_MIN ? FINFO_MIN : p.future_fill / p.scale;
+    f32x16 x[2];
+    short8 pb[2][2];
+    short8 vfr[PREV ? 4 * NDB : 1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { x[0][r] = 0.f; x[1][r] = 0.f; }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) pb[kk][s] = short8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < (PREV ? 4 * NDB : 1); ++i) vfr[i] = short8{0, 0, 0, 0, 0, 0, 0, 0};
+    auto bar = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
         asm volatile("" ::: "memory");
-        if (t + 2 < ntiles) issue(st == 0 ? 2 : st - 1);
-        if (active && t <= my_last) {
-            const unsigned char* ks = smem + st * STAGE;
-            const unsigned char* vs = ks + TILE;
-            const int kv0 = t * 64;
-            f32x16 x[2];
+    };
+#if CTMI_W32_TIMING
+    uint32_t tX = 0, tY = 0, tBX = 0, tBY = 0, tPro = 0;
+    uint64_t tlast = __builtin_amdgcn_s_memtime();
+    const uint64_t tbeg = tlast;
+#endif
+    if (grp == 1) bar();
+    W32_TICK(tPro);
+    for (int t = 0;; ++t) {
+        // ---- X(t): matrix segment
+        const bool do_pv = t > 0 && t - 1 <= my_last, do_qk = t < ntiles && t <= my_last;
+        const unsigned char* ks = smem + (t & 3) * STAGE;
+        const unsigned char* vs = smem + ((t - 1) & 3) * STAGE + TILE;
+        short8 kfr[PREV ? 2 * NDS : 1];
+        if constexpr (PREV) {
+            if (do_qk) {                                                     // every read of the segment goes out before its first MFMA
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { x[0][r] = 0.f; x[1][r] = 0.f; }
-#pragma unroll
-            for (int ds = 0; ds < NDS; ++ds) {
-                x[0] = mfma32(W::fragA(ks, l32, ds * 2 + hi), qf[ds], x[0]);
-                x[1] = mfma32(W::fragA(ks, 32 + l32, ds * 2 + hi), qf[ds], x[1]);
-            }
-            f32x4 kb[2][4];
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) kb[kk][j] = *reinterpret_cast<const f32x4*>(kbS + kv0 + kk * 32 + 8 * j + 4 * hi);
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) x[kk][r] = __builtin_fmaf(x[kk][r], c, kb[kk][r >> 2][r & 3]);   // padding -> finfo.min exactly
-            if (kv0 + 63 > q0w) {                                          // the tile holds (query, key) pairs in the causal future
-                const int thr = q0w + l32 - kv0 - 4 * hi;                   // key offset cc = kk*32 + 8*(r>>2) + (r&3) is in the future iff cc > thr
+                for (int ds = 0; ds < NDS; ++ds) { kfr[2 * ds] = W::fragA(ks, l32, ds * 2 + hi); kfr[2 * ds + 1] = W::fragA(ks, 32 + l32, ds * 2 + hi); }
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float kbv = kb[kk][r >> 2][r & 3];
-                        x[kk][r] = (kk * 32 + 8 * (r >> 2) + (r & 3) > thr) ? (kbv > FINFO_MIN ? ff2 : kbv) : x[kk][r];
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 kb4 = *reinterpret_cast<const f32x4*>(kbS + t * 64 + kk * 32 + 8 * j + 4 * hi);
+                        x[kk][4 * j] = kb4[0]; x[kk][4 * j + 1] = kb4[1]; x[kk][4 * j + 2] = kb4[2]; x[kk][4 * j + 3] = kb4[3];
                     }
             }
-            float mx = max3(x[0][0], x[0][1], x[0][2]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (CTMI_W32_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+        if (do_pv) {
 #pragma unroll
-            for (int r = 3; r < 15; r += 2) mx = max3(mx, x[0][r], x[0][r + 1]);
-            mx = max3(mx, x[0][15], x[1][0]);
+            for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int r = 1; r < 15; r += 2) mx = max3(mx, x[1][r], x[1][r + 1]);
-            mx = max3(mx, mx, x[1][15]);
-            mx = pair_max(mx);
-            const float m_new = max3(m, m, mx);                              // finite: every tile holds >= 1 existing key
-            const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-            float rs0 = 0.f, rs1 = 0.f;
+                for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                x[0][r] = __builtin_amdgcn_exp2f(x[0][r] - m_new);           // (s - m) first: finfo.min - finfo.min must be 0
-                x[1][r] = __builtin_amdgcn_exp2f(x[1][r] - m_new);
-                rs0 += x[0][r]; rs1 += x[1][r];
+                    for (int db = 0; db < NDB; ++db) {
+                        if constexpr (PREV) o[db] = mfma32(vfr[(kk * 2 + s) * NDB + db], pb[kk][s], o[db]);
+                        else o[db] = mfma32(W::fragT(vs, kk * 32 + 16 * s, db, lane), pb[kk][s], o[db]);
+                    }
+        }
+        if (do_qk) {
+            if constexpr (!PREV) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 kb4 = *reinterpret_cast<const f32x4*>(kbS + t * 64 + kk * 32 + 8 * j + 4 * hi);
+                        x[kk][4 * j] = kb4[0]; x[kk][4 * j + 1] = kb4[1]; x[kk][4 * j + 2] = kb4[2]; x[kk][4 * j + 3] = kb4[3];
+                    }
             }
-            lsum = lsum * alpha + (rs0 + rs1);
+#pragma unroll
+            for (int ds = 0; ds < NDS; ++ds) {
+                if constexpr (PREV) {
+                    x[0] = mfma32(kfr[2 * ds], qf[ds], x[0]);
+                    x[1] = mfma32(kfr[2 * ds + 1], qf[ds], x[1]);
+                } else {
+                    x[0] = mfma32(W::fragA(ks, l32, ds * 2 + hi), qf[ds], x[0]);
+                    x[1] = mfma32(W::fragA(ks, 32 + l32, ds * 2 + hi), qf[ds], x[1]);
+                }
+            }
+        }
+        if (CTMI_W32_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+        if (grp == 1 && t + 1 < ntiles) wait_vm<0>();                       // own pieces of tile t+1 (issued at the start of Y(t-1))
+        W32_TICK(tX);
+        bar();
+        W32_TICK(tBX);
+        if (t == ntiles) break;
+        // ---- Y(t): vector segment
+        if (t + 2 < ntiles) issue((t + 2) & 3);
+        if (CTMI_W32_PRIO == 2) __builtin_amdgcn_s_setprio(1);
+        if (t <= my_last) {
+            // The vector segment is bound by VALU issue and by the latency of dependent instructions (its SIMD partner is in a matrix
+            // segment), so the arithmetic is on float2 values (v_pk_fma / v_pk_add / v_pk_mul_f32: one issue slot per TWO elements)
+            // and the reductions run in four independent chains.
+            const int kv0 = t * 64;
+            if (kv0 + 63 > q0w) {                                          // the tile holds (query, key) pairs in the causal future
+                const int thr = q0w + l32 - kv0 - 4 * hi;                   // key offset cc = kk*32 + 8*(r>>2) + (r&3) is in the future iff cc > thr
+                if (ffr <= FINFO_MIN) {
+                    // masked_fill(finfo.min): padding keys already hold finfo.min, so every future score is finfo.min whatever the key
+#define W32_FILL(kk, j) fill4_future<4 * j, kk * 32 + 8 * j>(x[kk], thr, FINFO_MIN)
+                    W32_FILL(0, 0); W32_FILL(0, 1); W32_FILL(0, 2); W32_FILL(0, 3); W32_FILL(1, 0); W32_FILL(1, 1); W32_FILL(1, 2); W32_FILL(1, 3);
+#undef W32_FILL
+                } else {                                                     // GPT-2's -1e4 replacement: padding keys keep finfo.min
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const f32x4 kb4 = *reinterpret_cast<const f32x4*>(kbS + kv0 + kk * 32 + 8 * j + 4 * hi);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                x[kk][4 * j + e] = (kk * 32 + 8 * j + e > thr) ? (kb4[e] > FINFO_MIN ? ffr : kb4[e]) : x[kk][4 * j + e];
+                        }
+                }
+            }
+            float mx0 = max3(x[0][0], x[0][1], x[0][2]), mx1 = max3(x[0][8], x[0][9], x[0][10]);
+            float mx2 = max3(x[1][0], x[1][1], x[1][2]), mx3 = max3(x[1][8], x[1][9], x[1][10]);
+            mx0 = max3(mx0, x[0][3], x[0][4]); mx1 = max3(mx1, x[0][11], x[0][12]); mx2 = max3(mx2, x[1][3], x[1][4]); mx3 = max3(mx3, x[1][11], x[1][12]);
+            mx0 = max3(mx0, x[0][5], x[0][6]); mx1 = max3(mx1, x[0][13], x[0][14]); mx2 = max3(mx2, x[1][5], x[1][6]); mx3 = max3(mx3, x[1][13], x[1][14]);
+            mx0 = max3(mx0, x[0][7], x[0][15]); mx2 = max3(mx2, x[1][7], x[1][15]);
+            float mx = max3(mx0, mx1, mx2);
+            mx = max3(mx, mx, mx3);
+            mx = pair_max(mx);
+            float m_new = max3(m, m, mx);                                    // finite: every tile holds >= 1 existing key
+            if (CTMI_W32_DEFER_MAX > 0) {
+                // keep the old reference while no row maximum of the wave grew by more than 2^DEFER: the probabilities of this tile are
+                // then bounded by 2^DEFER instead of 1 (bf16 is a floating format: no precision is lost), O and l stay in the old scale
+                if (!__any((mx - m) * c > (float)CTMI_W32_DEFER_MAX)) m_new = m;
+            }
+            const float alpha = __builtin_amdgcn_exp2f((m - m_new) * c);
+            const float mc = m_new * c;
+            f32x2 xv[2][8];
+            if (allk) {
+                // a row may be all-masked here: its scores AND its maximum are finfo.min and the exponent must be exactly 0 — the two
+                // products are formed separately (identical roundings cancel); the fused form below would leave the rounding error
+                // of finfo.min * c, which is astronomically large
+#pragma clang fp contract(off)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const f32x2 pr = f32x2{x[kk][2 * i], x[kk][2 * i + 1]} * c;
+                        xv[kk][i] = pr - mc;
+                    }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) xv[kk][i] = f32x2{x[kk][2 * i], x[kk][2 * i + 1]} * c - mc;    // one v_pk_fma_f32
+            }
+            f32x2 rs[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const f32x2 e = {__builtin_amdgcn_exp2f(xv[kk][i][0]), __builtin_amdgcn_exp2f(xv[kk][i][1])};
+                    xv[kk][i] = e;
+                    rs[(kk * 8 + i) & 3] += e;
+                }
+            const f32x2 rsum = (rs[0] + rs[1]) + (rs[2] + rs[3]);
+            lsum = lsum * alpha + (rsum[0] + rsum[1]);
             if (__any(m_new > m)) {                                          // wave-uniform: rescale only when some row max moved
 #pragma unroll
                 for (int db = 0; db < NDB; ++db)
@@ -280,25 +452,39 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn32_fwd_kernel(AttnP p) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const short8 pb = pack8(x[kk][8 * s], x[kk][8 * s + 1], x[kk][8 * s + 2], x[kk][8 * s + 3],
-                                            x[kk][8 * s + 4], x[kk][8 * s + 5], x[kk][8 * s + 6], x[kk][8 * s + 7]);
+                for (int s = 0; s < 2; ++s)
+                    pb[kk][s] = pack8(xv[kk][4 * s][0], xv[kk][4 * s][1], xv[kk][4 * s + 1][0], xv[kk][4 * s + 1][1],
+                                      xv[kk][4 * s + 2][0], xv[kk][4 * s + 2][1], xv[kk][4 * s + 3][0], xv[kk][4 * s + 3][1]);
+            if constexpr (PREV) {                                           // the V fragments of the coming matrix segment: in flight across the barrier
+                const unsigned char* vn = smem + (t & 3) * STAGE + TILE;
 #pragma unroll
-                    for (int db = 0; db < NDB; ++db) o[db] = mfma32(W::fragT(vs, kk * 32 + 16 * s, db, lane), pb, o[db]);
-                }
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+#pragma unroll
+                        for (int db = 0; db < NDB; ++db) vfr[(kk * 2 + s) * NDB + db] = W::fragT(vn, kk * 32 + 16 * s, db, lane);
+            }
         }
-        st = st == 2 ? 0 : st + 1;
+        if (CTMI_W32_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+        if (grp == 0 && t + 1 < ntiles) { if (t + 2 < ntiles) wait_vm<2 * NPC>(); else wait_vm<0>(); }   // own pieces of tile t+1
+        W32_TICK(tY);
+        bar();
+        W32_TICK(tBY);
     }
+    if (grp == 0) bar();                                                    // group B's last matrix segment: the ring is free after this one
     lsum = pair_sum(lsum);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                           // every wave is done with the ring: reuse it as store patches
     if (active) {
         bf16_t* op = reinterpret_cast<bf16_t*>(p.out) + b * p.o_bs + h * p.o_hs + (int64_t)q0w * p.o_rs;
         store_tile32<HD>(o, 1.0f / lsum, op, p.o_rs, smem + wid * 32 * (HD * 2 + 16), lane);
         if (hi == 0) {
             const int64_t srow = (b * p.nh + h) * p.Sq + q0w + l32;
-            p.stat_m[srow] = m <= FINFO_MIN ? FINFO_MIN : m * LN2_F;
+            p.stat_m[srow] = m <= FINFO_MIN ? FINFO_MIN : m * p.scale;
             p.stat_l[srow] = lsum;
+#if CTMI_W32_TIMING
+            const uint32_t tot = (uint32_t)(__builtin_amdgcn_s_memtime() - tbeg);
+            const uint32_t v[8] = {tX, tY, tBX, tBY, tPro, tot, (uint32_t)ntiles, (uint32_t)(my_last + 1)};
+            if (l32 < 8) p.stat_l[srow] = (float)v[l32];
+#endif
         }
     }
 }
@@ -377,6 +563,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn32_dq_kernel(AttnP p) {
     dl = pair_sum(dl);
     if (active && hi == 0) p.delta[srow] = dl;
     __syncthreads();
+#pragma unroll
+    for (int ds = 0; ds < NDS; ++ds) { pin(qf[ds]); pin(gf[ds]); }
+    pin(m2); pin(il); pin(dl);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // the delta store as well: nothing of the prologue may be pending in the loop
 
     f32x16 dq[NDB];
 #pragma unroll
@@ -524,8 +714,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn32_dkdv_kernel(AttnP p) {
         for (int ds = 0; ds < NDS; ++ds) { kf[ds] = short8{0, 0, 0, 0, 0, 0, 0, 0}; vf[ds] = kf[ds]; }
     }
     const float ff2 = p.future_fill <= FINFO_MIN ? FINFO_MIN : p.future_fill * LOG2E_F;
-    const float lane_fill = key_pad ? FINFO_MIN : ff2;                      // what a masked score of this lane's key is replaced by
+    float lane_fill = key_pad ? FINFO_MIN : ff2;                            // what a masked score of this lane's key is replaced by
     __syncthreads();
+#pragma unroll
+    for (int ds = 0; ds < NDS; ++ds) { pin(kf[ds]); pin(vf[ds]); }
+    pin(kb_lane); pin(lane_fill);
 
     f32x16 dk[NDB], dv[NDB];
 #pragma unroll
@@ -628,7 +821,7 @@ void launch32(K kern, int64_t grid, int threads, size_t lds, hipStream_t st, con
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, st, p);
 }
-template <int HD, int NW> size_t lds_kv(const AttnP& p) { return 3 * (size_t)(2 * WT<HD, NW>::TILE) + 4 * (size_t)p.Sk; }
+template <int HD, int NW> size_t lds_kv(const AttnP& p, int nst = 3) { return nst * (size_t)(2 * WT<HD, NW>::TILE) + 4 * (size_t)p.Sk; }
 template <int HD, int NW> size_t lds_qg(const AttnP& p) { return 3 * (size_t)(2 * WT<HD, NW>::TILE) + 12 * (size_t)p.Sq; }
 
 }  // namespace
@@ -642,8 +835,8 @@ extern "C" int ctmi_attn_set_path(int mask) {
 int ctmi_attn32_fwd(const AttnP& p, hipStream_t st) {
     if (!w32_ok(p) || !(w32_mask() & 1)) return 0;
     const int64_t BH = p.B * p.nh;
-    if (p.hd == 64) launch32(&attn32_fwd_kernel<64, 8>, ((p.Sq + 255) / 256) * BH, 512, lds_kv<64, 8>(p), st, p);
-    else launch32(&attn32_fwd_kernel<128, 8>, ((p.Sq + 255) / 256) * BH, 512, lds_kv<128, 8>(p), st, p);
+    if (p.hd == 64) launch32(&attn32_fwd_kernel<64, 8>, ((p.Sq + 255) / 256) * BH, 512, lds_kv<64, 8>(p, 4), st, p);
+    else launch32(&attn32_fwd_kernel<128, 8>, ((p.Sq + 255) / 256) * BH, 512, lds_kv<128, 8>(p, 4), st, p);
     return 1;
 }
 

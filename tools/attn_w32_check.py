@@ -118,7 +118,11 @@ def timeit(fn, iters=20, warm=3):
 
 
 def time_():
-    for B, S, nh, hd in ((8, 1024, 16, 64), (4, 2048, 16, 64), (4, 2048, 32, 128)):
+    cases = ((8, 1024, 16, 64), (4, 2048, 16, 64), (4, 2048, 32, 128))
+    if os.environ.get("W32_CASES"):
+        cases = tuple(cases[int(i)] for i in os.environ["W32_CASES"].split(","))
+    paths = tuple(int(x) for x in os.environ.get("W32_PATHS", "0,3,0,3").split(","))
+    for B, S, nh, hd in cases:
         H, T = nh * hd, B * S
         qkv = (torch.randn(T, 3 * H, device=DEV) * 0.5).to(BF)
         go = (torch.randn(T, H, device=DEV) * 0.5).to(BF)
@@ -128,7 +132,7 @@ def time_():
         out = torch.empty((T, H), dtype=BF, device=DEV)
         dq = torch.zeros_like(qkv)
         fl = 4.0 * B * nh * S * S * hd / 2
-        for path in (0, 3, 0, 3):
+        for path in paths:
             ops.set_attn_path(path)
             sm, sl = ops.attn_fwd(qkv, qkv[:, hd:], qkv[:, 2 * hd:], out, desc, slopes, mask)
             tf = timeit(lambda: ops.attn_fwd(qkv, qkv[:, hd:], qkv[:, 2 * hd:], out, desc, slopes, mask))
