@@ -35,10 +35,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8_w32 __attribute__((ext_vector_type(8)));
 typedef short short4_w32 __attribute__((ext_vector_type(4)));
 
-// forward, head_dim 64: cap the registers at 128 so that TWO 8-wave workgroups share a CU (4 waves per SIMD from two workgroups that
-// are not coupled by a barrier)
-#ifndef CTMI_W32_FWD_2WG
-#define CTMI_W32_FWD_2WG 1
+// forward: 4-wave workgroups (128 query rows), three per CU at head_dim 64 (168 registers, 3 waves per SIMD from workgroups that no
+// barrier couples); K/V ring depth 2 (40 KiB of LDS per workgroup at S = 1024: three fit)
+#ifndef CTMI_W32_FWD_NW
+#define CTMI_W32_FWD_NW 4
+#endif
+#ifndef CTMI_W32_FWD_NST
+#define CTMI_W32_FWD_NST 2
+#endif
+// backward, head_dim 64: 4-wave workgroups too — dQ three per CU (168 registers), dK/dV two per CU (256 registers)
+#ifndef CTMI_W32_BWD_NW
+#define CTMI_W32_BWD_NW 4
+#endif
+#ifndef CTMI_W32_BWD_NST
+#define CTMI_W32_BWD_NST 2
 #endif
 // forward: log2 of the growth of a row maximum that is tolerated before O / l are rescaled (0 = rescale whenever a maximum moved)
 #ifndef CTMI_W32_DEFER_MAX
@@ -201,31 +211,25 @@ __device__ __forceinline__ void fill4_future(f32x16& v, int thr, float fill) {
     v[R0] = a; v[R0 + 1] = b; v[R0 + 2] = c; v[R0 + 3] = d;
 }
 
-// Ping-pong schedule (8 waves).  Every SIMD holds one wave of group A (waves 0-3) and one of group B (waves 4-7).  A tile's work
-// of one wave is cut into a MATRIX segment X(t) = { O += P(t-1) V(t-1) ; S(t) = K(t) Q^T + key bias } (16 MFMAs + their LDS fragment
-// reads, no VALU) and a VECTOR segment Y(t) = { softmax of S(t) -> P(t), prefetch of the V(t) fragments } (no MFMA); group B runs one
-// segment behind group A and a barrier closes every segment, so while one wave of a SIMD owns the matrix pipe its partner owns
-// the VALU.  Measured anatomy that led here (tools/attn_w32_timing.py, s_memtime per wave): with one wave of a SIMD in a segment
-// nothing hides a dependent instruction or an LDS round trip of that wave, so
-//   * every fragment read of a matrix segment is issued before its first MFMA (the V fragments already at the end of the vector
-//     segment before), the per-key bias arrives as the C operand of the first score MFMA (no bias reads, no add in Y);
-//   * the vector segment is one v_pk_fma (x*c - m*c) + one exp2 per score pair, row max and row sum in four independent chains.
-//   barriers   A:      X(0) b0 Y(0) b1 X(1) b2 ... Y(n-1) b X(n) b  b          B:  b0 X(0) b1 Y(0) b2 ... X(n) b
-//   K/V ring   4 stages.  Tile t+2 is issued at the start of Y(t); tile t is read in X(t) (K), Y(t) and X(t+1) (V) of both groups, i.e.
-//              until two segments after A's Y(t) — the slot of tile t+2 (= tile t-2) was last read in B's X(t-1), one barrier earlier.
-//              Every wave waits for its own pieces of tile t+1 before the barrier that ends the segment preceding A's X(t+1).
-// Scores are kept in units of 1/scale ("raw": q.k + bias/scale) until the exponent: p = exp2(raw*c - max*c), c = scale*log2(e).
+// Schedule.  Measured on this chip (profiles/r03_valu_issue_probe.txt, tools/attn_w32_timing.py): ONE wave issues at most one VALU
+// instruction per ~5 cycles while a SIMD retires one per ~2.35 when two or more of its waves are in vector code; packed fp32
+// (v_pk_*_f32) runs at 12.9 cycles per instruction beside a wave that issues MFMAs (scalar fp32 VALU is untouched by it); a
+// matrix/vector ping-pong of the two waves of a SIMD therefore runs its vector segment at a third of the SIMD's VALU rate (built
+// and measured: slower than the plain loop).  So: a plain loop, one barrier per tile, and FOUR waves per SIMD — two 8-wave
+// workgroups per CU that no barrier couples (head_dim 64: 128 registers) — so that while one wave waits for its MFMAs the others
+// issue VALU; every fp32 operation scalar (this file is built with -fno-slp-vectorize: hipcc would pack adjacent adds and
+// multiplies); the instruction count per score cut to the bone:
+//   * the per-key bias enters as the C operand of the first score MFMA (no bias add),
+//   * scores stay in units of 1/scale ("raw") and p = exp2(raw*c - max*c), c = scale*log2(e): ONE fma + ONE exp2 per score,
+//   * the future-key fill is four compares into SGPR pairs + four selects per four scores (no VCC round trips).
 template <int HD, int NW>
-__global__ __launch_bounds__(NW * 64, NW / 4) void attn32_fwd_kernel(AttnP p) {
-    static_assert(NW == 8, "the ping-pong schedule pairs waves w and w + 4 on one SIMD");
+__global__ __launch_bounds__(NW * 64, NW == 4 ? (HD == 64 ? 3 : 2) : NW / 4) void attn32_fwd_kernel(AttnP p) {
     using W = WT<HD, NW>;
-    constexpr int NDS = HD / 16, NDB = HD / 32, TILE = W::TILE, STAGE = 2 * TILE, NPC = W::NPC, RPB = 32 * NW, NST = 4;
-    constexpr bool PREV = HD == 64;                                          // V fragments prefetched a segment ahead (register budget)
+    constexpr int NDS = HD / 16, NDB = HD / 32, TILE = W::TILE, STAGE = 2 * TILE, NPC = W::NPC, RPB = 32 * NW, NST = CTMI_W32_FWD_NST;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* kbS = reinterpret_cast<float*>(smem + NST * STAGE);              // per-key bias / scale  (finfo.min: padding key)
     const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, hi = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wid >> 2;
     const int rbw = row_block<NW>(wid);
     const int BH = (int)(p.B * p.nh), nqb = (int)((p.Sq + RPB - 1) / RPB);
     const int vid = blockIdx.x;
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn32_fwd_kernel(AttnP p) {
         for (int j = 0; j < NPC; ++j) { dma16(pv[j], d + TILE + j * 1024); pv[j] += vstep; }
     };
     issue(0);
-    if (ntiles > 1) issue(1);
+    if (NST >= 3 && ntiles > 1) issue(1);
 
     const float slope_r = p.slopes ? p.slopes[h] / p.scale : 0.f;
     for (int key = tid; key < kv_end; key += NW * 64) {
@@ -273,9 +277,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn32_fwd_kernel(AttnP p) {
     __syncthreads();
 #pragma unroll
     for (int ds = 0; ds < NDS; ++ds) pin(qf[ds]);
-    if (ntiles > 1) wait_vm<2 * NPC>(); else wait_vm<0>();                  // own pieces of tile 0
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
 
     f32x16 o[NDB];
 #pragma unroll
@@ -285,98 +286,38 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn32_fwd_kernel(AttnP p) {
     float m = -INFINITY, lsum = 0.f;                                         // m in raw units
     const float c = p.scale * LOG2E_F;
     const float ffr = p.future_fill <= FINFO_MIN ? FINFO_MIN : p.future_fill / p.scale;
-    f32x16 x[2];
-    short8 pb[2][2];
-    short8 vfr[PREV ? 4 * NDB : 1];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { x[0][r] = 0.f; x[1][r] = 0.f; }
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) pb[kk][s] = short8{0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int i = 0; i < (PREV ? 4 * NDB : 1); ++i) vfr[i] = short8{0, 0, 0, 0, 0, 0, 0, 0};
-    auto bar = [&]() {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("" ::: "memory");
-    };
 #if CTMI_W32_TIMING
     uint32_t tX = 0, tY = 0, tBX = 0, tBY = 0, tPro = 0;
     uint64_t tlast = __builtin_amdgcn_s_memtime();
     const uint64_t tbeg = tlast;
 #endif
-    if (grp == 1) bar();
-    W32_TICK(tPro);
-    for (int t = 0;; ++t) {
-        // ---- X(t): matrix segment
-        const bool do_pv = t > 0 && t - 1 <= my_last, do_qk = t < ntiles && t <= my_last;
-        const unsigned char* ks = smem + (t & 3) * STAGE;
-        const unsigned char* vs = smem + ((t - 1) & 3) * STAGE + TILE;
-        short8 kfr[PREV ? 2 * NDS : 1];
-        if constexpr (PREV) {
-            if (do_qk) {                                                     // every read of the segment goes out before its first MFMA
-#pragma unroll
-                for (int ds = 0; ds < NDS; ++ds) { kfr[2 * ds] = W::fragA(ks, l32, ds * 2 + hi); kfr[2 * ds + 1] = W::fragA(ks, 32 + l32, ds * 2 + hi); }
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const f32x4 kb4 = *reinterpret_cast<const f32x4*>(kbS + t * 64 + kk * 32 + 8 * j + 4 * hi);
-                        x[kk][4 * j] = kb4[0]; x[kk][4 * j + 1] = kb4[1]; x[kk][4 * j + 2] = kb4[2]; x[kk][4 * j + 3] = kb4[3];
-                    }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (CTMI_W32_PRIO == 1) __builtin_amdgcn_s_setprio(1);
-        if (do_pv) {
+    int st = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        // ring of NST stages, NST - 1 tiles in flight: tile t + NST - 1 goes out right after the barrier that retires tile t - 1
+        if (NST >= 3 && t + 1 < ntiles) wait_vm<2 * NPC>(); else wait_vm<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        W32_TICK(tY);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        W32_TICK(tBX);
+        if (t + NST - 1 < ntiles) issue(st == 0 ? NST - 1 : st - 1);
+        if (t <= my_last) {
+            const unsigned char* ks = smem + st * STAGE;
+            const unsigned char* vs = ks + TILE;
+            const int kv0 = t * 64;
+            f32x16 x[2];
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int db = 0; db < NDB; ++db) {
-                        if constexpr (PREV) o[db] = mfma32(vfr[(kk * 2 + s) * NDB + db], pb[kk][s], o[db]);
-                        else o[db] = mfma32(W::fragT(vs, kk * 32 + 16 * s, db, lane), pb[kk][s], o[db]);
-                    }
-        }
-        if (do_qk) {
-            if constexpr (!PREV) {
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const f32x4 kb4 = *reinterpret_cast<const f32x4*>(kbS + t * 64 + kk * 32 + 8 * j + 4 * hi);
-                        x[kk][4 * j] = kb4[0]; x[kk][4 * j + 1] = kb4[1]; x[kk][4 * j + 2] = kb4[2]; x[kk][4 * j + 3] = kb4[3];
-                    }
-            }
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 kb4 = *reinterpret_cast<const f32x4*>(kbS + kv0 + kk * 32 + 8 * j + 4 * hi);
+                    x[kk][4 * j] = kb4[0]; x[kk][4 * j + 1] = kb4[1]; x[kk][4 * j + 2] = kb4[2]; x[kk][4 * j + 3] = kb4[3];
+                }
 #pragma unroll
             for (int ds = 0; ds < NDS; ++ds) {
-                if constexpr (PREV) {
-                    x[0] = mfma32(kfr[2 * ds], qf[ds], x[0]);
-                    x[1] = mfma32(kfr[2 * ds + 1], qf[ds], x[1]);
-                } else {
-                    x[0] = mfma32(W::fragA(ks, l32, ds * 2 + hi), qf[ds], x[0]);
-                    x[1] = mfma32(W::fragA(ks, 32 + l32, ds * 2 + hi), qf[ds], x[1]);
-                }
+                x[0] = mfma32(W::fragA(ks, l32, ds * 2 + hi), qf[ds], x[0]);   // raw score = q.k + bias/scale (padding: finfo.min absorbs the dot)
+                x[1] = mfma32(W::fragA(ks, 32 + l32, ds * 2 + hi), qf[ds], x[1]);
             }
-        }
-        if (CTMI_W32_PRIO == 1) __builtin_amdgcn_s_setprio(0);
-        if (grp == 1 && t + 1 < ntiles) wait_vm<0>();                       // own pieces of tile t+1 (issued at the start of Y(t-1))
-        W32_TICK(tX);
-        bar();
-        W32_TICK(tBX);
-        if (t == ntiles) break;
-        // ---- Y(t): vector segment
-        if (t + 2 < ntiles) issue((t + 2) & 3);
-        if (CTMI_W32_PRIO == 2) __builtin_amdgcn_s_setprio(1);
-        if (t <= my_last) {
-            // The vector segment is bound by VALU issue and by the latency of dependent instructions (its SIMD partner is in a matrix
-            // segment), so the arithmetic is on float2 values (v_pk_fma / v_pk_add / v_pk_mul_f32: one issue slot per TWO elements)
-            // and the reductions run in four independent chains.
-            const int kv0 = t * 64;
             if (kv0 + 63 > q0w) {                                          // the tile holds (query, key) pairs in the causal future
                 const int thr = q0w + l32 - kv0 - 4 * hi;                   // key offset cc = kk*32 + 8*(r>>2) + (r&3) is in the future iff cc > thr
                 if (ffr <= FINFO_MIN) {
@@ -412,36 +353,37 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn32_fwd_kernel(AttnP p) {
             }
             const float alpha = __builtin_amdgcn_exp2f((m - m_new) * c);
             const float mc = m_new * c;
-            f32x2 xv[2][8];
             if (allk) {
                 // a row may be all-masked here: its scores AND its maximum are finfo.min and the exponent must be exactly 0 — the two
                 // products are formed separately (identical roundings cancel); the fused form below would leave the rounding error
                 // of finfo.min * c, which is astronomically large
-#pragma clang fp contract(off)
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const f32x2 pr = f32x2{x[kk][2 * i], x[kk][2 * i + 1]} * c;
-                        xv[kk][i] = pr - mc;
+                    for (int r = 0; r < 16; ++r) {
+                        float pr;
+                        asm("v_mul_f32 %0, %1, %2\n\tv_sub_f32 %0, %0, %3" : "=&v"(pr) : "v"(x[kk][r]), "v"(c), "v"(mc));
+                        x[kk][r] = __builtin_amdgcn_exp2f(pr);
                     }
             } else {
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) xv[kk][i] = f32x2{x[kk][2 * i], x[kk][2 * i + 1]} * c - mc;    // one v_pk_fma_f32
+                    for (int r = 0; r < 16; ++r) x[kk][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(x[kk][r], c, -mc));
             }
-            f32x2 rs[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+            // row sums as plain fp32 adds in four chains (v_dot2c_f32_bf16 against (1, 1) on the packed values was built and measured:
+            // 16 instead of 32 instructions, but 41.7 vs 38.8 us — the dot instruction costs several issue slots)
+            float rs[4] = {x[0][0], x[0][1], x[1][0], x[1][1]};
+#pragma unroll
+            for (int r = 2; r < 16; r += 2) { rs[0] += x[0][r]; rs[1] += x[0][r + 1]; rs[2] += x[1][r]; rs[3] += x[1][r + 1]; }
+            short8 pb[2][2];
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const f32x2 e = {__builtin_amdgcn_exp2f(xv[kk][i][0]), __builtin_amdgcn_exp2f(xv[kk][i][1])};
-                    xv[kk][i] = e;
-                    rs[(kk * 8 + i) & 3] += e;
-                }
-            const f32x2 rsum = (rs[0] + rs[1]) + (rs[2] + rs[3]);
-            lsum = lsum * alpha + (rsum[0] + rsum[1]);
+                for (int s = 0; s < 2; ++s)
+                    pb[kk][s] = pack8(x[kk][8 * s], x[kk][8 * s + 1], x[kk][8 * s + 2], x[kk][8 * s + 3],
+                                      x[kk][8 * s + 4], x[kk][8 * s + 5], x[kk][8 * s + 6], x[kk][8 * s + 7]);
+            lsum = __builtin_fmaf(lsum, alpha, (rs[0] + rs[1]) + (rs[2] + rs[3]));
             if (__any(m_new > m)) {                                          // wave-uniform: rescale only when some row max moved
 #pragma unroll
                 for (int db = 0; db < NDB; ++db)
@@ -453,26 +395,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn32_fwd_kernel(AttnP p) {
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
-                    pb[kk][s] = pack8(xv[kk][4 * s][0], xv[kk][4 * s][1], xv[kk][4 * s + 1][0], xv[kk][4 * s + 1][1],
-                                      xv[kk][4 * s + 2][0], xv[kk][4 * s + 2][1], xv[kk][4 * s + 3][0], xv[kk][4 * s + 3][1]);
-            if constexpr (PREV) {                                           // the V fragments of the coming matrix segment: in flight across the barrier
-                const unsigned char* vn = smem + (t & 3) * STAGE + TILE;
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                    for (int s = 0; s < 2; ++s)
-#pragma unroll
-                        for (int db = 0; db < NDB; ++db) vfr[(kk * 2 + s) * NDB + db] = W::fragT(vn, kk * 32 + 16 * s, db, lane);
-            }
+                    for (int db = 0; db < NDB; ++db) o[db] = mfma32(W::fragT(vs, kk * 32 + 16 * s, db, lane), pb[kk][s], o[db]);
         }
-        if (CTMI_W32_PRIO == 2) __builtin_amdgcn_s_setprio(0);
-        if (grp == 0 && t + 1 < ntiles) { if (t + 2 < ntiles) wait_vm<2 * NPC>(); else wait_vm<0>(); }   // own pieces of tile t+1
-        W32_TICK(tY);
-        bar();
-        W32_TICK(tBY);
+        W32_TICK(tX);
+        st = st == NST - 1 ? 0 : st + 1;
     }
-    if (grp == 0) bar();                                                    // group B's last matrix segment: the ring is free after this one
     lsum = pair_sum(lsum);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                           // every wave is done with the ring: reuse it as store patches
     if (active) {
         bf16_t* op = reinterpret_cast<bf16_t*>(p.out) + b * p.o_bs + h * p.o_hs + (int64_t)q0w * p.o_rs;
         store_tile32<HD>(o, 1.0f / lsum, op, p.o_rs, smem + wid * 32 * (HD * 2 + 16), lane);
@@ -493,11 +424,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn32_fwd_kernel(AttnP p) {
 // own rows = queries.  Per key tile: S^T = K Q^T, dP^T = V dO^T (both with the own query in the accumulator column),
 // P = exp2(s2 - m2) / l, dS^T = P (dP^T - delta), masked entries dS = 0;  dQ^T += K^T dS^T.  Also forms delta = rowsum(dO * O).
 template <int HD, int NW>
-__global__ __launch_bounds__(NW * 64, NW / 4) void attn32_dq_kernel(AttnP p) {
+__global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 3 : NW / 4) void attn32_dq_kernel(AttnP p) {
     using W = WT<HD, NW>;
-    constexpr int NDS = HD / 16, NDB = HD / 32, TILE = W::TILE, STAGE = 2 * TILE, NPC = W::NPC, RPB = 32 * NW;
+    constexpr int NDS = HD / 16, NDB = HD / 32, TILE = W::TILE, STAGE = 2 * TILE, NPC = W::NPC, RPB = 32 * NW, NST = CTMI_W32_BWD_NST;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* kbS = reinterpret_cast<float*>(smem + 3 * STAGE);
+    float* kbS = reinterpret_cast<float*>(smem + NST * STAGE);
     const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, hi = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rbw = row_block<NW>(wid);
@@ -532,7 +463,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn32_dq_kernel(AttnP p) {
         for (int j = 0; j < NPC; ++j) { dma16(pv[j], d + TILE + j * 1024); pv[j] += vstep; }
     };
     issue(0);
-    if (ntiles > 1) issue(1);
+    if (NST >= 3 && ntiles > 1) issue(1);
 
     const float slope2 = p.slopes ? p.slopes[h] * LOG2E_F : 0.f;
     for (int key = tid; key < kv_end; key += NW * 64) {
@@ -576,11 +507,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn32_dq_kernel(AttnP p) {
     const float c = p.scale * LOG2E_F;
     int st = 0;
     for (int t = 0; t < ntiles; ++t) {
-        if (t + 1 < ntiles) wait_vm<2 * NPC>(); else wait_vm<0>();
+        if (NST >= 3 && t + 1 < ntiles) wait_vm<2 * NPC>(); else wait_vm<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (t + 2 < ntiles) issue(st == 0 ? 2 : st - 1);
+        if (t + NST - 1 < ntiles) issue(st == 0 ? NST - 1 : st - 1);
         if (active && t <= my_last) {
             const unsigned char* ks = smem + st * STAGE;
             const unsigned char* vs = ks + TILE;
@@ -622,7 +553,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn32_dq_kernel(AttnP p) {
                     for (int db = 0; db < NDB; ++db) dq[db] = mfma32(W::fragT(ks, kk * 32 + 16 * s, db, lane), db8, dq[db]);
                 }
         }
-        st = st == 2 ? 0 : st + 1;
+        st = st == NST - 1 ? 0 : st + 1;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -637,11 +568,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn32_dq_kernel(AttnP p) {
 // dS = P (dP - delta[q]); dV^T += dO^T P, dK^T += Q^T dS.  Masked entries (padding key, causal future): P keeps the fill value's
 // probability (non-zero only in all-masked rows, which are uniform), dS = 0.
 template <int HD, int NW>
-__global__ __launch_bounds__(NW * 64, NW / 4) void attn32_dkdv_kernel(AttnP p) {
+__global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 2 : NW / 4) void attn32_dkdv_kernel(AttnP p) {
     using W = WT<HD, NW>;
-    constexpr int NDS = HD / 16, NDB = HD / 32, TILE = W::TILE, STAGE = 2 * TILE, NPC = W::NPC, RPB = 32 * NW;
+    constexpr int NDS = HD / 16, NDB = HD / 32, TILE = W::TILE, STAGE = 2 * TILE, NPC = W::NPC, RPB = 32 * NW, NST = CTMI_W32_BWD_NST;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* m2S = reinterpret_cast<float*>(smem + 3 * STAGE);                // [Sq] row max in log2 units | [Sq] 1/l | [Sq] delta
+    float* m2S = reinterpret_cast<float*>(smem + NST * STAGE);                // [Sq] row max in log2 units | [Sq] 1/l | [Sq] delta
     float* ilS = m2S + p.Sq;
     float* dlS = ilS + p.Sq;
     const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, hi = lane >> 5;
@@ -678,7 +609,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn32_dkdv_kernel(AttnP p) {
         for (int j = 0; j < NPC; ++j) { dma16(pg[j], d + TILE + j * 1024); pg[j] += gstep; }
     };
     if (nt > 0) issue(0);
-    if (nt > 1) issue(1);
+    if (NST >= 3 && nt > 1) issue(1);
 
     // row statistics of every query this workgroup will stream, converted once (m in log2 units, 1/l, delta): three floats per row
     // in LDS for the lifetime of the workgroup instead of a per-tile restage
@@ -729,11 +660,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn32_dkdv_kernel(AttnP p) {
     int st = 0;
     for (int i = 0; i < nt; ++i) {
         const int t = qt_begin + i;
-        if (i + 1 < nt) wait_vm<2 * NPC>(); else wait_vm<0>();
+        if (NST >= 3 && i + 1 < nt) wait_vm<2 * NPC>(); else wait_vm<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (i + 2 < nt) issue(st == 0 ? 2 : st - 1);
+        if (i + NST - 1 < nt) issue(st == 0 ? NST - 1 : st - 1);
         if (active && t >= my_first) {
             const unsigned char* qs = smem + st * STAGE;
             const unsigned char* gs = qs + TILE;
@@ -786,7 +717,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn32_dkdv_kernel(AttnP p) {
                     }
                 }
         }
-        st = st == 2 ? 0 : st + 1;
+        st = st == NST - 1 ? 0 : st + 1;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -822,7 +753,7 @@ void launch32(K kern, int64_t grid, int threads, size_t lds, hipStream_t st, con
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, st, p);
 }
 template <int HD, int NW> size_t lds_kv(const AttnP& p, int nst = 3) { return nst * (size_t)(2 * WT<HD, NW>::TILE) + 4 * (size_t)p.Sk; }
-template <int HD, int NW> size_t lds_qg(const AttnP& p) { return 3 * (size_t)(2 * WT<HD, NW>::TILE) + 12 * (size_t)p.Sq; }
+template <int HD, int NW> size_t lds_qg(const AttnP& p, int nst = 3) { return nst * (size_t)(2 * WT<HD, NW>::TILE) + 12 * (size_t)p.Sq; }
 
 }  // namespace
 
@@ -835,21 +766,20 @@ extern "C" int ctmi_attn_set_path(int mask) {
 int ctmi_attn32_fwd(const AttnP& p, hipStream_t st) {
     if (!w32_ok(p) || !(w32_mask() & 1)) return 0;
     const int64_t BH = p.B * p.nh;
-    if (p.hd == 64) launch32(&attn32_fwd_kernel<64, 8>, ((p.Sq + 255) / 256) * BH, 512, lds_kv<64, 8>(p, 4), st, p);
-    else launch32(&attn32_fwd_kernel<128, 8>, ((p.Sq + 255) / 256) * BH, 512, lds_kv<128, 8>(p, 4), st, p);
+    constexpr int NW = CTMI_W32_FWD_NW, RPB = 32 * NW;
+    if (p.hd == 64) launch32(&attn32_fwd_kernel<64, NW>, ((p.Sq + RPB - 1) / RPB) * BH, 64 * NW, lds_kv<64, NW>(p, CTMI_W32_FWD_NST), st, p);
+    else launch32(&attn32_fwd_kernel<128, NW>, ((p.Sq + RPB - 1) / RPB) * BH, 64 * NW, lds_kv<128, NW>(p, CTMI_W32_FWD_NST), st, p);
     return 1;
 }
 
 int ctmi_attn32_bwd(const AttnP& p, hipStream_t st) {
-    if (!w32_ok(p) || !(w32_mask() & 2)) return 0;
+    // head_dim 128: the 32-row accumulators of the backward (dK^T and dV^T: 128 registers) leave one wave per SIMD, and the general
+    // 16-row kernels are faster there (B=4 S=2048 nh=32: 797 vs 915 us) — only the forward takes this path at head_dim 128
+    if (!w32_ok(p) || !(w32_mask() & 2) || p.hd != 64) return 0;
     const int64_t BH = p.B * p.nh;
     // dQ first: it also publishes delta = rowsum(dO * O) for the dK/dV kernel (same stream: ordered)
-    if (p.hd == 64) {
-        launch32(&attn32_dq_kernel<64, 8>, ((p.Sq + 255) / 256) * BH, 512, lds_kv<64, 8>(p), st, p);
-        launch32(&attn32_dkdv_kernel<64, 8>, ((p.Sk + 255) / 256) * BH, 512, lds_qg<64, 8>(p), st, p);
-    } else {
-        launch32(&attn32_dq_kernel<128, 4>, ((p.Sq + 127) / 128) * BH, 256, lds_kv<128, 4>(p), st, p);
-        launch32(&attn32_dkdv_kernel<128, 4>, ((p.Sk + 127) / 128) * BH, 256, lds_qg<128, 4>(p), st, p);
-    }
+    constexpr int NW = CTMI_W32_BWD_NW, RPB = 32 * NW, NST = CTMI_W32_BWD_NST;
+    launch32(&attn32_dq_kernel<64, NW>, ((p.Sq + RPB - 1) / RPB) * BH, 64 * NW, lds_kv<64, NW>(p, NST), st, p);
+    launch32(&attn32_dkdv_kernel<64, NW>, ((p.Sk + RPB - 1) / RPB) * BH, 64 * NW, lds_qg<64, NW>(p, NST), st, p);
     return 1;
 }

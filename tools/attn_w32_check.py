@@ -90,7 +90,7 @@ def check():
         e_m = float((m1 - m0)[fin].abs().max()) if fin.any() else 0.0
         same_min = bool(((m1 <= FMIN) == (m0 <= FMIN)).all())
         e_l = float(((l1 - l0).abs() / l0).max())
-        ok = e_new[0][1] <= max(2.5 * e_old[0][1], 8e-3) and e_new[1][1] <= max(2.5 * e_old[1][1], 1.6e-2) and e_m < 1e-3 and e_l < 1e-3 and same_min
+        ok = e_new[0][1] <= max(2.5 * e_old[0][1], 8e-3) and e_new[1][1] <= max(2.5 * e_old[1][1], 1.6e-2) and e_m < 1e-3 and e_l < 1e-3 and same_min   # (l: both families sum the unrounded probabilities)
         ok = ok and bool(torch.isfinite(o1).all()) and bool(torch.isfinite(g1).all())
         bad += 0 if ok else 1
         print(f"{'OK ' if ok else 'BAD'} B={B} S={S} nh={nh} hd={hd} {kind:5s} fill={fill:g}: out rel err new {e_new[0][1]:.2e} old {e_old[0][1]:.2e} | "
