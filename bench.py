@@ -127,57 +127,79 @@ def cpu_baseline(mode="full"):
             "samples": samples}
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--seq", type=int, default=1024)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", default="full", choices=["full", "short"], help="short: skip the 24-layer S=1024 CPU sample")
-    args = ap.parse_args()
+    ap.add_argument("--comm-dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="N > 1: wire dtype of the gradient buckets (bf16 halves the xGMI bytes; gradients then carry bf16 rounding)")
+    ap.add_argument("--no-breakdown", action="store_true", help="skip the per-class HIP-event pass after the timed region")
+    ap.add_argument("--no-padded-sample", action="store_true", help="skip the secondary sample with 25 %% of every row right-padded")
+    args = ap.parse_args(argv)
 
-    global V, L
-    plumbing = os.environ.get("CTMI_BENCH_PLUMBING")          # tests only: "layers,vocab" shrinks the model so the N>1 code path of this
-    if plumbing:                                               # file can be executed on a one-GPU box (the JSON line is marked, never a result)
-        L, V = (int(x) for x in plumbing.split(","))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
-    if os.environ.get("CTMI_BENCH_ONE_DEVICE"):            # plumbing test only: all ranks share cuda:0 (with gloo)
-        local_rank = 0
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("CTMI_GEMM_SHARED", "1")     # RCCL kernels share the CUs under backward
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(os.environ.get("CTMI_DIST_BACKEND", "nccl"))       # "nccl" == RCCL on ROCm
+        dist.init_process_group("nccl")                    # "nccl" == RCCL on ROCm
 
     from cleantransformer_amd import ops
+    from cleantransformer_amd.models import modeling_bloom
     from cleantransformer_amd.optimizer import AdamW
     from cleantransformer_amd.trainer.ddp import DistributedDataParallel as DDP
 
     B, S = args.batch, args.seq
     model = build_model(device, args.dtype)
-    net = DDP(model, device_ids=[local_rank]) if world > 1 else model
+    comm_dtype = torch.bfloat16 if args.comm_dtype == "bf16" else None
+    net = DDP(model, device_ids=[local_rank], comm_dtype=comm_dtype) if world > 1 else model
     opt = AdamW(net.parameters(), lr=1e-5, weight_decay=0.01, decoupled=True)      # == torch.optim.AdamW(lr=1e-5), ft_bloom.py:70
     g = torch.Generator(device=device).manual_seed(999 + rank)                       # per-rank data seed
     ids = torch.randint(0, V, (B, S), generator=g, device=device)
     am = torch.ones(B, S, dtype=torch.long, device=device)
     labels = ids.clone()
+    batch = {"ids": ids, "am": am, "labels": labels}
 
     def step():
-        outputs, _ = net(input_ids=ids, attention_mask=am, labels=labels)
+        outputs, _ = net(input_ids=batch["ids"], attention_mask=batch["am"], labels=batch["labels"])
         loss = outputs[0]
         opt.zero_grad()
         loss.backward()
         opt.step()
         return loss
+
+    def timed_steps(n):
+        """n steps between barrier + synchronize brackets; per-step device time from HIP events on the compute stream.
+        -> (wall seconds of the bracketed region, per-step milliseconds, host loop seconds, last loss)"""
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        t0 = time.perf_counter()
+        ev[0].record()
+        for i in range(n):
+            loss_ = step()
+            ev[i + 1].record()
+        host = time.perf_counter() - t0                                      # host loop time inside the timed region (back-pressured)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        return wall, [ev[i].elapsed_time(ev[i + 1]) for i in range(n)], host, loss_
 
     for _ in range(args.warmup):
         loss = step()
@@ -191,27 +213,52 @@ def main():
     host_enqueue_ms = (time.perf_counter() - h0) / 2 * 1e3
     timer = ops.KernelTimer(["lm_head_fwd"])
     ops.set_timer(timer)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    host_loop_ms = (time.perf_counter() - t0) / args.steps * 1e3         # host loop time inside the timed region (back-pressured)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt, per_step_ms, host_loop_s, loss = timed_steps(args.steps)
     ops.set_timer(None)
     final_loss = float(loss.detach())
+    med_ms = sorted(per_step_ms)[len(per_step_ms) // 2]
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        tt = torch.tensor([dt, med_ms], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt)
-    ms_per_step = dt / args.steps * 1e3
-    tokens_per_s = world * B * S * args.steps / dt
+        dt, med_ms = float(tt[0]), float(tt[1])
+    mean_ms = dt / args.steps * 1e3
+    tokens_per_s = world * B * S / (med_ms * 1e-3)                       # median of the timed steps (max over ranks)
+
+    # ---- per-class device time of one step (HIP-event brackets inside the library; side stream off so that brackets do not overlap)
+    breakdown = None
+    if not args.no_breakdown:
+        side = modeling_bloom._WGRAD_SIDE_STREAM
+        modeling_bloom._WGRAD_SIDE_STREAM = False
+        step()
+        torch.cuda.synchronize()
+        ops.profile_begin()
+        nb = 3
+        for _ in range(nb):
+            step()
+        prof = ops.profile_end()
+        modeling_bloom._WGRAD_SIDE_STREAM = side
+        breakdown = {"note": f"sum of HIP-event brackets per class over {nb} extra steps with the weight-gradient side stream off, ms per step; "
+                             "brackets include launch gaps inside a library call; 'launches' = library calls per step",
+                     "ms": {k: round(v[0] / nb, 3) for k, v in prof.items()}, "launches": {k: v[1] // nb for k, v in prof.items()}}
+        breakdown["ms_total"] = round(sum(breakdown["ms"].values()), 3)
+
+    # ---- secondary sample (SURVEY §8(d) "Synthetic inputs"): 25 % of every row right-padded
+    padded = None
+    if not args.no_padded_sample:
+        am_p = am.clone()
+        am_p[:, (S * 3) // 4:] = 0
+        batch["am"] = am_p
+        for _ in range(2):
+            step()
+        _, ps_ms, _, _ = timed_steps(max(5, args.steps // 2))
+        batch["am"] = am
+        pm = sorted(ps_ms)[len(ps_ms) // 2]
+        if world > 1:
+            tp = torch.tensor([pm], dtype=torch.float64, device=device)
+            dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+            pm = float(tp[0])
+        padded = {"mask": "last 25 % of every row padded (attention_mask = 0), labels unchanged", "ms_per_step": round(pm, 3),
+                  "tokens_per_s": round(world * B * S / (pm * 1e-3), 1), "steps": len(ps_ms)}
 
     if rank == 0:
         f_tok = flops_per_token(S)
@@ -222,23 +269,30 @@ def main():
         head_tflops = head_flops / (head_avg * 1e-3) / 1e12 if head_avg > 0 else 0.0
         out = {
             "metric": "SFT tokens/sec/step Bloom-560M bf16", "value": round(tokens_per_s, 1), "unit": "tokens/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(med_ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"Bloom-560M ({L}L, H=1024, nh=16, V={V}) SFT step fwd+bwd+AdamW, B={B} S={S} per GPU "
                                    f"(BASELINE configs[1]), random-init weights, fp32 master/grads/Adam state",
-                       "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}"},
+                       "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}",
+                       "comm_dtype": args.comm_dtype if world > 1 else None, "padded_sample": padded},
+            "timing": {"value_from": "median of the per-step HIP-event times of the timed steps (max over ranks)",
+                       "ms_per_step_median": round(med_ms, 3), "ms_per_step_mean_wall": round(mean_ms, 3),
+                       "ms_per_step_min": round(min(per_step_ms), 3), "ms_per_step_max": round(max(per_step_ms), 3),
+                       "wall_s_timed_region": round(dt, 4)},
             "final_loss": round(final_loss, 4), "host_enqueue_ms_per_step": round(host_enqueue_ms, 2),
-            "host_loop_ms_per_step_in_timed_region": round(host_loop_ms, 2),
-            "roofline": {"bound": "mfma", "kernel": "gemm_glds_kernel<bf16,NT,256x256 ping-pong> LM-head forward [T,1024]x[250880,1024]^T",
-                         "achieved": round(head_tflops, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(head_tflops / PEAK_BF16_TFLOPS, 4), "traffic": _profiled_traffic(),
-                         "avg_launch_ms": round(head_avg, 4), "launches": len(head_ms),
-                         "step_achieved": round(step_tflops, 1), "step_frac": round(step_tflops / PEAK_BF16_TFLOPS, 4),
-                         "flops_per_token": f_tok},
+            "host_loop_ms_per_step_in_timed_region": round(host_loop_s / args.steps * 1e3, 2),
+            # the step-level fraction — algorithmic FLOPs of the whole step (6 N_mm + 6 L S H per token, attention
+            # causal-half) over the step time, against the dense bf16 MFMA peak.  The largest single launch is a sub-entry.
+            "roofline": {"bound": "mfma", "kernel": "whole SFT step (all kernels; F_tok = 6*N_mm + 6*L*S*H)",
+                         "achieved": round(step_tflops, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(step_tflops / PEAK_BF16_TFLOPS, 4), "traffic": None, "flops_per_token": f_tok,
+                         "largest_launch": {"kernel": "gemm_glds_kernel<bf16,NT,256x256 ping-pong> LM-head forward [T,1024]x[250880,1024]^T",
+                                            "achieved": round(head_tflops, 1), "frac": round(head_tflops / PEAK_BF16_TFLOPS, 4),
+                                            "avg_launch_ms": round(head_avg, 4), "launches": len(head_ms),
+                                            "traffic_bytes_per_launch": _profiled_traffic(),
+                                            "algorithmic_bytes_per_launch": 2.0 * (B * S * H + V * H + B * S * V)},
+                         "breakdown_ms_per_step": breakdown},
         }
-        if plumbing:
-            out["metric"] = "PLUMBING RUN (not a measurement): " + out["metric"]
-            out["config"]["plumbing_override"] = {"layers": L, "vocab": V, "one_device": bool(os.environ.get("CTMI_BENCH_ONE_DEVICE"))}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_baseline)
         print(json.dumps(out), flush=True)

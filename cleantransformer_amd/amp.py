@@ -24,9 +24,31 @@ import torch
 from . import ops
 
 
+_warned_default = False
+
+
 @contextlib.contextmanager
-def autocast(*args, **kwargs):
-    """``torch.cuda.amp.autocast()`` stand-in for the reference's loop (ft_bloom_DDP.py:122): precision is a model property here."""
+def autocast(device_type=None, dtype=None, enabled=True, cache_enabled=None):
+    """``torch.cuda.amp.autocast()`` stand-in for the reference's loop (ft_bloom_DDP.py:122).  Precision is a MODEL property here
+    (``config.compute_dtype``: "bf16" or "fp32"; fp32 master weights, gradients and statistics either way) and the fused kernels
+    do not dispatch through torch's autocast, so the context changes nothing — and says what it cannot do instead of silently
+    ignoring it: the kernels have no fp16 path (the reference's default autocast dtype on a GPU, with its fp16 -> fp32 score
+    upcast at modeling_bloom.py:106-107), so
+      * ``autocast(dtype=torch.float16)`` raises;
+      * ``autocast()`` with the default dtype (what ft_bloom_DDP.py writes) warns once that the model's compute dtype is used instead
+        (bf16 has fp32's exponent range: the GradScaler around it stays exact and never has to back off)."""
+    global _warned_default
+    if enabled:
+        if dtype is torch.float16:
+            raise NotImplementedError("cleantransformer_amd has no fp16 compute path (bf16 / fp32 MFMA kernels only): use "
+                                      "config.compute_dtype = 'bf16' (autocast(dtype=torch.bfloat16) is accepted) — DESIGN.md §7d")
+        if dtype not in (None, torch.bfloat16, torch.float32):
+            raise NotImplementedError(f"autocast(dtype={dtype}) is not supported: compute dtypes are bf16 and fp32")
+        if dtype is None and not _warned_default:
+            _warned_default = True
+            import warnings
+            warnings.warn("cleantransformer_amd.amp.autocast(): torch's default autocast dtype (fp16) is not implemented; the forward runs "
+                          "in the model's config.compute_dtype (bf16 or fp32) with fp32 statistics and master weights", stacklevel=3)
     yield
 
 

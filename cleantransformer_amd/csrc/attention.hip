@@ -43,6 +43,7 @@
 #define ATTN_DBG(p) 0
 #endif
 #include "attn_params.h"
+#include "prof.h"
 
 // 64 x HDP tile staging helpers (256 threads).  Thread -> (row = id / CPR, 16-byte chunk = id % CPR): the CPR lanes of
 // one row read one contiguous run of HBM (coalesced: a head row of hd=64 bf16 is exactly one 128-byte line) and write one
@@ -996,6 +997,7 @@ extern "C" int ctmi_attn_fwd(const void* q, const void* k, const void* v, void* 
     int rc = fill_params(p, desc, dtype, "attn_fwd");
     if (rc != CTMI_OK) return rc;
     hipStream_t st = as_stream(stream);
+    ProfScope prof__(CTMI_PROF_ATTN_FWD, st);
     if (dtype == CTMI_F32) return HDP_DISPATCH(fwd_launch, float);
     if (ctmi_attn32_fwd(p, st)) { CTMI_CHECK_LAUNCH("attn32_fwd"); return CTMI_OK; }   // training shapes: attention_w32.hip
     return HDP_DISPATCH(fwd_launch, bf16_t);
@@ -1015,6 +1017,7 @@ extern "C" int ctmi_attn_bwd(const void* q, const void* k, const void* v, const 
     int rc = fill_params(p, desc, dtype, "attn_bwd");
     if (rc != CTMI_OK) return rc;
     hipStream_t st = as_stream(stream);
+    ProfScope prof__(CTMI_PROF_ATTN_BWD, st);
     if (dtype == CTMI_F32) return HDP_DISPATCH(bwd_launch, float);
     if (ctmi_attn32_bwd(p, st)) { CTMI_CHECK_LAUNCH("attn32_bwd"); return CTMI_OK; }   // training shapes: attention_w32.hip
     return HDP_DISPATCH(bwd_launch, bf16_t);

@@ -2,6 +2,7 @@
 // gfx950: one wave (64 lanes) per row for LayerNorm, one 256-thread block per vocabulary row for CE,
 // 16-byte loads everywhere, fp32 statistics, wavefront shuffles for the reductions.
 #include "common.h"
+#include "prof.h"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 // ------------------------------------------------------------------------------------------------
@@ -116,6 +117,7 @@ static int ln_fwd_launch(const void* x, const float* w, const float* b, void* y,
 
 extern "C" int ctmi_layernorm_fwd(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd,
                                   int64_t rows, int64_t cols, float eps, int dtype, void* stream) {
+    ProfScope prof__(CTMI_PROF_LAYERNORM, as_stream(stream));
     CTMI_REQUIRE(x && w && b && y && mean && rstd, "layernorm_fwd: null pointer");
     CTMI_REQUIRE(rows >= 0 && cols > 0, "layernorm_fwd: bad shape rows=%lld cols=%lld", (long long)rows, (long long)cols);
     if (rows == 0) return CTMI_OK;
@@ -496,6 +498,7 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* w, const fl
 int ctmi_ln_bwd_parts_internal(const void* dy, const void* x, const float* w, const float* mean, const float* rstd,
                                const void* dres, void* dx, float* ws, int64_t rows, int64_t cols, int dtype, int want_sums,
                                int* nparts, int* ns, hipStream_t st) {
+    ProfScope prof__(CTMI_PROF_LAYERNORM, st);
     if (dtype == CTMI_F32) return ln_bwd_parts<float>(dy, x, w, mean, rstd, dres, dx, ws, rows, cols, want_sums, nparts, ns, st);
     if (dtype == CTMI_BF16) return ln_bwd_parts<bf16_t>(dy, x, w, mean, rstd, dres, dx, ws, rows, cols, want_sums, nparts, ns, st);
     ctmi_set_error("layernorm_bwd: unsupported dtype %d", dtype);
@@ -505,6 +508,7 @@ int ctmi_ln_bwd_parts_internal(const void* dy, const void* x, const float* w, co
 extern "C" int ctmi_layernorm_bwd(const void* dy, const void* x, const float* w, const float* mean, const float* rstd,
                                   const void* dres, void* dx, float* dw, float* db, int accumulate, float* ws,
                                   int64_t rows, int64_t cols, int dtype, void* stream) {
+    ProfScope prof__(CTMI_PROF_LAYERNORM, as_stream(stream));
     CTMI_REQUIRE(dy && x && w && mean && rstd && dx && dw && db && ws, "layernorm_bwd: null pointer");
     CTMI_REQUIRE(rows > 0 && cols > 0, "layernorm_bwd: bad shape");
     if (dtype == CTMI_F32) return ln_bwd_launch<float>(dy, x, w, mean, rstd, dres, dx, dw, db, accumulate, ws, rows, cols, as_stream(stream));
@@ -587,6 +591,7 @@ __global__ __launch_bounds__(256) void colsum_final(const float* __restrict__ ws
 
 // partial rows only: ws[part][N]; *parts_out partial rows
 int ctmi_colsum_parts_internal(const void* x, int64_t ld, float* ws, int64_t M, int64_t N, int dtype, int* parts_out, hipStream_t st) {
+    ProfScope prof__(CTMI_PROF_REDUCE, st);
     const int64_t xblocks = cdiv64(N, 64 * (dtype == CTMI_F32 ? 4 : 8));
     // ~2048 workgroups (8 waves per SIMD) so the row streams cover the HBM latency; >= 16 rows per part
     int parts = (int)std::min<int64_t>(std::max<int64_t>(16, std::min<int64_t>(COLSUM_PARTS, cdiv64(2048, xblocks))), cdiv64(M, 16));
@@ -645,6 +650,7 @@ __global__ __launch_bounds__(256) void dropout_k(const T* __restrict__ x, const 
 extern "C" uint32_t ctmi_dropout_hash(uint32_t x) { return ctmi_hash32(x); }
 extern "C" uint32_t ctmi_dropout_threshold(float p) { return ctmi_drop_threshold(p); }
 extern "C" int ctmi_dropout(const void* x, const void* residual, void* y, int64_t n, float p, uint32_t seed, int dtype, void* stream) {
+    ProfScope prof__(CTMI_PROF_OTHER, as_stream(stream));
     CTMI_REQUIRE(x && y && n >= 0, "dropout: bad args");
     CTMI_REQUIRE(p >= 0.0f && p < 1.0f, "dropout: p must be in [0, 1)");
     if (n == 0) return CTMI_OK;
@@ -688,6 +694,7 @@ __global__ __launch_bounds__(256) void reduce_jobs_k(ReduceJobs R) {
 }
 
 extern "C" int ctmi_reduce_jobs(const ctmi_reduce_job* jobs, int count, void* stream) {
+    ProfScope prof__(CTMI_PROF_REDUCE, as_stream(stream));
     CTMI_REQUIRE(jobs != nullptr && count >= 0, "reduce_jobs: bad args");
     hipStream_t st = as_stream(stream);
     for (int base = 0; base < count; base += CTMI_REDUCE_MAX_JOBS) {
@@ -747,6 +754,7 @@ __global__ __launch_bounds__(256) void embed_bwd_k(const T* __restrict__ dout, c
 
 extern "C" int ctmi_embed_fwd(const void* table, const int64_t* ids, void* out, int64_t n, int64_t H, int64_t V,
                               int dtype, int32_t* err_flag, void* stream) {
+    ProfScope prof__(CTMI_PROF_OTHER, as_stream(stream));
     CTMI_REQUIRE(table && ids && out && n >= 0 && H > 0 && V > 0, "embed_fwd: bad args");
     if (n == 0) return CTMI_OK;
     int grid = (int)std::min<int64_t>(cdiv64(n, 4), 4096);
@@ -762,6 +770,7 @@ extern "C" int ctmi_embed_fwd(const void* table, const int64_t* ids, void* out, 
 }
 extern "C" int ctmi_embed_bwd(const void* dout, const int64_t* ids, float* dtable, int64_t n, int64_t H, int64_t V,
                               int dtype, float scale, void* stream) {
+    ProfScope prof__(CTMI_PROF_OTHER, as_stream(stream));
     CTMI_REQUIRE(dout && ids && dtable && n >= 0 && H > 0 && V > 0, "embed_bwd: bad args");
     if (n == 0) return CTMI_OK;
     int grid = (int)std::min<int64_t>(cdiv64(n, 4), 4096);
@@ -936,6 +945,7 @@ __global__ __launch_bounds__(256) void ce_bwd_k(const T* __restrict__ logits, in
 extern "C" int ctmi_ce_fwd(const void* logits, int64_t ld, const int64_t* labels, float* row_lse, float* row_loss,
                            float* loss_out, int64_t N, int64_t C, int64_t seq, int64_t shift, int64_t ignore_index,
                            int denom_mode, int64_t denom_rows, int dtype, void* stream) {
+    ProfScope prof__(CTMI_PROF_LOSS, as_stream(stream));
     CTMI_REQUIRE(logits && labels && row_lse && row_loss && loss_out, "ce_fwd: null pointer");
     CTMI_REQUIRE(N > 0 && C > 0 && seq > 0 && N % seq == 0 && shift >= 0 && ld >= C, "ce_fwd: bad shape N=%lld C=%lld seq=%lld", (long long)N, (long long)C, (long long)seq);
     hipStream_t st = as_stream(stream);
@@ -955,6 +965,7 @@ extern "C" int ctmi_ce_fwd(const void* logits, int64_t ld, const int64_t* labels
 extern "C" int ctmi_ce_bwd(const void* logits, int64_t ld, const int64_t* labels, const float* row_lse, const float* loss_out,
                            const float* gout, void* dlogits, int64_t ldd, int64_t N, int64_t C, int64_t seq, int64_t shift,
                            int64_t ignore_index, int dtype, void* stream) {
+    ProfScope prof__(CTMI_PROF_LOSS, as_stream(stream));
     CTMI_REQUIRE(logits && labels && row_lse && loss_out && dlogits, "ce_bwd: null pointer");
     CTMI_REQUIRE(N > 0 && C > 0 && seq > 0 && N % seq == 0 && ld >= C && ldd >= C, "ce_bwd: bad shape");
     hipStream_t st = as_stream(stream);
@@ -1115,6 +1126,7 @@ __global__ __launch_bounds__(1024) void ce_fused_k(const T* __restrict__ logits,
 extern "C" int ctmi_ce_fwd_bwd(const void* logits, int64_t ld, const int64_t* labels, float* row_lse, float* row_loss,
                                float* loss_out, void* dlogits, int64_t ldd, int64_t N, int64_t C, int64_t seq, int64_t shift,
                                int64_t ignore_index, int denom_mode, int64_t denom_rows, int dtype, void* stream) {
+    ProfScope prof__(CTMI_PROF_LOSS, as_stream(stream));
     CTMI_REQUIRE(logits && labels && row_lse && row_loss && loss_out && dlogits, "ce_fwd_bwd: null pointer");
     CTMI_REQUIRE(N > 0 && C > 0 && seq > 0 && N % seq == 0 && shift >= 0 && ld >= C && ldd >= C, "ce_fwd_bwd: bad shape N=%lld C=%lld seq=%lld", (long long)N, (long long)C, (long long)seq);
     CTMI_REQUIRE(dtype == CTMI_F32 || dtype == CTMI_BF16, "ce_fwd_bwd: unsupported dtype %d", dtype);
@@ -1150,6 +1162,7 @@ __global__ __launch_bounds__(256) void scale_if_k(T* __restrict__ x, int64_t ld,
         for (int64_t c = threadIdx.x; c < cols; c += 256) x[r * ld + c] = Cvt<T>::from_f(Cvt<T>::to_f(x[r * ld + c]) * s);
 }
 extern "C" int ctmi_scale_if(void* x, int64_t ld, int64_t rows, int64_t cols, const float* s_dev, int dtype, void* stream) {
+    ProfScope prof__(CTMI_PROF_LOSS, as_stream(stream));
     CTMI_REQUIRE(x && s_dev && rows > 0 && cols > 0 && ld >= cols, "scale_if: bad args");
     const unsigned grid = (unsigned)std::min<int64_t>(rows, 4096);
     if (dtype == CTMI_F32) hipLaunchKernelGGL((scale_if_k<float>), dim3(grid), dim3(256), 0, as_stream(stream), (float*)x, ld, rows, cols, s_dev);
@@ -1221,6 +1234,7 @@ __global__ __launch_bounds__(256) void ce_soft_bwd_k(const T* __restrict__ logit
 extern "C" int ctmi_ce_soft_fwd(const void* logits, int64_t ld, const float* target, int64_t ldt, float* row_lse, float* row_tsum,
                                 float* row_loss, float* loss_out, int64_t N, int64_t C, int denom_mode, int64_t denom_rows, int dtype,
                                 void* stream) {
+    ProfScope prof__(CTMI_PROF_LOSS, as_stream(stream));
     CTMI_REQUIRE(logits && target && row_lse && row_tsum && row_loss && loss_out, "ce_soft_fwd: null pointer");
     CTMI_REQUIRE(N > 0 && C > 0 && ld >= C && ldt >= C && (denom_mode == 1 || denom_mode == 2), "ce_soft_fwd: bad args");
     hipStream_t st = as_stream(stream);
@@ -1235,6 +1249,7 @@ extern "C" int ctmi_ce_soft_fwd(const void* logits, int64_t ld, const float* tar
 extern "C" int ctmi_ce_soft_bwd(const void* logits, int64_t ld, const float* target, int64_t ldt, const float* row_lse,
                                 const float* row_tsum, const float* loss_out, const float* gout, void* dlogits, int64_t ldd,
                                 int64_t N, int64_t C, int dtype, void* stream) {
+    ProfScope prof__(CTMI_PROF_LOSS, as_stream(stream));
     CTMI_REQUIRE(logits && target && row_lse && row_tsum && loss_out && dlogits, "ce_soft_bwd: null pointer");
     CTMI_REQUIRE(N > 0 && C > 0 && ld >= C && ldt >= C && ldd >= C, "ce_soft_bwd: bad shape");
     hipStream_t st = as_stream(stream);
@@ -1304,6 +1319,7 @@ static int mt_grid_x(const int64_t* n, int count) {
 extern "C" int ctmi_adamw_step(float* const* p, float* const* g, float* const* m, float* const* v, void* const* shadow,
                                const int64_t* n, int count, float lr, float beta1, float beta2, float eps,
                                float weight_decay, int step, int decoupled, int mutate_grad, float grad_scale, void* stream) {
+    ProfScope prof__(CTMI_PROF_OPTIMIZER, as_stream(stream));
     CTMI_REQUIRE(p && g && m && v && n && count >= 0 && step >= 1, "adamw_step: bad args (step must be >= 1)");
     AdamHyper h;
     h.lr = lr; h.b1 = beta1; h.b2 = beta2; h.eps = eps; h.wd = weight_decay;
@@ -1352,6 +1368,7 @@ __global__ __launch_bounds__(256) void amp_unscale_k(MTPack pk, float* __restric
     if (__any(bad) && (threadIdx.x & 63) == 0) state[2] = 1.0f;          // benign race: every writer stores the same value
 }
 extern "C" int ctmi_amp_unscale(float* const* g, const int64_t* n, int count, float* state, void* stream) {
+    ProfScope prof__(CTMI_PROF_OPTIMIZER, as_stream(stream));
     CTMI_REQUIRE(g && n && state && count >= 0, "amp_unscale: bad args");
     for (int base = 0; base < count; base += CTMI_MT_MAX) {
         const int c = std::min(CTMI_MT_MAX, count - base);
@@ -1378,6 +1395,7 @@ __global__ void amp_update_k(float* __restrict__ state, float growth, float back
     state[2] = 0.0f;
 }
 extern "C" int ctmi_amp_update(float* state, float growth, float backoff, int interval, void* stream) {
+    ProfScope prof__(CTMI_PROF_OPTIMIZER, as_stream(stream));
     CTMI_REQUIRE(state && interval >= 1, "amp_update: bad args");
     hipLaunchKernelGGL(amp_update_k, dim3(1), dim3(64), 0, as_stream(stream), state, growth, backoff, interval);
     CTMI_CHECK_LAUNCH("amp_update");
@@ -1405,6 +1423,7 @@ __global__ __launch_bounds__(256) void sgd_mt_k(MTPack pk, SgdHyper h) {
 }
 extern "C" int ctmi_sgd_step(float* const* p, float* const* g, float* const* buf, void* const* shadow, const int64_t* n,
                              int count, float lr, float momentum, float dampening, float weight_decay, int first_step, void* stream) {
+    ProfScope prof__(CTMI_PROF_OPTIMIZER, as_stream(stream));
     CTMI_REQUIRE(p && g && n && count >= 0, "sgd_step: bad args");
     SgdHyper h{lr, momentum, dampening, weight_decay, first_step};
     for (int base = 0; base < count; base += CTMI_MT_MAX) {
@@ -1435,6 +1454,7 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_v4(const float4* __restrict
     }
 }
 extern "C" int ctmi_cast(const void* src, int sd, void* dst, int dd, int64_t n, void* stream) {
+    ProfScope prof__(CTMI_PROF_OTHER, as_stream(stream));
     CTMI_REQUIRE(src && dst && n >= 0, "cast: bad args");
     if (n == 0) return CTMI_OK;
     hipStream_t st = as_stream(stream);
@@ -1469,6 +1489,7 @@ __global__ __launch_bounds__(256) void transpose_cast_k(const float* __restrict_
     }
 }
 extern "C" int ctmi_transpose_cast(const float* src, void* dst, int dst_dtype, int64_t rows, int64_t cols, void* stream) {
+    ProfScope prof__(CTMI_PROF_OTHER, as_stream(stream));
     CTMI_REQUIRE(src && dst && rows > 0 && cols > 0, "transpose_cast: bad args");
     const dim3 grid((unsigned)cdiv64(cols, 64), (unsigned)cdiv64(rows, 64));
     if (dst_dtype == CTMI_F32) hipLaunchKernelGGL((transpose_cast_k<float>), grid, dim3(256), 0, as_stream(stream), src, (float*)dst, rows, cols);
@@ -1488,6 +1509,7 @@ __global__ __launch_bounds__(256) void sumsq_k(const float* __restrict__ x, int6
     if (threadIdx.x == 0) atomicAdd(out, sm[0] + sm[1] + sm[2] + sm[3]);
 }
 extern "C" int ctmi_sumsq(const float* x, int64_t n, double* out, int accumulate, void* stream) {
+    ProfScope prof__(CTMI_PROF_OTHER, as_stream(stream));
     CTMI_REQUIRE(x && out && n >= 0, "sumsq: bad args");
     hipStream_t st = as_stream(stream);
     if (!accumulate) { if (hipMemsetAsync(out, 0, sizeof(double), st) != hipSuccess) { ctmi_set_error("sumsq: memset failed"); return CTMI_ERR_LAUNCH; } }
@@ -1519,10 +1541,12 @@ static int scale_copy_launch(const float* src, float* dst, int64_t n, float s, c
     return CTMI_OK;
 }
 extern "C" int ctmi_scale(float* x, int64_t n, float s, const float* s_dev, void* stream) {
+    ProfScope prof__(CTMI_PROF_OTHER, as_stream(stream));
     CTMI_REQUIRE(x && n >= 0, "scale: bad args");
     return scale_copy_launch(x, x, n, s, s_dev, stream, "scale");
 }
 extern "C" int ctmi_scale_copy(const float* src, float* dst, int64_t n, float s, void* stream) {
+    ProfScope prof__(CTMI_PROF_OTHER, as_stream(stream));
     CTMI_REQUIRE(src && dst && n >= 0, "scale_copy: bad args");
     return scale_copy_launch(src, dst, n, s, nullptr, stream, "scale_copy");
 }
@@ -1695,6 +1719,7 @@ __global__ __launch_bounds__(64) void mask_prep_k(const int64_t* __restrict__ am
     if (lane == 0) first_valid[b] = (int32_t)first;
 }
 extern "C" int ctmi_mask_prep(const int64_t* am, float* kpos, int32_t* kvalid, int32_t* first_valid, int64_t B, int64_t S, void* stream) {
+    ProfScope prof__(CTMI_PROF_OTHER, as_stream(stream));
     CTMI_REQUIRE(am && kpos && kvalid && first_valid && B > 0 && S > 0, "mask_prep: bad args");
     hipLaunchKernelGGL(mask_prep_k, dim3((unsigned)B), dim3(64), 0, as_stream(stream), am, kpos, kvalid, first_valid, S);
     CTMI_CHECK_LAUNCH("mask_prep");

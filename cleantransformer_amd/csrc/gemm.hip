@@ -16,6 +16,7 @@
 #include "common.h"
 #include <type_traits>
 #include "mma.h"
+#include "prof.h"
 #include <atomic>
 // translation-unit split (see the note above ctmi_gemm_bf16_nt below)
 #ifndef CTMI_GEMM_PART
@@ -1302,6 +1303,9 @@ extern "C" int ctmi_gemm(const void* A, int64_t lda, int a_kmajor, const void* B
     CTMI_REQUIRE((epilogue != CTMI_EPI_GELU && epilogue != CTMI_EPI_GELUG) || aux_out, "gemm: GELU epilogues need aux_out");
     CTMI_REQUIRE((epilogue != CTMI_EPI_DGELU && epilogue != CTMI_EPI_DRELU && epilogue != CTMI_EPI_MUL) || aux_in, "gemm: dGELU/dReLU/MUL epilogues need aux_in");
     CTMI_REQUIRE(dtype == CTMI_F32 || dtype == CTMI_BF16, "gemm: unsupported dtype %d", dtype);
+    // profile class: a vocabulary-sized dimension marks the tied head's three products; otherwise by operand layout
+    ProfScope prof__((M >= 65536 || N >= 65536 || K >= 65536) ? CTMI_PROF_LM_HEAD
+                     : (a_kmajor && b_kmajor ? CTMI_PROF_GEMM_WGRAD : ((!a_kmajor && b_kmajor) ? CTMI_PROF_GEMM_DGRAD : CTMI_PROF_GEMM_FWD)), as_stream(stream));
     const int es = dtype == CTMI_F32 ? 4 : 2;
     const int vec = 16 / es;
     const int bkt = dtype == CTMI_F32 ? Tile<float>::BK : Tile<bf16_t>::BK;

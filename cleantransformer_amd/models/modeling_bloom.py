@@ -116,16 +116,24 @@ class BloomBlockFn(torch.autograd.Function):
         params = (ln1_w.detach(), ln1_b.detach(), ops.compute_weight(wqkv, cd), bqkv.detach(), ops.compute_weight(wd, cd), bd.detach(),
                   ln2_w.detach(), ln2_b.detach(), ops.compute_weight(w1, cd), b1.detach(), ops.compute_weight(w2, cd), b2.detach())
         acts = ops.bloom_block_fwd(x2, params, actx.mask, actx.slopes, eps, post_ln_res, B, S, actx.nh)
-        ctx.save_for_backward(x2, ln1_w, ln1_b, wqkv, bqkv, wd, bd, ln2_w, ln2_b, w1, b1, w2, b2)
-        ctx.acts, ctx.actx, ctx.eps, ctx.post_ln_res, ctx.shape = acts, actx, eps, post_ln_res, (B, S, H)
-        kv_out.append(_LazyKV(acts, B, S, actx.nh))                     # the K/V "present" views (no gradient), made on demand
+        # The slab is a tensor: it goes through save_for_backward (released right after this node's backward — as a Python attribute of
+        # ctx it lived as long as anything referenced the graph, i.e. through the NEXT step's forward in the reference loop); only
+        # geometry stays on ctx.  Without a graph nothing is saved and the K/V presents are copied out (ops.LazyKV).
+        grad = any(ctx.needs_input_grad)
+        if grad:
+            ctx.save_for_backward(x2, ln1_w, ln1_b, wqkv, bqkv, wd, bd, ln2_w, ln2_b, w1, b1, w2, b2, acts.slab)
+            ctx.geo, ctx.actx, ctx.eps, ctx.post_ln_res, ctx.shape = acts.geometry(), actx, eps, post_ln_res, (B, S, H)
+        kv = ops.LazyKV(acts, blocked=False, eager=not grad)
+        if grad:
+            ctx.kv = kv
+        kv_out.append(kv)
         return acts.out.view(B, S, H)
 
     @staticmethod
     def backward(ctx, dout):
         if dout is None:
             return (None,) * 17
-        x2, ln1_w, ln1_b, wqkv, bqkv, wd, bd, ln2_w, ln2_b, w1, b1, w2, b2 = ctx.saved_tensors
+        x2, ln1_w, ln1_b, wqkv, bqkv, wd, bd, ln2_w, ln2_b, w1, b1, w2, b2, slab = ctx.saved_tensors
         B, S, H = ctx.shape
         cd = x2.dtype
         dout2 = dout.reshape(B * S, H)
@@ -136,7 +144,8 @@ class BloomBlockFn(torch.autograd.Function):
         # library call they run on a side HIP stream, concurrently with the dgrad GEMMs / attention backward, and are joined
         # back into the current stream before the call returns, so everything downstream (autograd accumulation, DDP hooks,
         # optimizer) is ordered.
-        dx, g = ops.bloom_block_bwd(ctx.acts, x2, params, ctx.actx.mask, ctx.actx.slopes, ctx.eps, ctx.post_ln_res, dout2,
+        ctx.kv.release()
+        dx, g = ops.bloom_block_bwd(ops.BlockActs.rebuild(slab, ctx.geo), x2, params, ctx.actx.mask, ctx.actx.slopes, ctx.eps, ctx.post_ln_res, dout2,
                                     use_side_stream=_WGRAD_SIDE_STREAM and x2.is_cuda)
         return (dx.view(B, S, H), *g, None, None, None, None)
 
@@ -220,31 +229,6 @@ class BloomBlockDropoutFn(torch.autograd.Function):
         dx, dln1_w, dln1_b = ops.layernorm_bwd(dln1, x2, ln1_w.detach(), mean1, rstd1, dres=None if post else dh1)
         return (dx.view(B, S, H), dln1_w, dln1_b, dwqkv, dbqkv, dwd, dbd, dln2_w, dln2_b, dw1, db1, dw2, db2,
                 None, None, None, None, None, None, None)
-
-
-class _LazyKV:
-    """``(present_k, present_v)`` of one block (modeling_bloom.py:88-92 returns them on every call): [B,nh,S,hd] views of the fused
-    QKV activation, built when first indexed — a training step never looks at them."""
-    __slots__ = ("_acts", "_geo", "_kv")
-
-    def __init__(self, acts, B, S, nh):
-        self._acts, self._geo, self._kv = acts, (B, S, nh), None
-
-    def _make(self):
-        if self._kv is None:
-            B, S, nh = self._geo
-            qv = self._acts.qkv.view(B, S, nh, 3, -1)
-            self._kv = (qv[:, :, :, 1, :].transpose(1, 2), qv[:, :, :, 2, :].transpose(1, 2))
-        return self._kv
-
-    def __getitem__(self, i):
-        return self._make()[i]
-
-    def __iter__(self):
-        return iter(self._make())
-
-    def __len__(self):
-        return 2
 
 
 def _decode_block(blk: "BloomBlock", x: Tensor, actx: _AttnCtx, past, eps: float, post_ln_res: bool):

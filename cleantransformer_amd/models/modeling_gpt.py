@@ -165,48 +165,30 @@ class GPT2BlockFn(torch.autograd.Function):
                   n2w.detach(), n2b.detach(), ops.compute_weight(wf, cd), bf.detach(), ops.compute_weight(wo, cd), bo.detach())
         acts = ops.bloom_block_fwd(x2, params, mask, None, eps, False, B, S, nh, flags=_lib.BLK_QKV_BLOCKED | _lib.BLK_WGRAD_IN_OUT | _lib.BLK_W_IN_OUT,
                                    attn_scale=scale, future_fill=-1e4)
-        ctx.save_for_backward(x2, n1w, n1b, wa, ba, wp, bp, n2w, n2b, wf, bf, wo, bo)
-        ctx.acts, ctx.mask, ctx.eps, ctx.shape = acts, mask, eps, (B, S, H)
-        kv_out.append(_LazyKVBlocked(acts, B, S, nh))
+        grad = any(ctx.needs_input_grad)                                # see BloomBlockFn: slab through save_for_backward, presents lazily
+        if grad:
+            ctx.save_for_backward(x2, n1w, n1b, wa, ba, wp, bp, n2w, n2b, wf, bf, wo, bo, acts.slab)
+            ctx.geo, ctx.mask, ctx.eps, ctx.shape = acts.geometry(), mask, eps, (B, S, H)
+        kv = ops.LazyKV(acts, blocked=True, eager=not grad)
+        if grad:
+            ctx.kv = kv
+        kv_out.append(kv)
         return acts.out.view(B, S, H)
 
     @staticmethod
     def backward(ctx, dout):
         if dout is None:
             return (None,) * 18
-        x2, n1w, n1b, wa, ba, wp, bp, n2w, n2b, wf, bf, wo, bo = ctx.saved_tensors
+        x2, n1w, n1b, wa, ba, wp, bp, n2w, n2b, wf, bf, wo, bo, slab = ctx.saved_tensors
         B, S, H = ctx.shape
         cd = x2.dtype
         dout2 = dout.reshape(B * S, H)
         dout2 = dout2 if dout2.is_contiguous() else dout2.contiguous()
         params = (n1w.detach(), n1b.detach(), ops.compute_weight(wa, cd), ba.detach(), ops.compute_weight(wp, cd), bp.detach(),
                   n2w.detach(), n2b.detach(), ops.compute_weight(wf, cd), bf.detach(), ops.compute_weight(wo, cd), bo.detach())
-        dx, g = ops.bloom_block_bwd(ctx.acts, x2, params, ctx.mask, None, ctx.eps, False, dout2)
+        ctx.kv.release()
+        dx, g = ops.bloom_block_bwd(ops.BlockActs.rebuild(slab, ctx.geo), x2, params, ctx.mask, None, ctx.eps, False, dout2)
         return (dx.view(B, S, H), *g, None, None, None, None, None)
-
-
-class _LazyKVBlocked:
-    """(k, v) [B,nh,S,hd] views of the q | k | v activation kept by GPT2BlockFn, built when first indexed."""
-    __slots__ = ("_acts", "_geo", "_kv")
-
-    def __init__(self, acts, B, S, nh):
-        self._acts, self._geo, self._kv = acts, (B, S, nh), None
-
-    def _make(self):
-        if self._kv is None:
-            B, S, nh = self._geo
-            qv = self._acts.qkv.view(B, S, 3, nh, -1)
-            self._kv = (qv[:, :, 1].transpose(1, 2), qv[:, :, 2].transpose(1, 2))
-        return self._kv
-
-    def __getitem__(self, i):
-        return self._make()[i]
-
-    def __iter__(self):
-        return iter(self._make())
-
-    def __len__(self):
-        return 2
 
 
 def _attend_cached(qkv: Tensor, past, mask: ops.MaskInfo, nh: int, scale: float, drop_p: float = 0.0, drop_seed: int = 0):

@@ -396,6 +396,64 @@ class BlockActs:
     def qkv(self) -> Tensor:
         return self.view("qkv", self.B * self.S, 3 * self.H)
 
+    def geometry(self):
+        """Everything but the slab tensor (small Python values): what an autograd node keeps on itself — the slab goes through
+        save_for_backward so that it is released with the node's other saved tensors right after the backward."""
+        return (self.lay, self.B, self.S, self.H, self.nh, self.dtype, self.flags, self.attn_scale, self.future_fill)
+
+    @staticmethod
+    def rebuild(slab: Tensor, geo) -> "BlockActs":
+        a = BlockActs()
+        a.slab = slab
+        a.lay, a.B, a.S, a.H, a.nh, a.dtype, a.flags, a.attn_scale, a.future_fill = geo
+        return a
+
+
+class LazyKV:
+    """``(present_k, present_v)`` [B,nh,S,hd] of one block (modeling_bloom.py:88-92 / modeling_gpt.py:73-75 return them on every call).
+    * forward that will be differentiated: nothing is copied — the pair is built on demand as VIEWS of the activation slab (a training
+      step never looks at them).  The object holds the slab only until the node's backward calls release(): the list of presents a
+      training loop leaves lying around (``outputs, _ = model(...)``) then pins nothing through the next forward.
+    * forward without a graph (prefill of a generation): contiguous copies made at once, so the block's slab (5x the K/V bytes) is
+      freed as soon as the next block has consumed its output."""
+    __slots__ = ("_slab", "_geo", "_kv", "_blocked")
+
+    def __init__(self, acts: BlockActs, blocked: bool, eager: bool):
+        self._slab, self._geo, self._blocked, self._kv = (None if eager else acts.slab), acts.geometry(), blocked, None
+        if eager:
+            k, v = self._views(acts)
+            self._kv = (k.contiguous(), v.contiguous())
+
+    def _views(self, acts: BlockActs):
+        B, S, nh = acts.B, acts.S, acts.nh
+        if self._blocked:                                               # q | k | v  [B,S,3,nh,hd]
+            qv = acts.qkv.view(B, S, 3, nh, -1)
+            return qv[:, :, 1].transpose(1, 2), qv[:, :, 2].transpose(1, 2)
+        qv = acts.qkv.view(B, S, nh, 3, -1)                             # head-interleaved [B,S,nh,3,hd]
+        return qv[:, :, :, 1, :].transpose(1, 2), qv[:, :, :, 2, :].transpose(1, 2)
+
+    def release(self) -> None:
+        """Called by the block's backward: the activations are about to be freed (views already handed out keep their storage)."""
+        self._slab = None
+
+    def _make(self):
+        if self._kv is None:
+            if self._slab is None:
+                raise RuntimeError("the K/V presents of a differentiated forward are views of activations that its backward has already "
+                                   "released; read them before backward(), or run the forward under torch.no_grad()")
+            self._kv = self._views(BlockActs.rebuild(self._slab, self._geo))
+            self._slab = None
+        return self._kv
+
+    def __getitem__(self, i):
+        return self._make()[i]
+
+    def __iter__(self):
+        return iter(self._make())
+
+    def __len__(self):
+        return 2
+
 
 def _fill_block_desc(d: "_lib.BloomBlock", x2: Tensor, params, mask: Optional[MaskInfo], slopes: Optional[Tensor], eps: float,
                      post_ln_res: bool, B: int, S: int, H: int, nh: int, slab: Tensor, flags: int = 0, attn_scale: float = 0.0,
@@ -537,6 +595,7 @@ def scale_(x: Tensor, s: float, s_dev: Optional[Tensor] = None) -> Tensor:
 
 def scale_copy(src: Tensor, dst: Tensor, s: float) -> Tensor:
     """dst = s * src (fp32, flat; dst may alias src)."""
+    _need_cuda(src, dst)
     check(_lib.load().ctmi_scale_copy(_p(src), _p(dst), src.numel(), float(s), _stream()), "scale_copy")
     return dst
 
@@ -549,6 +608,19 @@ def set_launch_policy(shared: bool, reserve_cus: Optional[int] = None) -> None:
         lib.ctmi_get_launch_policy(None, C.byref(r))
         reserve_cus = r.value
     check(lib.ctmi_set_launch_policy(int(bool(shared)), int(reserve_cus)), "set_launch_policy")
+
+
+def profile_begin() -> None:
+    """Start bracketing every library launch with HIP events (include/ctmi355.h ctmi_profile_begin)."""
+    check(_lib.load().ctmi_profile_begin(), "profile_begin")
+
+
+def profile_end():
+    """-> {class name: (milliseconds, brackets)} since profile_begin()."""
+    n = len(_lib.PROF_CLASSES)
+    ms, cnt = (C.c_float * n)(), (C.c_int * n)()
+    check(_lib.load().ctmi_profile_end(ms, cnt), "profile_end")
+    return {name: (float(ms[i]), int(cnt[i])) for i, name in enumerate(_lib.PROF_CLASSES)}
 
 
 def set_attn_path(mask: int) -> int:

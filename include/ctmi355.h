@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CTMI_ABI_VERSION 7
+#define CTMI_ABI_VERSION 8
 
 enum ctmi_dtype { CTMI_F32 = 0, CTMI_BF16 = 1 };
 enum ctmi_status { CTMI_OK = 0, CTMI_ERR_ARG = -1, CTMI_ERR_LAUNCH = -2, CTMI_ERR_UNSUPPORTED = -3 };
@@ -80,6 +80,26 @@ int ctmi_gemm(const void* A, int64_t lda, int a_kmajor, const void* B, int64_t l
  * layer GEMMs.  reserve_cus: CUs left out of persistent launches.  Initial values: CTMI_GEMM_SHARED / CTMI_GEMM_RESERVE_CUS. */
 int ctmi_set_launch_policy(int shared, int reserve_cus);
 int ctmi_get_launch_policy(int* shared /* host, may be NULL */, int* reserve_cus /* host, may be NULL */);
+
+/* ---- per-class device time of a step without an external profiler (bench.py's breakdown; SURVEY 8(d) measurement).  Between
+ * ctmi_profile_begin() and ctmi_profile_end() every entry point of this library brackets its launches with HIP events on the stream
+ * it launches on; ctmi_profile_end() waits for them and returns, per class, the summed bracket time in milliseconds and the number of
+ * brackets.  Brackets of concurrent streams overlap in wall time (sum of classes >= elapsed time then): measure with one stream. */
+enum ctmi_prof_class {
+    CTMI_PROF_GEMM_FWD = 0,   /* layer Linear forwards        x W^T          (modeling_bloom.py:79,121,256,267) */
+    CTMI_PROF_GEMM_DGRAD = 1, /* layer data gradients         dy W           */
+    CTMI_PROF_GEMM_WGRAD = 2, /* layer weight gradients       dy^T x  (+ split-K reduce) */
+    CTMI_PROF_LM_HEAD = 3,    /* the three [T,H] x [V,H] products of the tied head (modeling_bloom.py:220-221) */
+    CTMI_PROF_ATTN_FWD = 4, CTMI_PROF_ATTN_BWD = 5,
+    CTMI_PROF_LAYERNORM = 6,  /* forward + backward */
+    CTMI_PROF_LOSS = 7,       /* cross entropy forward + backward */
+    CTMI_PROF_OPTIMIZER = 8,
+    CTMI_PROF_REDUCE = 9,     /* bias / LayerNorm-parameter gradient reductions */
+    CTMI_PROF_OTHER = 10,     /* embedding, mask digest, casts, ... */
+    CTMI_PROF_NCLASS = 11
+};
+int ctmi_profile_begin(void);
+int ctmi_profile_end(float* ms /* host [CTMI_PROF_NCLASS] */, int* brackets /* host [CTMI_PROF_NCLASS] */);
 
 /* column sum: out[n] (+)= sum_m x[m,n]  — bias gradients (autograd of the Linear biases). */
 int ctmi_colsum(const void* x, int64_t ld, float* out, int accumulate, float* ws, int64_t M, int64_t N, int dtype, void* stream);

@@ -396,10 +396,32 @@ def scale_if_(x2d, s_dev):
 
 
 class BlockActs:
-    """Emulated counterpart of ops.BlockActs: the saved activations as plain tensors."""
+    """Emulated counterpart of ops.BlockActs: the saved activations as plain tensors.  The product keeps ONE slab tensor (through
+    save_for_backward) plus tensor-free geometry on the autograd node; here the "slab" is an empty tensor that carries the dict of
+    activation tensors as a Python attribute and the geometry is the dict of everything else, so the host logic (ops.LazyKV,
+    BlockActs.rebuild in the backward) runs unchanged AND the lifetime of the activations follows the slab's, as in the product."""
 
     def __init__(self, **kw):
-        self.__dict__.update(kw)
+        tensors = {k: v for k, v in kw.items() if isinstance(v, torch.Tensor)}
+        self._geo = {k: v for k, v in kw.items() if not isinstance(v, torch.Tensor)}
+        self.slab = torch.empty(0)
+        self.slab._emu = tensors
+
+    def __getattr__(self, name):
+        d = self.__dict__
+        if name in d.get("_geo", {}):
+            return d["_geo"][name]
+        slab = d.get("slab")
+        if slab is not None and name in slab._emu:
+            return slab._emu[name]
+        raise AttributeError(name)
+
+    def geometry(self):
+        return self._geo
+
+    @staticmethod
+    def rebuild(slab, geo):
+        return BlockActs(**geo, **slab._emu)
 
 
 def _fused_desc(B, S, nh, hd):
@@ -492,7 +514,7 @@ def install(monkeypatch):
     """Patch cleantransformer_amd.ops in place (pytest's monkeypatch undoes it after the test)."""
     from cleantransformer_amd import ops
     for name in ("layernorm_fwd", "layernorm_bwd", "gemm", "colsum", "MaskInfo", "attn_fwd", "attn_bwd", "embed_fwd", "embed_bwd",
-                 "dropout", "ce_fwd", "ce_bwd", "ce_fwd_bwd", "ce_fused_ok", "scale_if_", "bloom_block_fwd", "bloom_block_bwd", "ce_soft_fwd", "ce_soft_bwd", "cast", "transpose_cast", "sumsq", "scale_", "scale_copy", "argmax_lastdim", "row_lse", "group_topk",
+                 "dropout", "ce_fwd", "ce_bwd", "ce_fwd_bwd", "ce_fused_ok", "scale_if_", "BlockActs", "bloom_block_fwd", "bloom_block_bwd", "ce_soft_fwd", "ce_soft_bwd", "cast", "transpose_cast", "sumsq", "scale_", "scale_copy", "argmax_lastdim", "row_lse", "group_topk",
                  "scores_filter", "amp_unscale", "amp_update", "adamw_step", "sgd_step"):
         monkeypatch.setattr(ops, name, globals()[name])
     monkeypatch.setattr(ops, "_need_cuda", lambda *a: None)

@@ -100,3 +100,30 @@ def test_torch_gradscaler_drives_the_fused_optimizer(monkeypatch):
         scaler.update()
         assert abs(float(loss) - TINY["traj"][t, 0]) <= 1e-6 * TINY["traj"][t, 0]
     assert opt.steps[0] == 3
+
+
+def test_autocast_refuses_fp16_and_accepts_the_implemented_dtypes():
+    """ft_bloom_DDP.py:122 writes `with autocast():` (fp16 on a GPU).  There is no fp16 kernel path: an explicit fp16 request raises,
+    the default form warns once, bf16 / fp32 / disabled are silent no-ops."""
+    import warnings
+    from cleantransformer_amd import amp
+    with pytest.raises(NotImplementedError):
+        with amp.autocast(dtype=torch.float16):
+            pass
+    with pytest.raises(NotImplementedError):
+        with amp.autocast("cuda", torch.float64):
+            pass
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        with amp.autocast(dtype=torch.bfloat16):
+            pass
+        with amp.autocast(dtype=torch.float16, enabled=False):
+            pass
+    amp._warned_default = False
+    with pytest.warns(UserWarning, match="fp16"):
+        with amp.autocast():
+            pass
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        with amp.autocast():                                  # only once
+            pass

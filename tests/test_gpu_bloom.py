@@ -606,7 +606,8 @@ def test_ddp_bf16_buckets_and_uneven_sequence_lengths_on_the_gpu():
 
 def test_bench_two_rank_code_path_executes():
     """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), on this one-GPU box: both ranks
-    share cuda:0 and use gloo, the model is shrunk (CTMI_BENCH_PLUMBING) — what is checked is that the N>1 code path of bench.py
+    share cuda:0 and use gloo, the model is shrunk — all of it patched in from outside by tests/bench_plumbing.py, bench.py has no such
+    switches — what is checked is that the N>1 code path of bench.py
     runs end to end (DDP wrap, launch policy switch, barrier / max-over-ranks timing, one JSON line from rank 0), not a number."""
     import socket
     import subprocess
@@ -616,14 +617,16 @@ def test_bench_two_rank_code_path_executes():
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ)
-    env.update(CTMI_BENCH_ONE_DEVICE="1", CTMI_DIST_BACKEND="gloo", CTMI_BENCH_PLUMBING="2,4096", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--seq", "256"],
+                        "--master-port", str(port), os.path.join("tests", "bench_plumbing.py"), "2,4096", "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "2", "--seq", "256", "--comm-dtype", "bf16"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     doc = json.loads(lines[0])
     assert doc["n_gpus"] == 2 and doc["steps"] == 2 and doc["scaling"] == "weak" and doc["value"] > 0
-    assert doc["metric"].startswith("PLUMBING RUN") and doc["config"]["parallelism"] == "dp2"
+    assert doc["metric"].startswith("PLUMBING RUN") and doc["config"]["parallelism"] == "dp2" and doc["config"]["comm_dtype"] == "bf16"
+    assert doc["roofline"]["breakdown_ms_per_step"]["ms"]["gemm_fwd"] > 0 and doc["config"]["padded_sample"]["ms_per_step"] > 0
     assert math.isfinite(doc["final_loss"])

@@ -206,3 +206,38 @@ def test_bucket_builder_matches_torch_ddp_policy():
     assert b[0] == [5, 4]                                        # reverse order; first bucket capped at 1 MiB
     assert b[1] == [3]                                           # 28 MB tensor: a bucket of its own
     assert sorted(i for bb in b for i in bb) == list(range(6))
+
+
+def test_block_activations_are_released_by_the_backward_and_prefill_copies_its_presents(monkeypatch):
+    """the reference loop keeps `outputs` and the presents list of step t alive through the forward of step t+1
+    (``outputs, _ = model(...)``).  The slab of a block must not live on the autograd node or in the presents beyond its backward;
+    a forward without a graph (generation prefill) hands out contiguous K/V copies instead of views that pin the slab."""
+    import gc
+    import weakref
+    from cleantransformer_amd import ops
+    emu.install(monkeypatch)
+    V, H, L, nh, B, S = [int(v) for v in TINY["cfg"]]
+    m = build(V, H, L, nh)
+    ids, am = T(TINY["ids"]), T(TINY["mask"])
+    made = []
+    real_fwd = ops.bloom_block_fwd
+    monkeypatch.setattr(ops, "bloom_block_fwd", lambda *a, **k: (made.append(real_fwd(*a, **k)), made[-1])[1])
+    outputs, presents = m(input_ids=ids, attention_mask=am, labels=ids.clone())
+    slabs = [weakref.ref(a.slab) for a in made]
+    del made[:]
+    assert all(isinstance(p, ops.LazyKV) and p._slab is not None for p in presents)
+    k0, v0 = presents[0]                                               # read before the backward: views, fine
+    assert k0.shape == (B, nh, S, H // nh) and not k0.is_contiguous()
+    outputs[0].backward()
+    gc.collect()
+    # `outputs` and `presents` are still referenced here, as in the reference loop
+    assert all(p._slab is None for p in presents)
+    assert all(s() is None for s in slabs), "a block's slab outlived its backward"
+    assert torch.isfinite(k0).all()                                    # views handed out before the backward keep their own storage
+    with pytest.raises(RuntimeError, match="released"):
+        presents[1][0]
+    # no graph: copies, nothing referenced
+    with torch.no_grad():
+        (logits, _), pres = m(input_ids=ids, attention_mask=am)
+    assert all(p._slab is None and p[0].is_contiguous() and p[1].is_contiguous() for p in pres)
+    close(pres[0][0], k0.detach(), 0, 0)
