@@ -119,7 +119,7 @@ class BloomBlockFn(torch.autograd.Function):
         # The slab is a tensor: it goes through save_for_backward (released right after this node's backward — as a Python attribute of
         # ctx it lived as long as anything referenced the graph, i.e. through the NEXT step's forward in the reference loop); only
         # geometry stays on ctx.  Without a graph nothing is saved and the K/V presents are copied out (ops.LazyKV).
-        grad = any(ctx.needs_input_grad)
+        grad = getattr(kv_out, "grad", True) and any(ctx.needs_input_grad)
         if grad:
             ctx.save_for_backward(x2, ln1_w, ln1_b, wqkv, bqkv, wd, bd, ln2_w, ln2_b, w1, b1, w2, b2, acts.slab)
             ctx.geo, ctx.actx, ctx.eps, ctx.post_ln_res, ctx.shape = acts.geometry(), actx, eps, post_ln_res, (B, S, H)
@@ -500,7 +500,7 @@ class BloomBlock(torch.nn.Module):
                 actx, self.eps, self.apply_residual_connection_post_layernorm, p_hidden, p_attn,
                 (rng.next_seed(), rng.next_seed(), rng.next_seed()), kv)
             return out, kv[0]
-        kv = []
+        kv = ops.KVOut()
         out = BloomBlockFn.apply(
             hidden_states, self.input_layernorm.weight, self.input_layernorm.bias,
             sa.query_key_value.weight, sa.query_key_value.bias, sa.dense.weight, sa.dense.bias,

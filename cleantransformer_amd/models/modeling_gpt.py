@@ -165,7 +165,7 @@ class GPT2BlockFn(torch.autograd.Function):
                   n2w.detach(), n2b.detach(), ops.compute_weight(wf, cd), bf.detach(), ops.compute_weight(wo, cd), bo.detach())
         acts = ops.bloom_block_fwd(x2, params, mask, None, eps, False, B, S, nh, flags=_lib.BLK_QKV_BLOCKED | _lib.BLK_WGRAD_IN_OUT | _lib.BLK_W_IN_OUT,
                                    attn_scale=scale, future_fill=-1e4)
-        grad = any(ctx.needs_input_grad)                                # see BloomBlockFn: slab through save_for_backward, presents lazily
+        grad = getattr(kv_out, "grad", True) and any(ctx.needs_input_grad)                                # see BloomBlockFn: slab through save_for_backward, presents lazily
         if grad:
             ctx.save_for_backward(x2, n1w, n1b, wa, ba, wp, bp, n2w, n2b, wf, bf, wo, bo, acts.slab)
             ctx.geo, ctx.mask, ctx.eps, ctx.shape = acts.geometry(), mask, eps, (B, S, H)
@@ -307,7 +307,7 @@ class TransformerBlock(torch.nn.Module):
             # GPT-2/3 pre-LN training step without dropout: one autograd node, one library call per direction
             a, fc, proj = self.attn, self.mlp[0], self.mlp[2]
             hd = a.n_state // a.n_head
-            kv = []
+            kv = ops.KVOut()
             output = GPT2BlockFn.apply(x, self.norm1.weight, self.norm1.bias, a.c_attn.weight, a.c_attn.bias, a.c_proj.weight, a.c_proj.bias,
                                        self.norm2.weight, self.norm2.bias, fc.weight, fc.bias, proj.weight, proj.bias,
                                        attention_mask, a.n_head, self.norm1.eps, (1.0 / math.sqrt(hd)) if a.scale else 1.0, kv)

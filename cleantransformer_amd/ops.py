@@ -409,6 +409,15 @@ class BlockActs:
         return a
 
 
+class KVOut(list):
+    """The out-parameter through which a block node hands back its presents; it also carries the caller's grad mode into the node's
+    forward (inside autograd.Function.forward grad mode is always off, and needs_input_grad ignores torch.no_grad())."""
+
+    def __init__(self):
+        super().__init__()
+        self.grad = torch.is_grad_enabled()
+
+
 class LazyKV:
     """``(present_k, present_v)`` [B,nh,S,hd] of one block (modeling_bloom.py:88-92 / modeling_gpt.py:73-75 return them on every call).
     * forward that will be differentiated: nothing is copied — the pair is built on demand as VIEWS of the activation slab (a training
