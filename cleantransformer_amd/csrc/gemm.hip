@@ -47,6 +47,23 @@ constexpr int glds_patch_bytes(bool pp, int wm, bool xlane = false) { return (pp
 // better epilogue for a row-major-B [T,4H]-sized output and the worse one for the logits (see the note above), so the launcher
 // picks by output size (forward layout, no residual, not logits-sized).  Same-box A/B in round 2: h->4h forward with GELU 75.9 vs
 // 78.1 us, plain 67.7-69.3 vs 69.4-70.2, QKV forward +0.5 %; training step 42.56 vs 42.65 ms (3 interleaved runs each).
+// Ping-pong schedule: issue the B-operand LDS-DMA pieces of a stage inside the MFMA phase (between the matrix instructions) instead of
+// in the load phase with the A pieces.  tools/gemm_anatomy.py: a phase costs 730-830 cycles whatever its matrix work (272 / 544
+// cycles of MFMA) — the load phase (fragment reads + 3-4 DMA issues at ~150 cycles each beside ds_reads) sets the pace; a DMA issue among
+// bare MFMAs costs ~60.
+#ifndef CTMI_PP_SPLIT_DMA
+#define CTMI_PP_SPLIT_DMA 0    // measured (profiles/r03_gemm_split_dma.txt): 256-row tiles 3-10 % slower, 128-row tiles 5 % faster in the K-loop; not adopted
+#endif
+// Ping-pong schedule: four K-steps per trip with compile-time ring positions (the ring has four stages) and the steady-state waits
+// spelled out, instead of one generic step per trip.  tools/gemm_anatomy.py (profiles/r03_gemm_anatomy.txt): the LOAD segment of a
+// phase pair takes ~590 cycles against 544 cycles of MFMAs in the other row group — ~60 instructions at ~5 cycles of issue each plus
+// four LDS-DMA stalls — and about half of those instructions are ring / work-item bookkeeping the generic step recomputes.
+// Built and measured (profiles/r03_gemm_unroll.txt): the unrolled body itself compiles to 12 reads + the DMA block + two waits per
+// step, but hipcc renames the 128 accumulator registers across the four steps and restores them through scratch at the back edge
+// (256-row tiles 6x slower); 128-row tiles +2-5 % at K >= 3072 and -8...-23 % at K = 1024.  Off.
+#ifndef CTMI_PP_UNROLL
+#define CTMI_PP_UNROLL 0
+#endif
 #ifndef CTMI_PP256_XLANE
 #define CTMI_PP256_XLANE 1
 #endif
@@ -439,6 +456,18 @@ struct GTile {
     }
 };
 
+// -DCTMI_GEMM_TIMING=1 (tools/ variant builds only): wave 0 of every workgroup accumulates s_memtime deltas — prologue (entry ->
+// first K-step), K-loops, epilogues — into a __device__ array read back by ctmi_gemm_debug_ticks_<part>() (tools/gemm_anatomy.py)
+#ifndef CTMI_GEMM_TIMING
+#define CTMI_GEMM_TIMING 0
+#endif
+#if CTMI_GEMM_TIMING
+static __device__ unsigned long long g_gemm_ticks[2048 * 4];
+static __device__ unsigned long long g_gemm_phase[256 * 8];     // wave 0 and wave NW-1 of the first 128 workgroups: issue, waits, barrier 1, MFMAs, barrier 2
+#define GEMM_TICK(acc) do { const unsigned long long now__ = __builtin_amdgcn_s_memtime(); acc += now__ - tlast; tlast = now__; } while (0)
+#else
+#define GEMM_TICK(acc) do { } while (0)
+#endif
 template <typename TO, bool AK, bool BKM, int EPI, int WM, int WGN, bool PP = false, bool RES = false, bool XLANE = false>
 __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
     using T = bf16_t;
@@ -447,6 +476,9 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
     using TA = GTile<AK, BM>;
     using TB = GTile<BKM, BN>;
     constexpr int STAGE = TA::BYTES + TB::BYTES;
+    // LDS ring: the A tiles of all stages, then the B tiles of all stages — every fragment read is then ONE lane-constant base register per
+    // operand plus a 16-bit immediate (stage * tile bytes + fragment row offset < 64 KiB), also across the stages of an unrolled trip
+    constexpr int AOFF = 0, BOFF = NST * TA::BYTES;
     constexpr int PA = TA::NINSTR / NW, PB = TB::NINSTR / NW;               // DMA instructions per wave per stage
     constexpr int LOADS = PA + PB;
     static_assert(PP ? (LOADS == 3 || LOADS == 4) : (LOADS == 4 || LOADS == 6), "vmcnt immediates below assume these DMA piece counts");
@@ -501,14 +533,13 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
     };
     // one DMA piece (j-th of this wave's LOADS per stage) of the stage being issued; pointers advance
     auto issue_one = [&](int stage_buf, int j) {
-        const unsigned base = lds0 + stage_buf * STAGE;
-        if (j < PA) { glds16(pa[j], base + (wid * PA + j) * 1024); pa[j] += astep; }
-        else { const int jb = j - PA; glds16(pb[jb], base + TA::BYTES + (wid * PB + jb) * 1024); pb[jb] += bstep; }
+        if (j < PA) { glds16(pa[j], lds0 + AOFF + stage_buf * TA::BYTES + (wid * PA + j) * 1024); pa[j] += astep; }
+        else { const int jb = j - PA; glds16(pb[jb], lds0 + BOFF + stage_buf * TB::BYTES + (wid * PB + jb) * 1024); pb[jb] += bstep; }
     };
     // all pieces of one stage in ONE statement: M0 saved/restored once, the second piece of each operand reached by
     // bumping M0 (the ping-pong schedule issues a stage back-to-back, so the SALU traffic around each DMA matters)
     auto issue_stage = [&](int stage_buf) {
-        const unsigned da = lds0 + stage_buf * STAGE + wid * PA * 1024, db = lds0 + stage_buf * STAGE + TA::BYTES + wid * PB * 1024;
+        const unsigned da = lds0 + AOFF + stage_buf * TA::BYTES + wid * PA * 1024, db = lds0 + BOFF + stage_buf * TB::BYTES + wid * PB * 1024;
         unsigned keep;
         static_assert(!PP || (PB == 2 && (PA == 1 || PA == 2)), "issue_stage handles 1-2 A pieces and 2 B pieces per wave");
         if constexpr (!PP) { (void)da; (void)db; (void)keep; }
@@ -528,6 +559,26 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
         for (int j = 0; j < PA; ++j) pa[j] += astep;
 #pragma unroll
         for (int j = 0; j < PB; ++j) pb[j] += bstep;
+    };
+    // the same stage in two halves (CTMI_PP_SPLIT_DMA): the A pieces in the load phase, the B pieces one by one inside the MFMA phase
+    auto issue_A = [&](int stage_buf) {
+        const unsigned da = lds0 + AOFF + stage_buf * TA::BYTES + wid * PA * 1024;
+        unsigned keep;
+        if constexpr (!PP) { (void)da; (void)keep; }
+        else if constexpr (PA == 2) {
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(pa[0]), "v"(pa[1]), "s"(da) : "memory", "scc");
+        } else {
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(pa[0]), "s"(da) : "memory");
+        }
+#pragma unroll
+        for (int j = 0; j < PA; ++j) pa[j] += astep;
+    };
+    auto issue_B = [&](int stage_buf, int jb) {
+        glds16(pb[jb], lds0 + BOFF + stage_buf * TB::BYTES + (wid * PB + jb) * 1024);
+        pb[jb] += bstep;
     };
     auto stage_issued = [&]() {                                               // bookkeeping after a whole stage went out
         if (++ti == nti) { wi += G; if (wi < nwork) setup_issue(); }
@@ -881,6 +932,10 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
     }
     };
 
+#if CTMI_GEMM_TIMING
+    unsigned long long tlast = __builtin_amdgcn_s_memtime(), t_pro = 0, t_loop = 0, t_epi = 0;
+    const unsigned long long t_begin = tlast;
+#endif
     setup_issue();
     int inflight = 0;                                                         // stages issued and not yet consumed
     int rd = 0, wrb = 0;                                                      // ring positions: read stage, next write stage
@@ -902,6 +957,15 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
             else if (n == 1) { if (LOADS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         };
+        // split issue: `n` younger stages may stay in flight, the youngest of them (if `half`) with its A pieces only
+        auto wait_split = [&](int n, bool half) {
+            static_assert(NST == 4 || !CTMI_PP_SPLIT_DMA, "the split-issue waits are spelled out for the 4-stage ring");
+            if (n >= 2 && half) { if (LOADS == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+            else if (n >= 2) { if (LOADS == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+            else if (n == 1 && half) { if (LOADS == 4) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); }
+            else if (n == 1) { if (LOADS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
 #pragma unroll 1
         for (int s = 0; s < NST - 1 && wi < nwork; ++s) {
             issue_stage(wrb);
@@ -910,42 +974,118 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
         wait_stages(inflight - 1);
         __builtin_amdgcn_s_barrier();
         if (wr == 1) __builtin_amdgcn_s_barrier();                            // stagger the two row groups by one phase
+        GEMM_TICK(t_pro);
+#if CTMI_GEMM_TIMING
+        unsigned long long ph_issue = 0, ph_wait = 0, ph_bar1 = 0, ph_mfma = 0, ph_bar2 = 0;
+#endif
         int cw = bid, tc = 0, ntc;
         int64_t m0, n0; int split;
         decode(cw, m0, n0, split);
         ntc = (int)((min(g.K, (int64_t)(split + 1) * g.k_per_split) - (int64_t)split * g.k_per_split) / BK);
         for (;;) {
-            const unsigned char* as = smem_raw + rd * STAGE;
-            const unsigned char* bs = as + TA::BYTES;
+            bool tile_done = false;
+            if constexpr (CTMI_PP_UNROLL && NST == 4 && !CTMI_PP_SPLIT_DMA && !CTMI_GEMM_TIMING) {
+                // steady state: ring at position 0 with three stages in flight, >= 4 K-steps left in this tile and >= 4 stages left to issue
+                // (the issue side runs three stages ahead and may cross into the next work item inside the group)
+                // — and all four of THIS work item: the switch to the next item (setup_issue: 64-bit address arithmetic that needs scratch
+                // registers) stays out of the unrolled body; it happens at the end of the trip or in a generic step
+                while (rd == 0 && inflight == NST - 1 && ntc - tc >= 4 && !GEMM_DBG(g) && wi < nwork && nti - ti >= 4) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const unsigned char* as = smem_raw + AOFF + u * TA::BYTES;
+                        const unsigned char* bs = smem_raw + BOFF + u * TB::BYTES;
+                        short8 af[WM], bf[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) bf[j] = TB::frag(bs, wc * 64 + j * 16, lane);
+#pragma unroll
+                        for (int i = 0; i < WM; ++i) af[i] = TA::frag(as, wr * (WM * 16) + i * 16, lane);
+                        issue_stage((u + 3) & 3);
+                        ++ti;
+                        wait_stages(2);
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                        __builtin_amdgcn_s_barrier();
+                        __builtin_amdgcn_sched_barrier(0);
+                        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                        for (int i = 0; i < WM; ++i)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(bf[j], af[i], acc[i][j]);
+                        __builtin_amdgcn_s_setprio(0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        __builtin_amdgcn_s_barrier();
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (ti == nti) { wi += G; if (wi < nwork) setup_issue(); }
+                    tc += 4;
+                    if (tc == ntc) { tile_done = true; break; }
+                }
+            }
+            if (!tile_done) {
+            const unsigned char* as = smem_raw + AOFF + rd * TA::BYTES;
+            const unsigned char* bs = smem_raw + BOFF + rd * TB::BYTES;
             short8 af[WM], bf[4];
+#if CTMI_GEMM_TIMING
+            unsigned long long pl = __builtin_amdgcn_s_memtime();
+#define PH_TICK(acc) do { const unsigned long long n__ = __builtin_amdgcn_s_memtime(); acc += n__ - pl; pl = n__; } while (0)
+#else
+#define PH_TICK(acc) do { } while (0)
+#endif
             if (!(GEMM_DBG(g) & 4) || tc == 0) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) bf[j] = TB::frag(bs, wc * 64 + j * 16, lane);
 #pragma unroll
                 for (int i = 0; i < WM; ++i) af[i] = TA::frag(as, wr * (WM * 16) + i * 16, lane);
             }
-            if (wi < nwork && !(GEMM_DBG(g) & 1)) {
-                issue_stage(wrb);
-                stage_issued(); ++inflight; wrb = wrb == NST - 1 ? 0 : wrb + 1;
+            const bool more = wi < nwork && !(GEMM_DBG(g) & 1);
+            if constexpr (CTMI_PP_SPLIT_DMA) {
+                if (more) { issue_A(wrb); ++inflight; }
+                wait_split(inflight - 2, more);
+            } else {
+                if (more) {
+                    issue_stage(wrb);
+                    stage_issued(); ++inflight; wrb = wrb == NST - 1 ? 0 : wrb + 1;
+                }
+                PH_TICK(ph_issue);
+                wait_stages(inflight - 2);
             }
-            wait_stages(inflight - 2);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PH_TICK(ph_wait);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
+            PH_TICK(ph_bar1);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(bf[j], af[i], acc[i][j]);
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j] = Mma<T>::mma(bf[j], af[i], acc[i][j]);
+                    if constexpr (CTMI_PP_SPLIT_DMA) {
+                        constexpr int NM = WM * 4;
+                        const int idx = i * 4 + j;
+                        if (idx == NM / 4 - 1 || idx == (3 * NM) / 4 - 1) {
+                            if (more) issue_B(wrb, idx == NM / 4 - 1 ? 0 : 1);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+            if constexpr (CTMI_PP_SPLIT_DMA) {
+                if (more) { stage_issued(); wrb = wrb == NST - 1 ? 0 : wrb + 1; }
+            }
             __builtin_amdgcn_s_setprio(0);
+            PH_TICK(ph_mfma);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
+            PH_TICK(ph_bar2);
             rd = rd == NST - 1 ? 0 : rd + 1;
             --inflight;
             if (++tc < ntc) continue;
+            }
+            GEMM_TICK(t_loop);
             epilogue(m0, n0, split);
+            GEMM_TICK(t_epi);
             cw += G;
             if (cw >= nwork) break;
             decode(cw, m0, n0, split);
@@ -957,6 +1097,13 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
                 for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         if (wr == 0) __builtin_amdgcn_s_barrier();
+#if CTMI_GEMM_TIMING
+        if (tid == 0 && bid < 2048) { g_gemm_ticks[bid * 4] = t_pro; g_gemm_ticks[bid * 4 + 1] = t_loop; g_gemm_ticks[bid * 4 + 2] = t_epi; g_gemm_ticks[bid * 4 + 3] = __builtin_amdgcn_s_memtime() - t_begin; }
+        if (lane == 0 && (wid == 0 || wid == NW - 1) && bid < 128) {
+            unsigned long long* d = g_gemm_phase + (bid * 2 + (wid == 0 ? 0 : 1)) * 8;
+            d[0] = ph_issue; d[1] = ph_wait; d[2] = ph_bar1; d[3] = ph_mfma; d[4] = ph_bar2;
+        }
+#endif
         return;
     }
 #pragma unroll 1
@@ -966,6 +1113,7 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
         stage_issued(); ++inflight; wrb = wrb == NST - 1 ? 0 : wrb + 1;
     }
     // ---- compute side
+    GEMM_TICK(t_pro);
     int cw = bid, tc = 0, ntc;
     int64_t m0, n0; int split;
     decode(cw, m0, n0, split);
@@ -979,8 +1127,8 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!(GEMM_DBG(g) & 2)) __builtin_amdgcn_s_barrier();                      // everyone's stage landed; the previous one is fully consumed
         const bool more = (wi < nwork) && !(GEMM_DBG(g) & 1);
-        const unsigned char* as = smem_raw + rd * STAGE;
-        const unsigned char* bs = as + TA::BYTES;
+        const unsigned char* as = smem_raw + AOFF + rd * TA::BYTES;
+        const unsigned char* bs = smem_raw + BOFF + rd * TB::BYTES;
         short8 af[WM], bf[4];
         if (!(GEMM_DBG(g) & 4) || tc == 0) {
 #pragma unroll
@@ -1007,7 +1155,9 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
         --inflight;
         if (more) { stage_issued(); ++inflight; wrb = wrb == NST - 1 ? 0 : wrb + 1; }
         if (++tc < ntc) continue;
+        GEMM_TICK(t_loop);
         epilogue(m0, n0, split);
+        GEMM_TICK(t_epi);
         cw += G;
         if (cw >= nwork) break;
         decode(cw, m0, n0, split);
@@ -1018,6 +1168,9 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+#if CTMI_GEMM_TIMING
+    if (tid == 0 && bid < 2048) { g_gemm_ticks[bid * 4] = t_pro; g_gemm_ticks[bid * 4 + 1] = t_loop; g_gemm_ticks[bid * 4 + 2] = t_epi; g_gemm_ticks[bid * 4 + 3] = __builtin_amdgcn_s_memtime() - t_begin; }
+#endif
 }
 
 // C[m,n] = alpha * sum_s slabs[s][m][n] (+ C_old)   — deterministic split-K reduction
@@ -1237,7 +1390,16 @@ static int gemm_unsupported(int ak, int bk, int epi, int out_f32) {
     return CTMI_ERR_UNSUPPORTED;
 }
 
+#if CTMI_GEMM_TIMING
+#define CTMI_TICKS_ACCESSOR(name) extern "C" int name(unsigned long long* host_out, int n) { \
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gemm_ticks), (size_t)n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; } \
+    extern "C" int name##_phase(unsigned long long* host_out, int n) { \
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gemm_phase), (size_t)n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
+#else
+#define CTMI_TICKS_ACCESSOR(name)
+#endif
 #if CTMI_GEMM_HAS(1)
+CTMI_TICKS_ACCESSOR(ctmi_gemm_debug_ticks_nt)
 int ctmi_gemm_bf16_nt(GemmArgs& g, int epi, bool fast, hipStream_t st) {
     if (epi == CTMI_EPI_NONE) return gemm_launch<bf16_t, bf16_t, false, false, CTMI_EPI_NONE>(g, fast, st);
     if (epi == CTMI_EPI_GELU) return gemm_launch<bf16_t, bf16_t, false, false, CTMI_EPI_GELU>(g, fast, st);
@@ -1248,6 +1410,7 @@ int ctmi_gemm_bf16_nt(GemmArgs& g, int epi, bool fast, hipStream_t st) {
 }
 #endif
 #if CTMI_GEMM_HAS(2)
+CTMI_TICKS_ACCESSOR(ctmi_gemm_debug_ticks_nn)
 int ctmi_gemm_bf16_nn(GemmArgs& g, int epi, bool fast, hipStream_t st) {
     if (epi == CTMI_EPI_NONE) return gemm_launch<bf16_t, bf16_t, false, true, CTMI_EPI_NONE>(g, fast, st);
     if (epi == CTMI_EPI_DGELU) return gemm_launch<bf16_t, bf16_t, false, true, CTMI_EPI_DGELU>(g, fast, st);
@@ -1258,6 +1421,7 @@ int ctmi_gemm_bf16_nn(GemmArgs& g, int epi, bool fast, hipStream_t st) {
 }
 #endif
 #if CTMI_GEMM_HAS(3)
+CTMI_TICKS_ACCESSOR(ctmi_gemm_debug_ticks_tn)
 int ctmi_gemm_bf16_tn(GemmArgs& g, int epi, bool fast, hipStream_t st) {
     if (epi == CTMI_EPI_NONE) return gemm_launch<bf16_t, float, true, true, CTMI_EPI_NONE>(g, fast, st);
     return gemm_unsupported(1, 1, epi, 1);
