@@ -153,6 +153,9 @@ def main(argv=None):
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("CTMI_GEMM_SHARED", "1")     # RCCL kernels share the CUs under backward
+        # RCCL runs one workgroup per channel: bound the CUs the collectives may hold (and, with CTMI_DDP_LAUNCH_POLICY=reserve, keep
+        # exactly that many out of the persistent GEMM launches — trainer/ddp.py); read when the communicator is created
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", os.environ.get("CTMI_DDP_COMM_CUS", "16"))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl")                    # "nccl" == RCCL on ROCm
 
@@ -274,7 +277,11 @@ def main(argv=None):
             "config": {"workload": f"Bloom-560M ({L}L, H=1024, nh=16, V={V}) SFT step fwd+bwd+AdamW, B={B} S={S} per GPU "
                                    f"(BASELINE configs[1]), random-init weights, fp32 master/grads/Adam state",
                        "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}",
-                       "comm_dtype": args.comm_dtype if world > 1 else None, "padded_sample": padded},
+                       "comm_dtype": args.comm_dtype if world > 1 else None,
+                       "comm": None if world == 1 else {"nccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS"),
+                                                        "launch_policy": os.environ.get("CTMI_DDP_LAUNCH_POLICY", "shared"),
+                                                        "tied_chunk_mb": os.environ.get("CTMI_DDP_TIED_CHUNK_MB", "64")},
+                       "padded_sample": padded},
             "timing": {"value_from": "median of the per-step HIP-event times of the timed steps (max over ranks)",
                        "ms_per_step_median": round(med_ms, 3), "ms_per_step_mean_wall": round(mean_ms, 3),
                        "ms_per_step_min": round(min(per_step_ms), 3), "ms_per_step_max": round(max(per_step_ms), 3),

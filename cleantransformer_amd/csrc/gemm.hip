@@ -1007,10 +1007,13 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
                         __builtin_amdgcn_s_barrier();
                         __builtin_amdgcn_sched_barrier(0);
                         __builtin_amdgcn_s_setprio(1);
+                        // in-place accumulation spelled as asm ("+v": destination == C operand): with the builtin hipcc renames the 128
+                        // accumulator registers from step to step and restores them through scratch at the back edge of the trip
 #pragma unroll
                         for (int i = 0; i < WM; ++i)
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(bf[j], af[i], acc[i][j]);
+                            for (int j = 0; j < 4; ++j)
+                                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(bf[j]), "v"(af[i]));
                         __builtin_amdgcn_s_setprio(0);
                         __builtin_amdgcn_sched_barrier(0);
                         __builtin_amdgcn_s_barrier();

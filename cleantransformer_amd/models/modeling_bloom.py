@@ -291,7 +291,9 @@ class EmbedFn(torch.autograd.Function):
         if tie is not None:
             tie.embed_wants = weight.requires_grad
             sync = getattr(weight, "_ct_tied_sync", None)               # set by trainer/ddp.py on the shared [V,H] parameter
-            if sync is not None and weight.requires_grad and sync.owner.require_backward_grad_sync:
+            # (gated like the early path itself — _TiedGradSync.prescale: syncing, more than one rank, no accumulated gradient pending —
+            # so a forward that will take the generic bucket path, or no backward at all, issues no collective)
+            if sync is not None and weight.requires_grad and ctx.needs_input_grad[1] and sync.prescale(weight) is not None:
                 sync.announce(ids.numel(), weight.device)              # ranks agree on the row capacity of this step's exchange
         return out
 
@@ -355,6 +357,18 @@ class LMHeadFn(torch.autograd.Function):
             dw = ops.linear_wgrad(dp, h2, alpha=1.0 if pre is None else pre)[:V]
         else:
             d2 = d2 if d2.is_contiguous() else d2.contiguous()
+            rows = sync.chunk_rows(V, H) if pre is not None else V
+            if rows < V:
+                # data parallel: the [V,H] weight gradient in row pieces, each handed to the all-reduce as soon as its GEMM is enqueued
+                # (dW[c0:c1] = dlogits[:, c0:c1]^T h: the K-major A operand is a column window of dlogits, no copy)
+                dw = torch.empty((V, H), dtype=torch.float32, device=d2.device)
+                for c0 in range(0, V, rows):
+                    c1 = min(V, c0 + rows)
+                    ops.gemm(d2[:, c0:], V, True, h2, H, True, c1 - c0, H, B * S, out=dw[c0:c1], out_f32=True, alpha=pre)
+                    sync.begin(dw[c0:c1])
+                tie.pending, tie.early = dw, sync
+                dh = ops.linear_dgrad(d2, wc)
+                return dh.view(B, S, H), None, None
             dh = ops.linear_dgrad(d2, wc)
             dw = ops.linear_wgrad(d2, h2, alpha=1.0 if pre is None else pre)
         if tied:

@@ -60,8 +60,9 @@ class _TiedGradSync:
 
     def __init__(self, owner: "DistributedDataParallel"):
         self.owner = owner
-        self.work = None
+        self.works = []
         self.active = False
+        self._pad_rows_for_test = 0                                  # tests only: extra row capacity, so that the padded exchange runs on one rank
         self.steps = 0                                               # how many backward passes took the early path
         self._tmax = None                                            # agreed row capacity of this step's exchange (announce)
         self._announced = False
@@ -86,6 +87,9 @@ class _TiedGradSync:
         o = self.owner
         self._tmax = None
         self._announced = True
+        if o.world_size == 1 and self._pad_rows_for_test == 0 and os.environ.get("CTMI_DDP_TIED_EARLY_AT_WORLD1") != "1":
+            self._tmax = int(n_tokens)                               # single rank: nothing to agree on, no collective
+            return
         on_rccl = dist.get_backend(o.process_group) == "nccl" and torch.device(device).type == "cuda"
         if o.world_size == 1 and not on_rccl:
             self._tmax = int(n_tokens)
@@ -116,14 +120,38 @@ class _TiedGradSync:
             self._tmax = int(self._thost[0])
         if self._tmax < n_local:
             raise RuntimeError(f"tied-gradient row exchange: announced capacity {self._tmax} < local rows {n_local}")
-        return self._tmax
+        return self._tmax + self._pad_rows_for_test
+
+    CHUNK_ROWS_BYTES = 64 * _MiB                                   # one piece of the dense [V,H] reduction (fp32 bytes)
+
+    def chunk_rows(self, V: int, H: int) -> int:
+        """Rows per piece of the chunked dense reduction: <= 64 MiB of fp32, a multiple of 256 rows (whole GEMM tiles; at
+        H = 1024 that is 16384 rows = 64 x 4 tiles of 256 x 256 = exactly one round of the 256 CUs).  CTMI_DDP_TIED_CHUNK_MB
+        overrides; 0 = one piece."""
+        explicit = os.environ.get("CTMI_DDP_TIED_CHUNK_ROWS")        # (tests: any row count, so that tiny vocabularies take the path too)
+        if explicit is not None:
+            return max(1, min(int(explicit), V))
+        mb = os.environ.get("CTMI_DDP_TIED_CHUNK_MB")
+        nbytes = self.CHUNK_ROWS_BYTES if mb is None else int(float(mb) * _MiB)
+        if nbytes <= 0:
+            return V
+        rows = max(256, (nbytes // (4 * H)) // 256 * 256)
+        return min(rows, V)
 
     def begin(self, dw: torch.Tensor) -> None:
-        """dw = dW_lm_head / world (contiguous fp32 [V,H]): start its all-reduce now, under the rest of backward."""
+        """dw = dW_lm_head / world (contiguous fp32 [V,H] or a row range of it): start its all-reduce now, under the rest of
+        backward.  Called once per piece when the LM-head weight gradient is produced in row chunks (each piece's
+        collective is enqueued as soon as its GEMM is — communication starts after 1/16 of the weight-gradient work instead
+        of after all of it, and no single collective is larger than 64 MiB)."""
         o = self.owner
-        self.work = dist.all_reduce(dw, op=dist.ReduceOp.SUM, group=o.process_group, async_op=True)
-        self.active = True
-        self.steps += 1
+        self.works.append(dist.all_reduce(dw, op=dist.ReduceOp.SUM, group=o.process_group, async_op=True))
+        if o._launch_events is not None and dw.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            o._launch_events.append(("tied", ev))
+        if not self.active:
+            self.active = True
+            self.steps += 1
 
     def finish(self, dw: torch.Tensor, drows: torch.Tensor, ids: torch.Tensor) -> None:
         o = self.owner
@@ -156,8 +184,9 @@ class _TiedGradSync:
         else:
             dist.all_gather(list(all_ids.unbind(0)), ids, group=o.process_group)
             dist.all_gather(list(all_rows.unbind(0)), drows, group=o.process_group)
-        self.work.wait()
-        self.work = None
+        for w in self.works:
+            w.wait()
+        self.works = []
         self._tmax, self._announced = None, False
         _embed_scatter(all_rows.view(-1, Hc), all_ids.view(-1), dw, 1.0 / W)
 
@@ -233,17 +262,29 @@ class DistributedDataParallel(torch.nn.Module):
             for j, p in enumerate(b.params):
                 self._where[id(p)] = (b, j)
         self._callback_queued = False
+        self._launch_events = None                                    # record_launch_events(): [(kind, event)] of this step's collectives
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad_ready) for p in self._params]
 
     def _arm_launch_policy(self):
-        """world > 1: the all-reduce kernels will hold CUs under backward — switch the GEMM launcher to its shared-GPU policy
-        (ctmi_set_launch_policy; csrc/gemm.hip).  An explicit library call, re-made at every training forward, so it also
-        takes effect for a model that already ran GEMMs before it was wrapped (CTMI_DDP_LAUNCH_POLICY=0 leaves it alone)."""
-        if self.world_size > 1 and os.environ.get("CTMI_DDP_LAUNCH_POLICY", "1") != "0" and \
-                any(p.is_cuda for p in self.module.parameters()):
+        """world > 1: the all-reduce kernels will hold CUs under backward — switch the GEMM launcher to a policy that tolerates it
+        (ctmi_set_launch_policy; csrc/gemm.hip).  An explicit library call, re-made at every training forward, so it also takes
+        effect for a model that already ran GEMMs before it was wrapped.
+          CTMI_DDP_LAUNCH_POLICY = "shared" (default, also "1"): no persistent launches — one workgroup per tile, the hardware
+              dispatcher flows them over whatever CUs the collectives leave free;
+          "reserve": persistent launches on 256 - R CUs, R = CTMI_DDP_COMM_CUS (default 16) — meant to be paired with
+              NCCL_MAX_NCHANNELS = R (RCCL runs one workgroup per channel; bench.py exports both before init_process_group, the
+              communicator reads the variable when it is created), so the R channels always find a free CU and the GEMMs never wait
+              for one they cannot get;
+          "0": leave the launcher alone."""
+        mode = os.environ.get("CTMI_DDP_LAUNCH_POLICY", "shared").lower()
+        if self.world_size > 1 and mode != "0" and any(p.is_cuda for p in self.module.parameters()):
             from .. import ops
-            if not ops.get_launch_policy()[0]:
-                ops.set_launch_policy(True)
+            if mode == "reserve":
+                want = (False, max(0, min(128, int(os.environ.get("CTMI_DDP_COMM_CUS", "16")))))
+            else:
+                want = (True, ops.get_launch_policy()[1])
+            if ops.get_launch_policy() != want:
+                ops.set_launch_policy(*want)
 
     # ---------------------------------------------------------------- construction-time broadcast (rank 0 wins)
     def _sync_module_states(self):
@@ -315,6 +356,10 @@ class DistributedDataParallel(torch.nn.Module):
             _cast(b.flat, b.comm)                                   # one pass per bucket; the collective is enqueued behind it
             wire = b.comm
         b.work = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
+        if self._launch_events is not None and wire.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._launch_events.append(("bucket", ev))
 
     def _finalize_backward(self):
         self._callback_queued = False
@@ -333,6 +378,12 @@ class DistributedDataParallel(torch.nn.Module):
                 # view — what lm_head.weight.grad[100:110, 100:110], ft_bloom_DDP.py:148, needs)
                 p.grad = b.flat[off:off + p.numel()].view(p.shape)
             b.work = None
+
+    def record_launch_events(self, on: bool = True) -> list:
+        """Diagnostics / tests: from now on every collective launched by the backward hooks records a HIP event on the compute
+        stream at its launch point (("bucket" | "tied", event)); returns the list they are appended to (cleared here)."""
+        self._launch_events = [] if on else None
+        return self._launch_events
 
     @contextmanager
     def no_sync(self):
@@ -353,7 +404,7 @@ class DistributedDataParallel(torch.nn.Module):
             b.work = None
         if self._tied_sync is not None:
             self._tied_sync.active = False
-            self._tied_sync.work = None
+            self._tied_sync.works = []
 
     def forward(self, *inputs, **kwargs):
         if torch.is_grad_enabled():

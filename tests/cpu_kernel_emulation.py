@@ -42,10 +42,9 @@ def layernorm_bwd(dy, x, w, mean, rstd, dres=None):
 
 def gemm(A, lda, a_kmajor, B, ldb, b_kmajor, M, N, K, *, out=None, out_f32=False, bias=None, residual=None, epilogue=0,
          aux_in=None, aux_out=None, alpha=1.0, beta=0, tag=None):
-    a = A.reshape(-1)[: (K if a_kmajor else M) * lda].view(-1, lda)
-    a = a[:, :M].t() if a_kmajor else a[:, :K]
-    b = B.reshape(-1)[: (K if b_kmajor else N) * ldb].view(-1, ldb)
-    b = b[:, :N] if b_kmajor else b[:, :K].t()
+    # pointer + leading-dimension semantics of the C ABI (A / B may be windows of a larger buffer: element 0 of the view is the origin)
+    a = A.as_strided((K, M), (lda, 1)).t() if a_kmajor else A.as_strided((M, K), (lda, 1))
+    b = B.as_strided((K, N), (ldb, 1)) if b_kmajor else B.as_strided((N, K), (ldb, 1)).t()
     v = alpha * (a.float() @ b.float())
     if bias is not None:
         v = v + bias

@@ -105,8 +105,13 @@ def _worker(rank, world, port, bucket_mb, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,bucket_mb", [(2, 25), (2, 0.05), (4, 0.2)])
-def test_ddp_matches_torch_ddp_on_reference_model(world, bucket_mb):
+@pytest.mark.parametrize("world,bucket_mb", [(2, 25), (2, 0.05), (4, 0.2), (2, -64)])
+def test_ddp_matches_torch_ddp_on_reference_model(world, bucket_mb, monkeypatch):
+    """bucket_mb < 0: the dense part of the tied [V,H] gradient in row pieces of -bucket_mb rows (V = 211: 64 + 64 + 64 + 19), each
+    piece produced by its own weight-gradient GEMM over a column window of dlogits and handed to its own all-reduce."""
+    if bucket_mb < 0:
+        monkeypatch.setenv("CTMI_DDP_TIED_CHUNK_ROWS", str(-bucket_mb))
+        bucket_mb = 25
     gold = np.load(os.path.join(G, "ddp_tiny.npz"))
     mgr = mp.Manager()
     ret = mgr.dict()
@@ -317,8 +322,8 @@ def _uneven_worker(rank, world, port, ret):
     for b in ddp._buckets:                                       # drain what the failed pass left in flight
         if b.work is not None:
             b.work.wait()
-    if ddp._tied_sync.work is not None:
-        ddp._tied_sync.work.wait()
+    for w in ddp._tied_sync.works:
+        w.wait()
     dist.barrier()
     again = run()
     ok_after_failure = bool(torch.allclose(again, want, rtol=1e-4, atol=1e-8))
@@ -335,3 +340,19 @@ def test_ddp_uneven_sequence_lengths_and_failed_backward_recovery(world):
     assert ret["took_early"] == 1, "the tied [V,H] gradient must still take its early dense + row-exchange path"
     assert ret["ok_uneven"], "averaged gradients with rank-dependent T differ from the mean of the local gradients"
     assert ret["raised"] and ret["ok_after_failure"]
+
+
+def test_tied_chunk_rows_policy(monkeypatch):
+    """<= 64 MiB of fp32 per piece, whole 256-row tiles: 16384 rows at H = 1024 (one round of 256 x 256 tiles on 256 CUs), the
+    whole tensor when it is smaller than a piece, overrides honoured."""
+    from cleantransformer_amd.trainer.ddp import _TiedGradSync
+    t = _TiedGradSync.__new__(_TiedGradSync)
+    monkeypatch.delenv("CTMI_DDP_TIED_CHUNK_MB", raising=False)
+    monkeypatch.delenv("CTMI_DDP_TIED_CHUNK_ROWS", raising=False)
+    assert t.chunk_rows(250880, 1024) == 16384 and 16384 * 1024 * 4 == 64 * 1024 * 1024
+    assert t.chunk_rows(250880, 4096) == 4096
+    assert t.chunk_rows(211, 64) == 211
+    monkeypatch.setenv("CTMI_DDP_TIED_CHUNK_MB", "0")
+    assert t.chunk_rows(250880, 1024) == 250880
+    monkeypatch.setenv("CTMI_DDP_TIED_CHUNK_ROWS", "64")
+    assert t.chunk_rows(211, 64) == 64

@@ -323,7 +323,7 @@ def test_ddp_wrapper_on_rccl_single_rank():
     code = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, os.getcwd())
-os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", CTMI_DDP_TIED_EARLY_AT_WORLD1="1")
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", CTMI_DDP_TIED_EARLY_AT_WORLD1="1", CTMI_DDP_TIED_CHUNK_ROWS="256")
 dist.init_process_group("nccl", rank=0, world_size=1)
 from cleantransformer_amd.models.modeling_bloom import BloomConfig, BloomForCausalLM
 from cleantransformer_amd.trainer.ddp import DistributedDataParallel as DDP
@@ -339,11 +339,14 @@ am = torch.ones(2, 64, dtype=torch.long, device=dev)
 ref = make()
 (l0, _, _), _ = ref(input_ids=ids, attention_mask=am, labels=ids.clone()); l0.backward()
 m = make(); ddp = DDP(m, device_ids=[0], bucket_cap_mb=0.25)
+ddp._tied_sync._pad_rows_for_test = 37          # capacity != local rows: the padded id / row exchange (all_gather_into_tensor) on the real backend
+evs = ddp.record_launch_events()
 for it in range(2):
     for p in m.parameters(): p.grad = None
     (l1, _, _), _ = ddp(input_ids=ids, attention_mask=am, labels=ids.clone()); l1.backward()
 torch.cuda.synchronize()
 assert ddp._tied_sync.steps == 2, ddp._tied_sync.steps
+assert sum(1 for k, _ in evs if k == "tied") == 2 * 4, evs   # V = 1000 in row pieces of 256: four dense all-reduces per step
 assert len(ddp.bucket_summary()) >= 3
 assert abs(float(l0) - float(l1)) < 1e-6
 for (n, a), (_, b) in zip(ref.named_parameters(), m.named_parameters()):
@@ -382,13 +385,23 @@ def _two_rank_worker(rank, world, port, ret):
         am[0, 11:] = 0
     am = am.to(DEV)
     ddp.train()
-    for _ in range(2):                                         # second pass: gradients are bucket views by then
+    os.environ["CTMI_DDP_TIED_CHUNK_ROWS"] = "64"             # V = 211: the tied dense part in four row pieces
+    for it in range(2):                                        # second pass: gradients are bucket views by then
         for p in m.parameters():
             p.grad = None
         (loss, _, _), _ = ddp(input_ids=ids, attention_mask=am, labels=ids.clone())
+        if it == 1:
+            evs = ddp.record_launch_events()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         loss.backward()
+        if it == 1:
+            e1.record()
     torch.cuda.synchronize()
     if rank == 0:
+        # where in the backward's stream of kernels each collective was launched (fraction of the backward's device time)
+        span = e0.elapsed_time(e1)
+        ret["launch_pos"] = [(k, e0.elapsed_time(ev) / span) for k, ev in evs]
         ret["loss0"] = float(loss)
         ret["early"] = ddp._tied_sync.steps
         ret["nbuckets"] = len(ddp.bucket_summary())
@@ -419,6 +432,15 @@ def test_ddp_two_ranks_sharing_the_gpu_match_torch_ddp_golden():
             name = k[len("w2_"):]
             a, b = ret["g_" + name], gold[k]
             assert a.shape == b.shape and np.allclose(a, b, rtol=1e-4, atol=2e-7), (name, float(np.abs(a - b).max()))   # fp32 GEMM summation order on the GPU
+    # overlap by construction: the collectives are launched from the gradient hooks INSIDE the backward's kernel stream, not queued
+    # behind it — the tied dense pieces first (the LM head is the first backward op), the buckets spread over the rest
+    pos = ret["launch_pos"]
+    tied = [p for k, p in pos if k == "tied"]
+    buckets = [p for k, p in pos if k == "bucket"]
+    assert len(tied) == 4 and len(buckets) >= 2, pos
+    assert max(tied) < min(buckets) and tied == sorted(tied) and buckets == sorted(buckets), pos
+    assert tied[0] < 0.5 and buckets[0] < 0.9 and buckets[-1] <= 1.0 + 1e-6, pos
+    assert buckets[-1] - buckets[0] > 0.05, pos                       # not one clump at the end
 
 
 class _cpu_threads:
