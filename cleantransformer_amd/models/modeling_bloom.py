@@ -269,6 +269,7 @@ class _TieCtx:
 
     def __init__(self):
         self.pending: Optional[Tensor] = None
+        self.n_tokens = 0
         self.embed_wants = False
         self.early = None              # the data-parallel wrapper's tied-gradient reducer, once it took the LM-head part
 
@@ -290,11 +291,8 @@ class EmbedFn(torch.autograd.Function):
         ctx.vh, ctx.tie = tuple(weight.shape), tie
         if tie is not None:
             tie.embed_wants = weight.requires_grad
-            sync = getattr(weight, "_ct_tied_sync", None)               # set by trainer/ddp.py on the shared [V,H] parameter
-            # (gated like the early path itself — _TiedGradSync.prescale: syncing, more than one rank, no accumulated gradient pending —
-            # so a forward that will take the generic bucket path, or no backward at all, issues no collective)
-            if sync is not None and weight.requires_grad and ctx.needs_input_grad[1] and sync.prescale(weight) is not None:
-                sync.announce(ids.numel(), weight.device)              # ranks agree on the row capacity of this step's exchange
+            tie.n_tokens = ids.numel()        # the data-parallel row exchange agrees on max over ranks of this — at LM-head BACKWARD time
+                                              # (trainer/ddp.py: only a backward that takes the early path issues the collective)
         return out
 
     @staticmethod
@@ -362,6 +360,7 @@ class LMHeadFn(torch.autograd.Function):
                 # data parallel: the [V,H] weight gradient in row pieces, each handed to the all-reduce as soon as its GEMM is enqueued
                 # (dW[c0:c1] = dlogits[:, c0:c1]^T h: the K-major A operand is a column window of dlogits, no copy)
                 dw = torch.empty((V, H), dtype=torch.float32, device=d2.device)
+                sync.announce(tie.n_tokens, d2.device)
                 for c0 in range(0, V, rows):
                     c1 = min(V, c0 + rows)
                     ops.gemm(d2[:, c0:], V, True, h2, H, True, c1 - c0, H, B * S, out=dw[c0:c1], out_f32=True, alpha=pre)
@@ -374,6 +373,7 @@ class LMHeadFn(torch.autograd.Function):
         if tied:
             tie.pending = dw                                   # the embedding backward (always later) finishes and returns it
             if pre is not None:
+                sync.announce(tie.n_tokens, dw.device)
                 sync.begin(dw)
                 tie.early = sync
             dw = None

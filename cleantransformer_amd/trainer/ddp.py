@@ -79,8 +79,11 @@ class _TiedGradSync:
         return 1.0 / o.world_size
 
     def announce(self, n_tokens: int, device) -> None:
-        """Called from the embedding forward (every rank, every forward that will be synchronised): agree on max_r T_r, the
-        row capacity of this step's exchange.  The reference's collate pads each rank's batch to ITS longest sample
+        """Called from the LM-head backward of a step that takes the early path (every rank takes it or none: the conditions —
+        syncing, no accumulated gradient pending — are rank-uniform), with the token count its embedding forward recorded: agree on
+        max_r T_r, the row capacity of this step's exchange.  (Announcing from the forward, as round 2 did, issued a collective for
+        forwards whose backward took the bucket path or never ran — and the reference loop's zero_grad() sits BETWEEN forward and
+        backward, so the forward cannot know which path the backward will take.)  The reference's collate pads each rank's batch to ITS longest sample
         (examples/ft_bloom_DDP.py:45-60, padding=True), so T = B*S differs between ranks; all_gather needs equal extents.
         The maximum is taken by a tiny all-reduce issued now and read at the end of backward; on RCCL it is copied to pinned
         host memory on a side stream, so reading it never waits for the compute stream."""
@@ -113,8 +116,8 @@ class _TiedGradSync:
 
     def _row_capacity(self, n_local: int) -> int:
         if not self._announced:
-            raise RuntimeError("tied-gradient row exchange: the embedding forward of this step did not announce its row count "
-                               "(was the forward run under no_sync() and the backward outside of it?)")
+            raise RuntimeError("tied-gradient row exchange: no row capacity was agreed for this step (the LM-head backward announces it "
+                               "when it starts the early dense reduction)")
         if self._tmax is None:
             self._tevent.synchronize()
             self._tmax = int(self._thost[0])
