@@ -64,6 +64,14 @@ constexpr int glds_patch_bytes(bool pp, int wm, bool xlane = false) { return (pp
 #ifndef CTMI_PP_UNROLL
 #define CTMI_PP_UNROLL 0
 #endif
+// Ping-pong schedule: a STEADY inner loop — as many K-steps as fit before either side (the MFMA side's tile, the DMA side's work item,
+// three stages ahead) reaches a boundary — with one trip counter and none of the generic step's per-step checks (more work? item
+// switch? ring fill? ablation switches?).  The generic step stays for ring fill / drain.  tools/gemm_anatomy.py: the load segment of a
+// step (~64 instructions, half of them bookkeeping, at ~5 cycles of issue each + four LDS-DMA stalls) is longer than the 544 cycles
+// of MFMAs it should hide behind.
+#ifndef CTMI_PP_STEADY
+#define CTMI_PP_STEADY 1
+#endif
 #ifndef CTMI_PP256_XLANE
 #define CTMI_PP256_XLANE 1
 #endif
@@ -1022,6 +1030,43 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
                     if (ti == nti) { wi += G; if (wi < nwork) setup_issue(); }
                     tc += 4;
                     if (tc == ntc) { tile_done = true; break; }
+                }
+            }
+            if constexpr (CTMI_PP_STEADY && !CTMI_PP_SPLIT_DMA && !CTMI_GEMM_TIMING) {
+                if (inflight == NST - 1 && wi < nwork && !GEMM_DBG(g)) {
+                    const int nsteady = min(ntc - tc, nti - ti);                  // >= 1 on both sides here
+#pragma unroll 1
+                    for (int n = nsteady; n > 0; --n) {
+                        const unsigned char* as = smem_raw + AOFF + rd * TA::BYTES;
+                        const unsigned char* bs = smem_raw + BOFF + rd * TB::BYTES;
+                        short8 af[WM], bf[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) bf[j] = TB::frag(bs, wc * 64 + j * 16, lane);
+#pragma unroll
+                        for (int i = 0; i < WM; ++i) af[i] = TA::frag(as, wr * (WM * 16) + i * 16, lane);
+                        issue_stage(wrb);
+                        wait_stages(2);
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                        __builtin_amdgcn_s_barrier();
+                        __builtin_amdgcn_sched_barrier(0);
+                        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                        for (int i = 0; i < WM; ++i)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(bf[j], af[i], acc[i][j]);
+                        __builtin_amdgcn_s_setprio(0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        __builtin_amdgcn_s_barrier();
+                        __builtin_amdgcn_sched_barrier(0);
+                        rd = (rd + 1) & (NST - 1);
+                        wrb = (wrb + 1) & (NST - 1);
+                    }
+                    static_assert(!CTMI_PP_STEADY || (NST & (NST - 1)) == 0 || !PP, "ring positions wrap by masking");
+                    ti += nsteady;
+                    tc += nsteady;
+                    if (ti == nti) { wi += G; if (wi < nwork) setup_issue(); }
+                    if (tc == ntc) tile_done = true;
                 }
             }
             if (!tile_done) {
