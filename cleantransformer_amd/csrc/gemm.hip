@@ -69,6 +69,9 @@ constexpr int glds_patch_bytes(bool pp, int wm, bool xlane = false) { return (pp
 // switch? ring fill? ablation switches?).  The generic step stays for ring fill / drain.  tools/gemm_anatomy.py: the load segment of a
 // step (~64 instructions, half of them bookkeeping, at ~5 cycles of issue each + four LDS-DMA stalls) is longer than the 544 cycles
 // of MFMAs it should hide behind.
+#ifndef CTMI_TILE_RULES_R3
+#define CTMI_TILE_RULES_R3 1   // 0 = the round-2 tile rules, for A/B runs (profiles/r03_gemm_tile_sweep.txt)
+#endif
 #ifndef CTMI_PP_STEADY
 #define CTMI_PP_STEADY 1
 #endif
@@ -1342,13 +1345,16 @@ static void pick_tile(int64_t M, int64_t N, int64_t K, bool wgrad, bool bkm, int
         if (t1 >= 1024) tile = 3;                                   // LM head: [V,H]
         else if (nosplit) tile = nosplit == 2 ? 4 : 3;
         else {
-            tile = t1 >= 128 ? 1 : 0;
+            // round 3 sweep (profiles/r03_gemm_tile_sweep.txt): a weight gradient whose 128x128 tiles already fill the chip (>= 256
+            // of them: h->4h and 4h->h) runs them UNSPLIT — 778-785 TF/s against 651-693 for 256x128 tiles split two ways, and no
+            // fp32 slabs / reduce launch; three such workgroups share a CU with the data-gradient chain of the main stream
+            tile = (CTMI_TILE_RULES_R3 && t0 >= 256) ? 0 : (t1 >= 128 ? 1 : 0);
             const int64_t tiles = tile ? t1 : t0;
             while (splits < max_splits && tiles * splits < CTMI_WGRAD_ITEMS && K / (splits * 2) >= 1024) splits *= 2;
         }
     } else if (K >= 32768 && max_splits >= 2 && t2 * 2 >= 192) { tile = 3; splits = 2; }
     else if (t2 >= 350) tile = 3;
-    else if (t4 >= 256 && (!bkm || K <= 1024)) tile = 4;
+    else if (t4 >= 256 && (CTMI_TILE_RULES_R3 || !bkm || K <= 1024)) tile = 4;                                  // (round 3: also K-major B with long K — 919 vs 861 TF/s on the QKV data gradient)
     else if (t1 >= 700) tile = 1;
     else tile = 0;
     // epilogues that read a second [M,N] operand (activation-derivative input): only the 128-row ping-pong tile has the
