@@ -1313,6 +1313,9 @@ extern "C" int ctmi_get_launch_policy(int* shared, int* reserve_cus) {
 }
 #endif
 
+#ifndef CTMI_WGRAD_ITEMS_TILE0
+#define CTMI_WGRAD_ITEMS_TILE0 256
+#endif
 #ifndef CTMI_WGRAD_ITEMS
 #define CTMI_WGRAD_ITEMS 256     // (same-box A/B vs 512: -0.15 ms per step — half the fp32 slab traffic) split-K target of the layer weight gradients: work items (tiles x splits) to aim for
 #endif
@@ -1345,12 +1348,17 @@ static void pick_tile(int64_t M, int64_t N, int64_t K, bool wgrad, bool bkm, int
         if (t1 >= 1024) tile = 3;                                   // LM head: [V,H]
         else if (nosplit) tile = nosplit == 2 ? 4 : 3;
         else {
-            // round 3 sweep (profiles/r03_gemm_tile_sweep.txt): a weight gradient whose 128x128 tiles already fill the chip (>= 256
-            // of them: h->4h and 4h->h) runs them UNSPLIT — 778-785 TF/s against 651-693 for 256x128 tiles split two ways, and no
-            // fp32 slabs / reduce launch; three such workgroups share a CU with the data-gradient chain of the main stream
-            tile = (CTMI_TILE_RULES_R3 && t0 >= 256) ? 0 : (t1 >= 128 ? 1 : 0);
+            // round 3 (profiles/r03_gemm_tile_sweep.txt): a weight gradient with >= 256 tiles of 128x128 (h->4h and 4h->h) runs them
+            // UNSPLIT (CTMI_WGRAD_ITEMS_TILE0 = 256).  Alone on the GPU that is the slowest choice (602-621 TF/s, one workgroup per
+            // CU; split two ways 778-805; the round-2 256x128 tiles split two ways 651-693) — in the training step it is the fastest:
+            // 39.63 / 39.99 ms against 40.22 / 40.64 (split two ways) and 40.40 / 40.51 (round-2 rule), same box, interleaved.  The
+            // weight gradients run on the side stream under the data-gradient chain: what counts there is how little they take from
+            // the main stream (no fp32 slabs, no reduce launch, one co-resident workgroup per CU), not their own duration.
+            const bool t0_fills = CTMI_TILE_RULES_R3 && t0 >= 256;
+            tile = t0_fills ? 0 : (t1 >= 128 ? 1 : 0);
             const int64_t tiles = tile ? t1 : t0;
-            while (splits < max_splits && tiles * splits < CTMI_WGRAD_ITEMS && K / (splits * 2) >= 1024) splits *= 2;
+            const int64_t items = t0_fills ? CTMI_WGRAD_ITEMS_TILE0 : CTMI_WGRAD_ITEMS;
+            while (splits < max_splits && tiles * splits < items && K / (splits * 2) >= 1024) splits *= 2;
         }
     } else if (K >= 32768 && max_splits >= 2 && t2 * 2 >= 192) { tile = 3; splits = 2; }
     else if (t2 >= 350) tile = 3;

@@ -50,14 +50,14 @@ def test_gemm_kernels_fit_their_occupancy(kernels):
     for name, k in gemms.items():
         assert k["vgpr_count"] <= 256, (name, k["vgpr_count"])                 # two waves per SIMD (eight-wave tiles: one workgroup per CU)
         assert k["agpr_count"] == 0, (name, k["agpr_count"])
-        assert k["vgpr_spill_count"] <= 32, (name, k["vgpr_spill_count"])     # (today: 0 in every K-loop; up to 28 in the 256-row tile's epilogues)
+        assert k["vgpr_spill_count"] <= 40, (name, k["vgpr_spill_count"])     # (today: 0 in every K-loop; up to 36 in the 256-row tile's epilogues)
     # the 128 x 128 free-running tile: three workgroups per CU
     for name, k in gemms.items():
         if ", 4, 2, false, false, false>" in name:
             assert k["vgpr_count"] <= 168 and k["vgpr_spill_count"] == 0, (name, k)
     # the roofline kernel of bench.py (LM-head forward) and the two epilogue choices of the 256-row tile
     (name, k), = pick(kernels, "void gemm_glds_kernel<unsigned short, false, false, 0, 8, 4, true, false, false>").items()
-    assert k["vgpr_spill_count"] == 0, (name, k)
+    assert k["vgpr_spill_count"] <= 4, (name, k)      # (since the steady inner loop: two 64-bit values stored once before the K-loops, reloaded in the edge-tile epilogue)
     (name, k), = pick(kernels, "void gemm_glds_kernel<unsigned short, false, false, 0, 8, 4, true, false, true>").items()
     assert k["vgpr_spill_count"] == 0, (name, k)
 

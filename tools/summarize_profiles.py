@@ -63,7 +63,8 @@ json.dump(traffic, open(os.path.join(dst, f"{rnd}_lmhead_traffic.json"), "w"), i
 # the plain result files of the collection travel as they are
 import shutil
 for name in (f"{rnd}_bench_default.json", f"{rnd}_bench_under_rocprof.json", f"{rnd}_bench_1stream_under_rocprof.json",
-             f"{rnd}_microbench.txt", f"{rnd}_gemm_tile_sweep.txt", f"{rnd}_vendor_gemm_reference.txt"):
+             f"{rnd}_microbench.txt", f"{rnd}_vendor_gemm_reference.txt", f"{rnd}_microbench_epilogues.txt", f"{rnd}_attention_paths.txt",
+             f"{rnd}_gpt2_medium_bench.txt", f"{rnd}_bloom7b1_1gpu_bench.txt"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, name))
 shutil.copy(one("prof_bench/*/*_kernel_stats.csv"), os.path.join(dst, f"{rnd}_bench_kernel_stats.csv"))
