@@ -211,6 +211,76 @@ __device__ __forceinline__ void fill4_future(f32x16& v, int thr, float fill) {
     v[R0] = a; v[R0 + 1] = b; v[R0 + 2] = c; v[R0 + 3] = d;
 }
 
+// The same for a fill value that padding keys do not take (GPT-2's -1e4: padding keys keep finfo.min): a padding key's raw score IS
+// finfo.min (its bias absorbs the dot product exactly), so x[i] = (cc_i > thr && x[i] > finfo.min) ? fill : x[i] needs no second look
+// at the key-bias row — which hipcc would otherwise keep live across the score MFMAs (32 registers and 16 copies per tile).
+template <int R0, int C0>
+__device__ __forceinline__ void fill4_future_keepmin(f32x16& v, int thr, float fill) {
+    constexpr int C1 = C0 + 1, C2 = C0 + 2, C3 = C0 + 3;
+    static_assert(C0 >= 0 && C3 <= 64, "inline integer constants");
+    float a = v[R0], b = v[R0 + 1], c = v[R0 + 2], d = v[R0 + 3];
+    const float fmin = FINFO_MIN;
+    uint64_t m0, m1, m2, m3, n0, n1, n2, n3;
+    asm volatile("v_cmp_lt_i32_e64 %4, %12, %15\n\t"
+                 "v_cmp_lt_i32_e64 %5, %12, %16\n\t"
+                 "v_cmp_lt_i32_e64 %6, %12, %17\n\t"
+                 "v_cmp_lt_i32_e64 %7, %12, %18\n\t"
+                 "v_cmp_lt_f32_e64 %8, %14, %0\n\t"
+                 "v_cmp_lt_f32_e64 %9, %14, %1\n\t"
+                 "v_cmp_lt_f32_e64 %10, %14, %2\n\t"
+                 "v_cmp_lt_f32_e64 %11, %14, %3\n\t"
+                 "s_and_b64 %4, %4, %8\n\t"
+                 "s_and_b64 %5, %5, %9\n\t"
+                 "s_and_b64 %6, %6, %10\n\t"
+                 "s_and_b64 %7, %7, %11\n\t"
+                 "v_cndmask_b32_e64 %0, %0, %13, %4\n\t"
+                 "v_cndmask_b32_e64 %1, %1, %13, %5\n\t"
+                 "v_cndmask_b32_e64 %2, %2, %13, %6\n\t"
+                 "v_cndmask_b32_e64 %3, %3, %13, %7"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&s"(n0), "=&s"(n1), "=&s"(n2), "=&s"(n3)
+                 : "v"(thr), "v"(fill), "v"(fmin), "n"(C0), "n"(C1), "n"(C2), "n"(C3) : "scc");
+    v[R0] = a; v[R0 + 1] = b; v[R0 + 2] = c; v[R0 + 3] = d;
+}
+
+// v[i] = (cc_i > thr  [GT]  or  cc_i < thr  [!GT]) ? 0 : v[i] on TWO accumulators at once (backward: P and dS of the masked pairs), the
+// four compares shared
+template <int R0, int C0, bool GT>
+__device__ __forceinline__ void zero4_pair(f32x16& u, f32x16& v, int thr) {
+    constexpr int C1 = C0 + 1, C2 = C0 + 2, C3 = C0 + 3;
+    static_assert(C0 >= 0 && C3 <= 64, "inline integer constants");
+    float a = u[R0], b = u[R0 + 1], c = u[R0 + 2], d = u[R0 + 3], e = v[R0], f = v[R0 + 1], g = v[R0 + 2], h = v[R0 + 3];
+    uint64_t m0, m1, m2, m3;
+    if constexpr (GT)
+        asm volatile("v_cmp_lt_i32_e64 %8, %12, %13\n\tv_cmp_lt_i32_e64 %9, %12, %14\n\tv_cmp_lt_i32_e64 %10, %12, %15\n\tv_cmp_lt_i32_e64 %11, %12, %16\n\t"
+                     "v_cndmask_b32_e64 %0, %0, 0, %8\n\tv_cndmask_b32_e64 %1, %1, 0, %9\n\tv_cndmask_b32_e64 %2, %2, 0, %10\n\tv_cndmask_b32_e64 %3, %3, 0, %11\n\t"
+                     "v_cndmask_b32_e64 %4, %4, 0, %8\n\tv_cndmask_b32_e64 %5, %5, 0, %9\n\tv_cndmask_b32_e64 %6, %6, 0, %10\n\tv_cndmask_b32_e64 %7, %7, 0, %11"
+                     : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+                     : "v"(thr), "n"(C0), "n"(C1), "n"(C2), "n"(C3));
+    else
+        asm volatile("v_cmp_gt_i32_e64 %8, %12, %13\n\tv_cmp_gt_i32_e64 %9, %12, %14\n\tv_cmp_gt_i32_e64 %10, %12, %15\n\tv_cmp_gt_i32_e64 %11, %12, %16\n\t"
+                     "v_cndmask_b32_e64 %0, %0, 0, %8\n\tv_cndmask_b32_e64 %1, %1, 0, %9\n\tv_cndmask_b32_e64 %2, %2, 0, %10\n\tv_cndmask_b32_e64 %3, %3, 0, %11\n\t"
+                     "v_cndmask_b32_e64 %4, %4, 0, %8\n\tv_cndmask_b32_e64 %5, %5, 0, %9\n\tv_cndmask_b32_e64 %6, %6, 0, %10\n\tv_cndmask_b32_e64 %7, %7, 0, %11"
+                     : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+                     : "v"(thr), "n"(C0), "n"(C1), "n"(C2), "n"(C3));
+    u[R0] = a; u[R0 + 1] = b; u[R0 + 2] = c; u[R0 + 3] = d; v[R0] = e; v[R0 + 1] = f; v[R0 + 2] = g; v[R0 + 3] = h;
+}
+// v[i] = (cc_i > thr || x[i] <= finfo.min) ? 0 : v[i]   (dQ, batch rows with all-masked queries: future pairs and padding keys)
+template <int R0, int C0>
+__device__ __forceinline__ void zero4_masked(f32x16& v, const f32x16& x, int thr) {
+    constexpr int C1 = C0 + 1, C2 = C0 + 2, C3 = C0 + 3;
+    static_assert(C0 >= 0 && C3 <= 64, "inline integer constants");
+    float a = v[R0], b = v[R0 + 1], c = v[R0 + 2], d = v[R0 + 3];
+    const float fmin = FINFO_MIN;
+    uint64_t m0, m1, m2, m3, n0, n1, n2, n3;
+    asm volatile("v_cmp_lt_i32_e64 %4, %12, %18\n\tv_cmp_lt_i32_e64 %5, %12, %19\n\tv_cmp_lt_i32_e64 %6, %12, %20\n\tv_cmp_lt_i32_e64 %7, %12, %21\n\t"
+                 "v_cmp_ge_f32_e64 %8, %13, %14\n\tv_cmp_ge_f32_e64 %9, %13, %15\n\tv_cmp_ge_f32_e64 %10, %13, %16\n\tv_cmp_ge_f32_e64 %11, %13, %17\n\t"
+                 "s_or_b64 %4, %4, %8\n\ts_or_b64 %5, %5, %9\n\ts_or_b64 %6, %6, %10\n\ts_or_b64 %7, %7, %11\n\t"
+                 "v_cndmask_b32_e64 %0, %0, 0, %4\n\tv_cndmask_b32_e64 %1, %1, 0, %5\n\tv_cndmask_b32_e64 %2, %2, 0, %6\n\tv_cndmask_b32_e64 %3, %3, 0, %7"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&s"(n0), "=&s"(n1), "=&s"(n2), "=&s"(n3)
+                 : "v"(thr), "v"(fmin), "v"(x[R0]), "v"(x[R0 + 1]), "v"(x[R0 + 2]), "v"(x[R0 + 3]), "n"(C0), "n"(C1), "n"(C2), "n"(C3) : "scc");
+    v[R0] = a; v[R0 + 1] = b; v[R0 + 2] = c; v[R0 + 3] = d;
+}
+
 // Schedule.  Measured on this chip (profiles/r03_valu_issue_probe.txt, tools/attn_w32_timing.py): ONE wave issues at most one VALU
 // instruction per ~5 cycles while a SIMD retires one per ~2.35 when two or more of its waves are in vector code; packed fp32
 // (v_pk_*_f32) runs at 12.9 cycles per instruction beside a wave that issues MFMAs (scalar fp32 VALU is untouched by it); a
@@ -326,15 +396,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (HD == 64 ? 3 : 2) : NW / 4) voi
                     W32_FILL(0, 0); W32_FILL(0, 1); W32_FILL(0, 2); W32_FILL(0, 3); W32_FILL(1, 0); W32_FILL(1, 1); W32_FILL(1, 2); W32_FILL(1, 3);
 #undef W32_FILL
                 } else {                                                     // GPT-2's -1e4 replacement: padding keys keep finfo.min
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const f32x4 kb4 = *reinterpret_cast<const f32x4*>(kbS + kv0 + kk * 32 + 8 * j + 4 * hi);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                x[kk][4 * j + e] = (kk * 32 + 8 * j + e > thr) ? (kb4[e] > FINFO_MIN ? ffr : kb4[e]) : x[kk][4 * j + e];
-                        }
+#define W32_FILL(kk, j) fill4_future_keepmin<4 * j, kk * 32 + 8 * j>(x[kk], thr, ffr)
+                    W32_FILL(0, 0); W32_FILL(0, 1); W32_FILL(0, 2); W32_FILL(0, 3); W32_FILL(1, 0); W32_FILL(1, 1); W32_FILL(1, 2); W32_FILL(1, 3);
+#undef W32_FILL
                 }
             }
             float mx0 = max3(x[0][0], x[0][1], x[0][2]), mx1 = max3(x[0][8], x[0][9], x[0][10]);
@@ -465,14 +529,17 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 3 : NW / 4) void a
     issue(0);
     if (NST >= 3 && ntiles > 1) issue(1);
 
-    const float slope2 = p.slopes ? p.slopes[h] * LOG2E_F : 0.f;
+    // per-key bias in units of 1/scale ("raw", as in the forward): it enters as the C operand of the first score MFMA, a padding key's
+    // finfo.min absorbs the dot product exactly
+    const float slope_r = p.slopes ? p.slopes[h] / p.scale : 0.f;
     for (int key = tid; key < kv_end; key += NW * 64) {
         const int valid = p.kvalid != nullptr ? (int)p.kvalid[b * p.Sk + key] : 1;
         const float pos = p.kpos != nullptr ? p.kpos[b * p.Sk + key] : 0.f;
-        kbS[key] = valid != 0 ? slope2 * pos : FINFO_MIN;
+        kbS[key] = valid != 0 ? slope_r * pos : FINFO_MIN;
     }
+    const float c = p.scale * LOG2E_F;
     short8 qf[NDS], gf[NDS];
-    float m2 = 0.f, il = 0.f, dl = 0.f;
+    float dl = 0.f, nm2l = 0.f;
     const int64_t srow = (b * p.nh + h) * p.Sq + q0w + l32;
     if (active) {
         const int64_t ro = (int64_t)(q0w + l32) * p.o_rs;
@@ -484,9 +551,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 3 : NW / 4) void a
 #pragma unroll
             for (int j = 0; j < 8; ++j) dl += bf2f((bf16_t)gf[ds][j]) * bf2f((bf16_t)of[j]);
         }
-        const float mm = p.stat_m[srow];
-        m2 = mm <= FINFO_MIN ? FINFO_MIN : mm * LOG2E_F;
-        il = 1.0f / p.stat_l[srow];
+        // P = exp2(raw * c - m2 - log2 l): 1/l folded into the exponent.  (An all-masked row's finfo.min statistic overflows to +inf
+        // here; every dS of such a row is replaced by 0 in the loop.)
+        nm2l = -(p.stat_m[srow] * LOG2E_F + __builtin_amdgcn_logf(p.stat_l[srow]));
     } else {
 #pragma unroll
         for (int ds = 0; ds < NDS; ++ds) { qf[ds] = short8{0, 0, 0, 0, 0, 0, 0, 0}; gf[ds] = qf[ds]; }
@@ -496,7 +563,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 3 : NW / 4) void a
     __syncthreads();
 #pragma unroll
     for (int ds = 0; ds < NDS; ++ds) { pin(qf[ds]); pin(gf[ds]); }
-    pin(m2); pin(il); pin(dl);
+    pin(dl); pin(nm2l);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // the delta store as well: nothing of the prologue may be pending in the loop
 
     f32x16 dq[NDB];
@@ -504,7 +571,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 3 : NW / 4) void a
     for (int db = 0; db < NDB; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
-    const float c = p.scale * LOG2E_F;
     int st = 0;
     for (int t = 0; t < ntiles; ++t) {
         if (NST >= 3 && t + 1 < ntiles) wait_vm<2 * NPC>(); else wait_vm<0>();
@@ -518,7 +584,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 3 : NW / 4) void a
             const int kv0 = t * 64;
             f32x16 x[2], y[2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { x[0][r] = 0.f; x[1][r] = 0.f; y[0][r] = 0.f; y[1][r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { y[0][r] = 0.f; y[1][r] = 0.f; }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 kb4 = *reinterpret_cast<const f32x4*>(kbS + kv0 + kk * 32 + 8 * j + 4 * hi);
+                    x[kk][4 * j] = kb4[0]; x[kk][4 * j + 1] = kb4[1]; x[kk][4 * j + 2] = kb4[2]; x[kk][4 * j + 3] = kb4[3];
+                }
 #pragma unroll
             for (int ds = 0; ds < NDS; ++ds) {
                 x[0] = mfma32(W::fragA(ks, l32, ds * 2 + hi), qf[ds], x[0]);
@@ -526,23 +599,40 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 3 : NW / 4) void a
                 y[0] = mfma32(W::fragA(vs, l32, ds * 2 + hi), gf[ds], y[0]);
                 y[1] = mfma32(W::fragA(vs, 32 + l32, ds * 2 + hi), gf[ds], y[1]);
             }
-            const bool maskt = general || (kv0 + 63 > q0w);
             const int thr = q0w + l32 - kv0 - 4 * hi;                       // key offset cc usable iff cc <= thr (not in the causal future)
+            // Per score: one fma, one exp2, one sub, one mul.  P of a padding key is exp2(-huge) = 0 by itself, so dS = P (dP - delta) needs
+            // a select only for the causal future, on the diagonal tiles — and, in a batch row with LEFT padding (all-masked query rows:
+            // P uniform over masked keys, possibly inf here, dS must be 0), for padding keys as well, on every tile.  The select replaces
+            // the value (no arithmetic on it), so an inf / NaN of an all-masked row ends there.
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4 kb4 = *reinterpret_cast<const f32x4*>(kbS + kv0 + kk * 32 + 8 * j + 4 * hi);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int r = 4 * j + e;
-                        const float s2 = __builtin_fmaf(x[kk][r], c, kb4[e]);
-                        const float pr = __builtin_amdgcn_exp2f(s2 - m2) * il;
-                        float d = pr * (y[kk][r] - dl);
-                        if (maskt) d = ((kb4[e] > FINFO_MIN) & (kk * 32 + 8 * j + e <= thr)) ? d : 0.f;   // padding / future keys: dS = 0
-                        y[kk][r] = d;
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(x[kk][r], c, nm2l));
+                    y[kk][r] = pr * (y[kk][r] - dl);
                 }
+            if (general) {
+                // (the key-bias row is read a second time, behind an opaque index: kept from the first read it would stay live across the
+                // exponentials of every tile — registers the common path does not have)
+                int kvo = kv0;
+                asm volatile("" : "+v"(kvo));
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 kb4 = *reinterpret_cast<const f32x4*>(kbS + kvo + kk * 32 + 8 * j + 4 * hi);
+                        f32x16 kbx;
+                        kbx[4 * j] = kb4[0]; kbx[4 * j + 1] = kb4[1]; kbx[4 * j + 2] = kb4[2]; kbx[4 * j + 3] = kb4[3];
+                        if (j == 0) zero4_masked<0, 0>(y[kk], kbx, thr - kk * 32);
+                        else if (j == 1) zero4_masked<4, 8>(y[kk], kbx, thr - kk * 32);
+                        else if (j == 2) zero4_masked<8, 16>(y[kk], kbx, thr - kk * 32);
+                        else zero4_masked<12, 24>(y[kk], kbx, thr - kk * 32);
+                    }
+            } else if (kv0 + 63 > q0w) {
+#define W32_ZERO(kk, j) fill4_future<4 * j, kk * 32 + 8 * j>(y[kk], thr, 0.f)
+                W32_ZERO(0, 0); W32_ZERO(0, 1); W32_ZERO(0, 2); W32_ZERO(0, 3); W32_ZERO(1, 0); W32_ZERO(1, 1); W32_ZERO(1, 2); W32_ZERO(1, 3);
+#undef W32_ZERO
+            }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -617,11 +707,19 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 2 : NW / 4) void a
         const float* sm = p.stat_m + (b * p.nh + h) * p.Sq;
         const float* sl = p.stat_l + (b * p.nh + h) * p.Sq;
         const float* sd = p.delta + (b * p.nh + h) * p.Sq;
+        const float rc = 1.0f / (p.scale * LOG2E_F);
         for (int q = qt_begin * 64 + tid; q < (int)p.Sq; q += NW * 64) {
-            const float mm = sm[q];
-            m2S[q] = mm <= FINFO_MIN ? FINFO_MIN : mm * LOG2E_F;
-            ilS[q] = 1.0f / sl[q];
-            dlS[q] = sd[q];
+            const float mm = sm[q], ll = sl[q];
+            if (allq) {                                                      // exact path (all-masked query rows exist in this batch row)
+                m2S[q] = mm <= FINFO_MIN ? FINFO_MIN : mm * LOG2E_F;
+                ilS[q] = 1.0f / ll;
+                dlS[q] = sd[q];
+            } else {
+                // fast path: both per-query terms enter as the C operands of the tile's first MFMAs — the score accumulator starts at
+                // -(m2 + log2 l) / c (raw units), the dP accumulator at -delta — and the loop is P = exp2(fma(raw, c, bias)), dS = P * dPd
+                m2S[q] = -(mm * LOG2E_F + __builtin_amdgcn_logf(ll)) * rc;
+                dlS[q] = -sd[q];
+            }
         }
     }
 
@@ -669,8 +767,21 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 2 : NW / 4) void a
             const unsigned char* qs = smem + st * STAGE;
             const unsigned char* gs = qs + TILE;
             f32x16 x[2], y[2];
+            if (allq) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { x[0][r] = 0.f; x[1][r] = 0.f; y[0][r] = 0.f; y[1][r] = 0.f; }
+                for (int r = 0; r < 16; ++r) { x[0][r] = 0.f; x[1][r] = 0.f; y[0][r] = 0.f; y[1][r] = 0.f; }
+            } else {
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int qi = t * 64 + qq * 32 + 8 * j + 4 * hi;
+                        const f32x4 a4 = *reinterpret_cast<const f32x4*>(m2S + qi);
+                        const f32x4 d4 = *reinterpret_cast<const f32x4*>(dlS + qi);
+                        x[qq][4 * j] = a4[0]; x[qq][4 * j + 1] = a4[1]; x[qq][4 * j + 2] = a4[2]; x[qq][4 * j + 3] = a4[3];
+                        y[qq][4 * j] = d4[0]; y[qq][4 * j + 1] = d4[1]; y[qq][4 * j + 2] = d4[2]; y[qq][4 * j + 3] = d4[3];
+                    }
+            }
 #pragma unroll
             for (int ds = 0; ds < NDS; ++ds) {
                 x[0] = mfma32(W::fragA(qs, l32, ds * 2 + hi), kf[ds], x[0]);
@@ -678,9 +789,25 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 2 : NW / 4) void a
                 y[0] = mfma32(W::fragA(gs, l32, ds * 2 + hi), vf[ds], y[0]);
                 y[1] = mfma32(W::fragA(gs, 32 + l32, ds * 2 + hi), vf[ds], y[1]);
             }
-            const bool maskt = allq || (t * 64 < k0w + 31);                 // some (query, key) pair of the tile is in the causal future
             // masked(cc) for the query at offset cc = qq*32 + 8*j + e of this lane's group: padding key, or query index < key index
             const int thr = key_pad ? 0x7fffffff : (k0w + l32 - t * 64 - 4 * hi);
+            if (!allq) {
+                // every query row has an unmasked key, so a masked pair has P = 0 and dS = 0: a padding key gets there by itself (its
+                // bias is finfo.min), the causal future by a select on the diagonal tiles.  Per score: one fma, one exp2, one mul.
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(x[qq][r], c, kb_lane));
+                        x[qq][r] = pr;
+                        y[qq][r] = pr * y[qq][r];
+                    }
+                if (t * 64 < k0w + 31) {
+#define W32_ZERO(qq, j) zero4_pair<4 * j, qq * 32 + 8 * j, false>(x[qq], y[qq], thr)
+                    W32_ZERO(0, 0); W32_ZERO(0, 1); W32_ZERO(0, 2); W32_ZERO(0, 3); W32_ZERO(1, 0); W32_ZERO(1, 1); W32_ZERO(1, 2); W32_ZERO(1, 3);
+#undef W32_ZERO
+                }
+            } else {
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq)
 #pragma unroll
@@ -692,16 +819,15 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 2 : NW / 4) void a
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int r = 4 * j + e;
-                        float s2 = __builtin_fmaf(x[qq][r], c, kb_lane);
-                        bool msk = false;
-                        if (maskt) { msk = (qq * 32 + 8 * j + e) < thr; s2 = msk ? lane_fill : s2; }
+                        const bool msk = (qq * 32 + 8 * j + e) < thr;
+                        const float s2 = msk ? lane_fill : __builtin_fmaf(x[qq][r], c, kb_lane);
                         const float pr = __builtin_amdgcn_exp2f(s2 - mm[e]) * il4[e];
-                        float d = pr * (y[qq][r] - dl4[e]);
-                        if (maskt) d = msk ? 0.f : d;
+                        const float d = msk ? 0.f : pr * (y[qq][r] - dl4[e]);
                         x[qq][r] = pr;
                         y[qq][r] = d;
                     }
                 }
+            }
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq)
 #pragma unroll
