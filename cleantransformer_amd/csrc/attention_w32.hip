@@ -281,6 +281,17 @@ __device__ __forceinline__ void zero4_masked(f32x16& v, const f32x16& x, int thr
     v[R0] = a; v[R0 + 1] = b; v[R0 + 2] = c; v[R0 + 3] = d;
 }
 
+// The hazard recognizer of hipcc does not look into inline asm: an asm VALU instruction (max3, the fill helpers) that reads an MFMA
+// result gets none of the wait states a compiler-emitted reader would.  With the max tree directly behind the last score MFMA the
+// row maximum was taken over the partial sums of the earlier K-slices (caught by the statistics check of tools/attn_w32_check.py).
+// 19 wait states cover an MFMA of this shape; the fences keep the scheduler from moving asm readers above it.  Needed wherever
+// the FIRST reader of an accumulator is an asm statement.
+__device__ __forceinline__ void mfma_results_fence() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 2" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // Schedule.  Measured on this chip (profiles/r03_valu_issue_probe.txt, tools/attn_w32_timing.py): ONE wave issues at most one VALU
 // instruction per ~5 cycles while a SIMD retires one per ~2.35 when two or more of its waves are in vector code; packed fp32
 // (v_pk_*_f32) runs at 12.9 cycles per instruction beside a wave that issues MFMAs (scalar fp32 VALU is untouched by it); a
@@ -292,7 +303,7 @@ __device__ __forceinline__ void zero4_masked(f32x16& v, const f32x16& x, int thr
 //   * the per-key bias enters as the C operand of the first score MFMA (no bias add),
 //   * scores stay in units of 1/scale ("raw") and p = exp2(raw*c - max*c), c = scale*log2(e): ONE fma + ONE exp2 per score,
 //   * the future-key fill is four compares into SGPR pairs + four selects per four scores (no VCC round trips).
-template <int HD, int NW>
+template <int HD, int NW, bool REPLACE>       // REPLACE: future scores are REPLACED by a value other than finfo.min (GPT-2's -1e4)
 __global__ __launch_bounds__(NW * 64, NW == 4 ? (HD == 64 ? 3 : 2) : NW / 4) void attn32_fwd_kernel(AttnP p) {
     using W = WT<HD, NW>;
     constexpr int NDS = HD / 16, NDB = HD / 32, TILE = W::TILE, STAGE = 2 * TILE, NPC = W::NPC, RPB = 32 * NW, NST = CTMI_W32_FWD_NST;
@@ -376,30 +387,39 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (HD == 64 ? 3 : 2) : NW / 4) voi
             const unsigned char* vs = ks + TILE;
             const int kv0 = t * 64;
             f32x16 x[2];
+            const bool diag = kv0 + 63 > q0w;                              // the tile holds (query, key) pairs in the causal future
+            const int thr = q0w + l32 - kv0 - 4 * hi;                       // key offset cc = kk*32 + 8*(r>>2) + (r&3) is in the future iff cc > thr
+            // masked_fill(finfo.min) of the future keys rides in the C operand too: finfo.min + q.k = finfo.min.  (A select AFTER the
+            // MFMAs on the diagonal tiles only makes hipcc copy all 32 scores of EVERY tile out of the accumulator tuples where the two
+            // paths merge — one v_mov per score on a loop bound by vector issue.  Before the MFMAs both paths define the tuple afresh.)
+            if (!REPLACE && diag) {
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
+                for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4 kb4 = *reinterpret_cast<const f32x4*>(kbS + kv0 + kk * 32 + 8 * j + 4 * hi);
-                    x[kk][4 * j] = kb4[0]; x[kk][4 * j + 1] = kb4[1]; x[kk][4 * j + 2] = kb4[2]; x[kk][4 * j + 3] = kb4[3];
-                }
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 kb4 = *reinterpret_cast<const f32x4*>(kbS + kv0 + kk * 32 + 8 * j + 4 * hi);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) x[kk][4 * j + e] = (kk * 32 + 8 * j + e > thr) ? FINFO_MIN : kb4[e];
+                    }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 kb4 = *reinterpret_cast<const f32x4*>(kbS + kv0 + kk * 32 + 8 * j + 4 * hi);
+                        x[kk][4 * j] = kb4[0]; x[kk][4 * j + 1] = kb4[1]; x[kk][4 * j + 2] = kb4[2]; x[kk][4 * j + 3] = kb4[3];
+                    }
+            }
 #pragma unroll
             for (int ds = 0; ds < NDS; ++ds) {
                 x[0] = mfma32(W::fragA(ks, l32, ds * 2 + hi), qf[ds], x[0]);   // raw score = q.k + bias/scale (padding: finfo.min absorbs the dot)
                 x[1] = mfma32(W::fragA(ks, 32 + l32, ds * 2 + hi), qf[ds], x[1]);
             }
-            if (kv0 + 63 > q0w) {                                          // the tile holds (query, key) pairs in the causal future
-                const int thr = q0w + l32 - kv0 - 4 * hi;                   // key offset cc = kk*32 + 8*(r>>2) + (r&3) is in the future iff cc > thr
-                if (ffr <= FINFO_MIN) {
-                    // masked_fill(finfo.min): padding keys already hold finfo.min, so every future score is finfo.min whatever the key
-#define W32_FILL(kk, j) fill4_future<4 * j, kk * 32 + 8 * j>(x[kk], thr, FINFO_MIN)
-                    W32_FILL(0, 0); W32_FILL(0, 1); W32_FILL(0, 2); W32_FILL(0, 3); W32_FILL(1, 0); W32_FILL(1, 1); W32_FILL(1, 2); W32_FILL(1, 3);
-#undef W32_FILL
-                } else {                                                     // GPT-2's -1e4 replacement: padding keys keep finfo.min
+            mfma_results_fence();
+            if (REPLACE && diag) {                                           // GPT-2's -1e4 replacement: padding keys keep finfo.min
 #define W32_FILL(kk, j) fill4_future_keepmin<4 * j, kk * 32 + 8 * j>(x[kk], thr, ffr)
-                    W32_FILL(0, 0); W32_FILL(0, 1); W32_FILL(0, 2); W32_FILL(0, 3); W32_FILL(1, 0); W32_FILL(1, 1); W32_FILL(1, 2); W32_FILL(1, 3);
+                W32_FILL(0, 0); W32_FILL(0, 1); W32_FILL(0, 2); W32_FILL(0, 3); W32_FILL(1, 0); W32_FILL(1, 1); W32_FILL(1, 2); W32_FILL(1, 3);
 #undef W32_FILL
-                }
             }
             float mx0 = max3(x[0][0], x[0][1], x[0][2]), mx1 = max3(x[0][8], x[0][9], x[0][10]);
             float mx2 = max3(x[1][0], x[1][1], x[1][2]), mx3 = max3(x[1][8], x[1][9], x[1][10]);
@@ -505,8 +525,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 3 : NW / 4) void a
     const int kv_end = min((int)p.Sk, q0 + RPB);                             // masked entries have dS = 0: nothing beyond the diagonal
     const int ntiles = kv_end / 64;
     const int my_last = min(ntiles - 1, (q0w + 31) / 64);
-    // a batch row with LEFT padding has all-masked query rows (P uniform, dS must still be 0): every tile keeps the select
-    const bool general = p.kvalid != nullptr && p.first_valid[b] > 0;
     const bf16_t* qp = reinterpret_cast<const bf16_t*>(p.q) + b * p.q_bs + h * p.q_hs;
     const bf16_t* kp = reinterpret_cast<const bf16_t*>(p.k) + b * p.k_bs + h * p.k_hs;
     const bf16_t* vp = reinterpret_cast<const bf16_t*>(p.v) + b * p.v_bs + h * p.v_hs;
@@ -551,9 +569,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 3 : NW / 4) void a
 #pragma unroll
             for (int j = 0; j < 8; ++j) dl += bf2f((bf16_t)gf[ds][j]) * bf2f((bf16_t)of[j]);
         }
-        // P = exp2(raw * c - m2 - log2 l): 1/l folded into the exponent.  (An all-masked row's finfo.min statistic overflows to +inf
-        // here; every dS of such a row is replaced by 0 in the loop.)
-        nm2l = -(p.stat_m[srow] * LOG2E_F + __builtin_amdgcn_logf(p.stat_l[srow]));
+        // P = exp2(raw * c - m2 - log2 l): 1/l folded into the exponent.  An all-masked row (finfo.min statistic) has only finfo.min
+        // scores in this kernel, P = 0 whatever the finite offset.
+        const float mm = p.stat_m[srow];
+        nm2l = mm <= FINFO_MIN ? 0.f : -(mm * LOG2E_F + __builtin_amdgcn_logf(p.stat_l[srow]));
     } else {
 #pragma unroll
         for (int ds = 0; ds < NDS; ++ds) { qf[ds] = short8{0, 0, 0, 0, 0, 0, 0, 0}; gf[ds] = qf[ds]; }
@@ -585,13 +604,28 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 3 : NW / 4) void a
             f32x16 x[2], y[2];
 #pragma unroll
             for (int r = 0; r < 16; ++r) { y[0][r] = 0.f; y[1][r] = 0.f; }
+            const int thr = q0w + l32 - kv0 - 4 * hi;                       // key offset cc usable iff cc <= thr (not in the causal future)
+            // A masked pair must give dS = 0.  A padding key does by itself (bias finfo.min -> P = exp2(-huge) = 0); the causal future of
+            // the diagonal tile gets finfo.min through the same C operand (a select after the MFMAs costs a register copy per score on
+            // every tile, see the forward).  An all-masked query row (LEFT padding) then has P = 0 everywhere: its exponent offset is 0.
+            if (kv0 + 63 > q0w) {
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
+                for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4 kb4 = *reinterpret_cast<const f32x4*>(kbS + kv0 + kk * 32 + 8 * j + 4 * hi);
-                    x[kk][4 * j] = kb4[0]; x[kk][4 * j + 1] = kb4[1]; x[kk][4 * j + 2] = kb4[2]; x[kk][4 * j + 3] = kb4[3];
-                }
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 kb4 = *reinterpret_cast<const f32x4*>(kbS + kv0 + kk * 32 + 8 * j + 4 * hi);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) x[kk][4 * j + e] = (kk * 32 + 8 * j + e > thr) ? FINFO_MIN : kb4[e];
+                    }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 kb4 = *reinterpret_cast<const f32x4*>(kbS + kv0 + kk * 32 + 8 * j + 4 * hi);
+                        x[kk][4 * j] = kb4[0]; x[kk][4 * j + 1] = kb4[1]; x[kk][4 * j + 2] = kb4[2]; x[kk][4 * j + 3] = kb4[3];
+                    }
+            }
 #pragma unroll
             for (int ds = 0; ds < NDS; ++ds) {
                 x[0] = mfma32(W::fragA(ks, l32, ds * 2 + hi), qf[ds], x[0]);
@@ -599,11 +633,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 3 : NW / 4) void a
                 y[0] = mfma32(W::fragA(vs, l32, ds * 2 + hi), gf[ds], y[0]);
                 y[1] = mfma32(W::fragA(vs, 32 + l32, ds * 2 + hi), gf[ds], y[1]);
             }
-            const int thr = q0w + l32 - kv0 - 4 * hi;                       // key offset cc usable iff cc <= thr (not in the causal future)
-            // Per score: one fma, one exp2, one sub, one mul.  P of a padding key is exp2(-huge) = 0 by itself, so dS = P (dP - delta) needs
-            // a select only for the causal future, on the diagonal tiles — and, in a batch row with LEFT padding (all-masked query rows:
-            // P uniform over masked keys, possibly inf here, dS must be 0), for padding keys as well, on every tile.  The select replaces
-            // the value (no arithmetic on it), so an inf / NaN of an all-masked row ends there.
+            // per score: one fma, one exp2, one sub, one mul
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -611,28 +641,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 3 : NW / 4) void a
                     const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(x[kk][r], c, nm2l));
                     y[kk][r] = pr * (y[kk][r] - dl);
                 }
-            if (general) {
-                // (the key-bias row is read a second time, behind an opaque index: kept from the first read it would stay live across the
-                // exponentials of every tile — registers the common path does not have)
-                int kvo = kv0;
-                asm volatile("" : "+v"(kvo));
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const f32x4 kb4 = *reinterpret_cast<const f32x4*>(kbS + kvo + kk * 32 + 8 * j + 4 * hi);
-                        f32x16 kbx;
-                        kbx[4 * j] = kb4[0]; kbx[4 * j + 1] = kb4[1]; kbx[4 * j + 2] = kb4[2]; kbx[4 * j + 3] = kb4[3];
-                        if (j == 0) zero4_masked<0, 0>(y[kk], kbx, thr - kk * 32);
-                        else if (j == 1) zero4_masked<4, 8>(y[kk], kbx, thr - kk * 32);
-                        else if (j == 2) zero4_masked<8, 16>(y[kk], kbx, thr - kk * 32);
-                        else zero4_masked<12, 24>(y[kk], kbx, thr - kk * 32);
-                    }
-            } else if (kv0 + 63 > q0w) {
-#define W32_ZERO(kk, j) fill4_future<4 * j, kk * 32 + 8 * j>(y[kk], thr, 0.f)
-                W32_ZERO(0, 0); W32_ZERO(0, 1); W32_ZERO(0, 2); W32_ZERO(0, 3); W32_ZERO(1, 0); W32_ZERO(1, 1); W32_ZERO(1, 2); W32_ZERO(1, 3);
-#undef W32_ZERO
-            }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -767,6 +775,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 2 : NW / 4) void a
             const unsigned char* qs = smem + st * STAGE;
             const unsigned char* gs = qs + TILE;
             f32x16 x[2], y[2];
+            // masked(cc) for the query at offset cc = qq*32 + 8*j + e of this lane's group: padding key, or query index < key index
+            const int thr = key_pad ? 0x7fffffff : (k0w + l32 - t * 64 - 4 * hi);
+            const bool diag = t * 64 < k0w + 31;                            // some (query, key) pair of the tile is in the causal future
             if (allq) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { x[0][r] = 0.f; x[1][r] = 0.f; y[0][r] = 0.f; y[1][r] = 0.f; }
@@ -778,7 +789,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 2 : NW / 4) void a
                         const int qi = t * 64 + qq * 32 + 8 * j + 4 * hi;
                         const f32x4 a4 = *reinterpret_cast<const f32x4*>(m2S + qi);
                         const f32x4 d4 = *reinterpret_cast<const f32x4*>(dlS + qi);
-                        x[qq][4 * j] = a4[0]; x[qq][4 * j + 1] = a4[1]; x[qq][4 * j + 2] = a4[2]; x[qq][4 * j + 3] = a4[3];
+                        if (diag) {                                            // masked pair: score finfo.min -> P = 0, dS = 0
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) x[qq][4 * j + e] = (qq * 32 + 8 * j + e < thr) ? FINFO_MIN : a4[e];
+                        } else {
+                            x[qq][4 * j] = a4[0]; x[qq][4 * j + 1] = a4[1]; x[qq][4 * j + 2] = a4[2]; x[qq][4 * j + 3] = a4[3];
+                        }
                         y[qq][4 * j] = d4[0]; y[qq][4 * j + 1] = d4[1]; y[qq][4 * j + 2] = d4[2]; y[qq][4 * j + 3] = d4[3];
                     }
             }
@@ -789,11 +805,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 2 : NW / 4) void a
                 y[0] = mfma32(W::fragA(gs, l32, ds * 2 + hi), vf[ds], y[0]);
                 y[1] = mfma32(W::fragA(gs, 32 + l32, ds * 2 + hi), vf[ds], y[1]);
             }
-            // masked(cc) for the query at offset cc = qq*32 + 8*j + e of this lane's group: padding key, or query index < key index
-            const int thr = key_pad ? 0x7fffffff : (k0w + l32 - t * 64 - 4 * hi);
             if (!allq) {
                 // every query row has an unmasked key, so a masked pair has P = 0 and dS = 0: a padding key gets there by itself (its
-                // bias is finfo.min), the causal future by a select on the diagonal tiles.  Per score: one fma, one exp2, one mul.
+                // bias is finfo.min), the causal future through the C operand above.  Per score: one fma, one exp2, one mul.
 #pragma unroll
                 for (int qq = 0; qq < 2; ++qq)
 #pragma unroll
@@ -802,11 +816,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 2 : NW / 4) void a
                         x[qq][r] = pr;
                         y[qq][r] = pr * y[qq][r];
                     }
-                if (t * 64 < k0w + 31) {
-#define W32_ZERO(qq, j) zero4_pair<4 * j, qq * 32 + 8 * j, false>(x[qq], y[qq], thr)
-                    W32_ZERO(0, 0); W32_ZERO(0, 1); W32_ZERO(0, 2); W32_ZERO(0, 3); W32_ZERO(1, 0); W32_ZERO(1, 1); W32_ZERO(1, 2); W32_ZERO(1, 3);
-#undef W32_ZERO
-                }
             } else {
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq)
@@ -893,8 +902,15 @@ int ctmi_attn32_fwd(const AttnP& p, hipStream_t st) {
     if (!w32_ok(p) || !(w32_mask() & 1)) return 0;
     const int64_t BH = p.B * p.nh;
     constexpr int NW = CTMI_W32_FWD_NW, RPB = 32 * NW;
-    if (p.hd == 64) launch32(&attn32_fwd_kernel<64, NW>, ((p.Sq + RPB - 1) / RPB) * BH, 64 * NW, lds_kv<64, NW>(p, CTMI_W32_FWD_NST), st, p);
-    else launch32(&attn32_fwd_kernel<128, NW>, ((p.Sq + RPB - 1) / RPB) * BH, 64 * NW, lds_kv<128, NW>(p, CTMI_W32_FWD_NST), st, p);
+    const bool replace = p.future_fill > FINFO_MIN;
+    const int64_t grid = ((p.Sq + RPB - 1) / RPB) * BH;
+    if (p.hd == 64) {
+        if (replace) launch32(&attn32_fwd_kernel<64, NW, true>, grid, 64 * NW, lds_kv<64, NW>(p, CTMI_W32_FWD_NST), st, p);
+        else launch32(&attn32_fwd_kernel<64, NW, false>, grid, 64 * NW, lds_kv<64, NW>(p, CTMI_W32_FWD_NST), st, p);
+    } else {
+        if (replace) launch32(&attn32_fwd_kernel<128, NW, true>, grid, 64 * NW, lds_kv<128, NW>(p, CTMI_W32_FWD_NST), st, p);
+        else launch32(&attn32_fwd_kernel<128, NW, false>, grid, 64 * NW, lds_kv<128, NW>(p, CTMI_W32_FWD_NST), st, p);
+    }
     return 1;
 }
 
