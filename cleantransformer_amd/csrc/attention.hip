@@ -516,7 +516,7 @@ __global__ __launch_bounds__(256, CTMI_ATTN_MINW) void attn_fwd_kernel(AttnP p) 
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    x[nt][r] = ctmi_hash32((c0 + (uint32_t)(nt * 16 + r)) ^ p.drop_seed) >= p.drop_thr ? x[nt][r] * p.drop_scale : 0.f;
+                    x[nt][r] = ctmi_keep_hash(c0 + (uint32_t)(nt * 16 + r), p.drop_seed) >= p.drop_thr ? x[nt][r] * p.drop_scale : 0.f;
         }
         if (__any(m_new > m)) {                                              // wave-uniform: rescale only when some row max moved
 #pragma unroll
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(256, CTMI_ATTN_MINW) void attn_bwd_dkdv_kernel(Attn
             if constexpr (DROP) {                                                 // O = dropout(P) V:  dV uses dropout(P), dP = mask/(1-p) * (dO V^T)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const bool keep = ctmi_hash32((drop_c0 + (uint32_t)(qbase + nt * 16 + r) * (uint32_t)p.Sk) ^ p.drop_seed) >= p.drop_thr;
+                    const bool keep = ctmi_keep_hash(drop_c0 + (uint32_t)(qbase + nt * 16 + r) * (uint32_t)p.Sk, p.drop_seed) >= p.drop_thr;
                     pv4[r] = keep ? p4[r] * p.drop_scale : 0.f;
                     dp4[r] = keep ? dp4[r] * p.drop_scale : 0.f;
                 }
@@ -868,7 +868,7 @@ __global__ __launch_bounds__(256, CTMI_ATTN_MINW) void attn_bwd_dq_kernel(AttnP 
                 const uint32_t c0 = (uint32_t)(((b * p.nh + h) * p.Sq + q_eff) * p.Sk + k0t);
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    dp4[r] = ctmi_hash32((c0 + (uint32_t)r) ^ p.drop_seed) >= p.drop_thr ? dp4[r] * p.drop_scale : 0.f;
+                    dp4[r] = ctmi_keep_hash(c0 + (uint32_t)r, p.drop_seed) >= p.drop_thr ? dp4[r] * p.drop_scale : 0.f;
             }
             f32x4 d4 = (p4 * il) * (dp4 - dl);
             if constexpr (MASKED) {

@@ -93,12 +93,19 @@ __device__ __forceinline__ float gelu_tanh_f(float x) { return gelu_tanh_pk(f32x
 __device__ __forceinline__ float gelu_tanh_grad_f(float x) { return gelu_tanh_grad_pk(f32x2{x, x})[0]; }
 
 // ---------------------------------------------------------------- dropout: counter-based keep mask
-// keep(i) = hash32(i ^ seed) >= thr with thr = p * 2^32: a pure function of the element's 32-bit counter and a per-call seed,
+// keep(i) = keep_hash(i, seed) >= thr with thr = p * 2^32: a pure function of the element's 32-bit counter and a per-call seed,
 // so the backward regenerates the mask instead of storing it (no [S,S] or [T,H] mask tensor ever exists).  hash32 = the "lowbias32"
 // integer finaliser (two multiplies, three xor-shifts); seeds come well mixed from the host (cleantransformer_amd/rng.py).
+// keep_hash is KEYED by the seed in two places: hash32(hash32(i ^ seed) + key(seed)).  With the xor alone every mask of a run would be
+// an xor-relabelled window of ONE 2^32-long bit sequence (two sites whose seeds differ only in high bits draw permutations of the same
+// mask); the additive key of the second round makes two seeds two different functions of the counter.
 __host__ __device__ __forceinline__ uint32_t ctmi_hash32(uint32_t x) {
     x ^= x >> 16; x *= 0x21f0aaadu; x ^= x >> 15; x *= 0x735a2d97u; x ^= x >> 15;
     return x;
+}
+__host__ __device__ __forceinline__ uint32_t ctmi_keep_key(uint32_t seed) { return seed * 0x9E3779B1u + 0x7F4A7C15u; }
+__host__ __device__ __forceinline__ uint32_t ctmi_keep_hash(uint32_t counter, uint32_t seed) {
+    return ctmi_hash32(ctmi_hash32(counter ^ seed) + ctmi_keep_key(seed));
 }
 static inline uint32_t ctmi_drop_threshold(float p) {                  // p in [0, 1): P(hash < thr) = p to 2^-32
     const double t = (double)p * 4294967296.0;

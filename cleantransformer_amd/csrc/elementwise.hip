@@ -634,20 +634,21 @@ __global__ __launch_bounds__(256) void dropout_k(const T* __restrict__ x, const 
         if (res != nullptr) unpack16<T>(*reinterpret_cast<const uint4*>(res + v * VEC), r);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            const bool keep = ctmi_hash32((uint32_t)(v * VEC + j) ^ seed) >= thr;
+            const bool keep = ctmi_keep_hash((uint32_t)(v * VEC + j), seed) >= thr;
             a[j] = keep ? a[j] * scale : 0.f;
             if (res != nullptr) a[j] += r[j];
         }
         *reinterpret_cast<uint4*>(y + v * VEC) = pack16<T>(a);
     }
     for (int64_t i = nv * VEC + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const bool keep = ctmi_hash32((uint32_t)i ^ seed) >= thr;
+        const bool keep = ctmi_keep_hash((uint32_t)i, seed) >= thr;
         float a = keep ? Cvt<T>::to_f(x[i]) * scale : 0.f;
         if (res != nullptr) a += Cvt<T>::to_f(res[i]);
         y[i] = Cvt<T>::from_f(a);
     }
 }
 extern "C" uint32_t ctmi_dropout_hash(uint32_t x) { return ctmi_hash32(x); }
+extern "C" uint32_t ctmi_dropout_keep_hash(uint32_t counter, uint32_t seed) { return ctmi_keep_hash(counter, seed); }
 extern "C" uint32_t ctmi_dropout_threshold(float p) { return ctmi_drop_threshold(p); }
 extern "C" int ctmi_dropout(const void* x, const void* residual, void* y, int64_t n, float p, uint32_t seed, int dtype, void* stream) {
     ProfScope prof__(CTMI_PROF_OTHER, as_stream(stream));

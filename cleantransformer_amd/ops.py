@@ -530,7 +530,7 @@ def bloom_block_bwd(acts: BlockActs, x2: Tensor, params, mask: Optional[MaskInfo
 
 
 def dropout(x: Tensor, p: float, seed: int, residual: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
-    """(keep ? x/(1-p) : 0) (+ residual), keep(i) = hash32(i ^ seed) >= p*2^32 over the flat element index — and, applied to a gradient
+    """(keep ? x/(1-p) : 0) (+ residual), keep(i) = keep_hash(i, seed) >= p*2^32 over the flat element index — and, applied to a gradient
     with the same seed, its own backward."""
     _need_cuda(x, residual)
     x = _c(x)

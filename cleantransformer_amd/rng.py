@@ -1,7 +1,8 @@
 """Seeds for the counter-based dropout masks of the ctmi355 kernels.
 
-The kernels keep element ``i`` of a dropout site iff ``hash32(i ^ seed) >= p * 2**32`` (csrc/common.h); the backward regenerates the
-mask from the same 32-bit seed.  A site draws its seed here once per forward call, from torch's default CPU generator — so
+The kernels keep element ``i`` of a dropout site iff ``keep_hash(i, seed) >= p * 2**32`` (csrc/common.h: the seed keys both rounds of
+the hash, so two seeds give two functions of the counter, not two windows of one sequence); the backward regenerates the mask from the
+same 32-bit seed.  A site draws its seed here once per forward call, from torch's default CPU generator — so
 ``torch.manual_seed(n)`` makes a run reproducible, exactly as it does for the reference's ``torch.nn.Dropout`` modules — and passes
 it through SplitMix64, so consecutive draws give unrelated masks."""
 from __future__ import annotations
@@ -34,6 +35,14 @@ def hash32(x: torch.Tensor) -> torch.Tensor:
     x = (x * 0x735a2d97) & m
     x = x ^ (x >> 15)
     return x
+
+
+def keep_hash(counter: torch.Tensor, seed: int) -> torch.Tensor:
+    """ctmi_dropout_keep_hash: hash32(hash32(counter ^ seed) + seed * 0x9E3779B1 + 0x7F4A7C15) on an int64 tensor of 32-bit counters."""
+    m = 0xFFFFFFFF
+    seed = int(seed) & m
+    key = (seed * 0x9E3779B1 + 0x7F4A7C15) & m
+    return hash32((hash32((counter & m) ^ seed) + key) & m)
 
 
 def drop_threshold(p: float) -> int:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CTMI_ABI_VERSION 8
+#define CTMI_ABI_VERSION 9
 
 enum ctmi_dtype { CTMI_F32 = 0, CTMI_BF16 = 1 };
 enum ctmi_status { CTMI_OK = 0, CTMI_ERR_ARG = -1, CTMI_ERR_LAUNCH = -2, CTMI_ERR_UNSUPPORTED = -3 };
@@ -130,8 +130,8 @@ typedef struct ctmi_attn_desc {
                             the -1e4 of the future keys is ABOVE the finfo.min of the padded visible ones and the reference attends to
                             the future; pass -1e4 to reproduce that. */
     uint32_t dropout_seed;   /* attention-probability dropout (torch.nn.Dropout on the softmax output: modeling_bloom.py:111,               */
-    float dropout_p;         /* modeling_gpt.py:96, transformer.py:46-47): element (b,h,q,k) is kept iff hash32(counter ^ seed) >= p*2^32     */
-    int32_t reserved_;       /* with counter = ((b*nh+h)*Sq+q)*Sk+k mod 2^32 (common.h ctmi_hash32) and scaled by 1/(1-p); the backward       */
+    float dropout_p;         /* modeling_gpt.py:96, transformer.py:46-47): element (b,h,q,k) is kept iff keep_hash(counter, seed) >= p*2^32   */
+    int32_t reserved_;       /* with counter = ((b*nh+h)*Sq+q)*Sk+k mod 2^32 (ctmi_dropout_keep_hash) and scaled by 1/(1-p); the backward       */
                              /* regenerates the mask from the same seed.  p = 0: off.                                                        */
 } ctmi_attn_desc;
 int ctmi_attn_fwd(const void* q, const void* k, const void* v, void* o, float* stat_m, float* stat_l,
@@ -197,12 +197,15 @@ int ctmi_ce_soft_bwd(const void* logits, int64_t ld, const float* target, int64_
 
 /* ---- dropout on activations  (torch.nn.functional.dropout / torch.nn.Dropout at modeling_bloom.py:122,270, modeling_gpt.py:74,100,
  *      136,190, transformer.py:111-119)
- * y[i] = (keep(i) ? x[i] / (1-p) : 0) (+ residual[i]),  keep(i) = hash32(i ^ seed) >= p * 2^32 (i = flat element index mod 2^32).
+ * y[i] = (keep(i) ? x[i] / (1-p) : 0) (+ residual[i]),  keep(i) = keep_hash(i, seed) >= p * 2^32 (i = flat element index mod 2^32).
  * The same call on a gradient (residual = NULL, same seed) is the backward: no mask tensor is stored.  y may alias x. */
 int ctmi_dropout(const void* x, const void* residual, void* y, int64_t n, float p, uint32_t seed, int dtype, void* stream);
-/* the mask function itself, on the host: keep(counter) = ctmi_dropout_hash(counter ^ seed) >= ctmi_dropout_threshold(p)
- * (what the kernels evaluate per element; exported so that callers / tests can restate a mask without a device) */
+/* the mask function itself, on the host: keep(counter) = ctmi_dropout_keep_hash(counter, seed) >= ctmi_dropout_threshold(p)
+ * (what the kernels evaluate per element; exported so that callers / tests can restate a mask without a device).
+ * keep_hash(counter, seed) = hash(hash(counter ^ seed) + seed * 0x9E3779B1 + 0x7F4A7C15) with hash = ctmi_dropout_hash, the
+ * "lowbias32" finaliser (ABI v9: the seed keys BOTH rounds, so two seeds give two functions, not two windows of one sequence). */
 uint32_t ctmi_dropout_hash(uint32_t x);
+uint32_t ctmi_dropout_keep_hash(uint32_t counter, uint32_t seed);
 uint32_t ctmi_dropout_threshold(float p);
 
 /* ---- optimizers  (optimizer.py:53-97 AdamW [L2 form]; torch.optim.AdamW as called at ft_bloom.py:70 [decoupled];

@@ -133,13 +133,13 @@ def _attn_keep(desc):
         return None, 1.0
     B, nh, Sq, Sk = desc.B, desc.nh, desc.Sq, desc.Sk
     c = torch.arange(B * nh * Sq * Sk, dtype=torch.int64).view(B, nh, Sq, Sk)
-    keep = rng.hash32(c ^ int(desc.dropout_seed)) >= rng.drop_threshold(p)
+    keep = rng.keep_hash(c, int(desc.dropout_seed)) >= rng.drop_threshold(p)
     return keep, 1.0 / (1.0 - p)
 
 
 def dropout(x, p, seed, residual=None, out=None):
     from cleantransformer_amd import rng
-    keep = rng.hash32(torch.arange(x.numel(), dtype=torch.int64) ^ (int(seed) & 0xFFFFFFFF)) >= rng.drop_threshold(p)
+    keep = rng.keep_hash(torch.arange(x.numel(), dtype=torch.int64), int(seed)) >= rng.drop_threshold(p)
     y = torch.where(keep.view(x.shape), x.float() * torch.tensor(1.0 / (1.0 - p), dtype=torch.float32), torch.zeros(()))
     if residual is not None:
         y = y + residual.float()

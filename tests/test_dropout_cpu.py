@@ -27,6 +27,16 @@ def test_python_hash_equals_library_host_export():
     got = rng.hash32(torch.tensor(xs, dtype=torch.int64))
     for x, g in zip(xs, got.tolist()):
         assert lib.ctmi_dropout_hash(x) == g, x
+    for seed in (0, 1, 0x80000000, 0xFFFFFFFF, 0x12345678):
+        got2 = rng.keep_hash(torch.tensor(xs[:200], dtype=torch.int64), seed)
+        for x, g in zip(xs[:200], got2.tolist()):
+            assert lib.ctmi_dropout_keep_hash(x, seed) == g, (x, seed)
+    # two seeds are two functions, not two windows of one sequence: relabelling the counters by the xor of the seeds does NOT map one
+    # mask onto the other (it would with keep(i) = hash32(i ^ seed))
+    c = torch.arange(1 << 14, dtype=torch.int64)
+    s1, s2 = 0x0001ABCD, 0x7001ABCD
+    same = (rng.keep_hash(c ^ (s1 ^ s2), s1) >= 2 ** 31) == (rng.keep_hash(c, s2) >= 2 ** 31)
+    assert 0.45 < float(same.float().mean()) < 0.55
     for p in (0.0, 0.1, 0.25, 0.5, 0.999, 1e-9):
         assert lib.ctmi_dropout_threshold(p) == rng.drop_threshold(p), p
     # avalanche sanity: one flipped input bit flips ~half of the output bits
@@ -45,7 +55,7 @@ def test_seeds_follow_torch_manual_seed():
 
 def _keep(n_or_shape, seed, p):
     n = int(np.prod(n_or_shape))
-    return (rng.hash32(torch.arange(n, dtype=torch.int64) ^ seed) >= rng.drop_threshold(p)).view(n_or_shape)
+    return (rng.keep_hash(torch.arange(n, dtype=torch.int64), seed) >= rng.drop_threshold(p)).view(n_or_shape)
 
 
 def _drop(x, seed, p):

@@ -1,5 +1,5 @@
 """GPU (-m gpu): dropout (round 2) — the counter-based keep mask of the kernels (include/ctmi355.h ctmi_dropout, ctmi_attn_desc.dropout_*)
-against its host-side restatement (cleantransformer_amd/rng.py hash32; tests/cpu_kernel_emulation.py applies it with plain torch ops):
+against its host-side restatement (cleantransformer_amd/rng.py keep_hash; tests/cpu_kernel_emulation.py applies it with plain torch ops):
 because the mask is a pure function of (element counter, seed), dropout is checked for PARITY — the kernel output must equal the
 explicit-mask computation to rounding — not only through statistical properties.  The reference draws its masks from torch's RNG
 stream (torch.nn.Dropout), which no other implementation can reproduce; what is pinned to the reference is the semantics: Bernoulli(1-p)
