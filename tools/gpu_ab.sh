@@ -8,6 +8,6 @@ for i in 1 2; do
   for v in cleantransformer_amd/lib/variants/*/; do n=$(basename $v); echo "== $n"; CTMI_LIB_PATH=$PWD/$v/libctmi355.so timeout 300 python tools/microbench.py $2 2>&1 | grep -E "$3"; done
 done
 for i in $(seq 1 ${4:-3}); do
-  echo "== bench default"; python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | grep -o '"ms_per_step": [0-9.]*'
-  for v in cleantransformer_amd/lib/variants/*/; do n=$(basename $v); echo "== bench $n"; CTMI_LIB_PATH=$PWD/$v/libctmi355.so python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | grep -o '"ms_per_step": [0-9.]*'; done
+  echo "== bench default"; python bench.py --no-cpu-baseline --no-breakdown --no-padded-sample 2>/dev/null | tail -1 | grep -o '"ms_per_step": [0-9.]*'
+  for v in cleantransformer_amd/lib/variants/*/; do n=$(basename $v); echo "== bench $n"; CTMI_LIB_PATH=$PWD/$v/libctmi355.so python bench.py --no-cpu-baseline --no-breakdown --no-padded-sample 2>/dev/null | tail -1 | grep -o '"ms_per_step": [0-9.]*'; done
 done
