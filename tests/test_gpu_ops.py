@@ -284,6 +284,71 @@ def test_bloom_attention_fwd_bwd(dtype, rtol, atol, B, S, nh, hd, kind):
     check("attn.dqkv", dq.float().view(B, S, 3 * H), qr.grad, rtol * 5, atol * 5)
 
 
+W32_CASES = [  # B, S, nh, hd, mask kind, future fill (0 = finfo.min: Bloom; -1e4: GPT-2)
+    (2, 64, 2, 64, "ones", 0.0), (2, 128, 2, 64, "right", 0.0), (1, 192, 2, 64, "left", 0.0), (2, 256, 3, 64, "mixed", 0.0),
+    (2, 320, 2, 64, "mixed", 0.0), (1, 512, 2, 64, "holes", 0.0), (2, 1024, 2, 64, "mixed", 0.0), (1, 576, 2, 64, "left", -1e4),
+    (2, 256, 2, 128, "mixed", 0.0), (1, 448, 2, 128, "left", 0.0), (1, 384, 2, 128, "holes", -1e4), (1, 4096, 1, 64, "right", 0.0)]
+
+
+def _w32_mask(kind, B, S):
+    am = _mask(kind, B, S) if kind != "holes" else torch.ones(B, S, dtype=torch.long)
+    if kind == "holes":
+        am[:, 5::7] = 0
+        am[0, :3] = 0
+    return am
+
+
+@pytest.mark.parametrize("B,S,nh,hd,kind,fill", W32_CASES)
+def test_attention_128row_kernels_vs_oracle_and_general_kernels(B, S, nh, hd, kind, fill):
+    """csrc/attention_w32.hip (the bf16 training path: 32x32x16 MFMA, masks and row terms as MFMA C operands) on shapes with left /
+    right / scattered padding, both fill kinds and both head sizes: against the CPU oracle (finfo.min fill; modeling_bloom.py:84-116),
+    against the general kernels of csrc/attention.hip in the same process (GPT-2's -1e4 replacement, whose left-padding quirk rows the
+    general kernels reproduce from the reference's golden: tests/test_gpu_gpt.py), on the PUBLISHED statistics (row maximum in the
+    natural domain and row sum: the two families must be interchangeable — the first build of the C-operand form read the maximum before
+    the last MFMA had landed and only this comparison saw it), and crosswise: the new forward feeding the general backward."""
+    o = ops()
+    from cleantransformer_amd.models.modeling_bloom import alibi_slopes
+    FMIN = torch.finfo(torch.float32).min
+    H = nh * hd
+    qkv, go = bf(rnd(B, S, 3 * H, seed=S + hd, scale=0.7)), bf(rnd(B, S, H, seed=S + hd + 1, scale=0.5))
+    am = _w32_mask(kind, B, S)
+    mask = o.MaskInfo(am.to(DEV))
+    slopes = alibi_slopes(nh).to(DEV)
+    qd, god = qkv.reshape(B * S, 3 * H).to(DEV).to(torch.bfloat16), go.reshape(B * S, H).to(DEV).to(torch.bfloat16)
+
+    def run(path_fwd, path_bwd):
+        desc = o.fused_qkv_desc(B, S, nh, hd, causal=True)
+        desc.future_fill = fill
+        out = torch.empty((B * S, H), dtype=torch.bfloat16, device=DEV)
+        o.set_attn_path(path_fwd)
+        sm, sl = o.attn_fwd(qd, qd[:, hd:], qd[:, 2 * hd:], out, desc, slopes, mask)
+        dq = torch.zeros_like(qd)
+        o.set_attn_path(path_bwd)
+        o.attn_bwd(qd, qd[:, hd:], qd[:, 2 * hd:], out, god, sm, sl, dq, dq[:, hd:], dq[:, 2 * hd:], desc, slopes, mask)
+        torch.cuda.synchronize()
+        return out.float().cpu(), sm.cpu(), sl.cpu(), dq.float().cpu()
+
+    try:
+        o_old, m_old, l_old, g_old = run(0, 0)
+        o_new, m_new, l_new, g_new = run(3, 3)
+        o_x, _, _, g_x = run(1, 0)                                            # new forward (and its statistics) into the general backward
+    finally:
+        o.set_attn_path(3)
+    fin = m_old > FMIN / 2
+    assert torch.equal(m_new <= FMIN, m_old <= FMIN)                         # all-masked rows carry the same sentinel
+    assert float((m_new - m_old)[fin].abs().max()) < 1e-3 and float(((l_new - l_old).abs() / l_old).max()) < 1e-3
+    if fill == 0.0:
+        qr = qkv.clone().requires_grad_(True)
+        ref = _attn_oracle(qr, am, nh)
+        ref.backward(go)
+        check("w32 out vs oracle", o_new.view(B, S, H), ref, 2e-2, 1e-2)
+        check("w32 dqkv vs oracle", g_new.view(B, S, 3 * H), qr.grad, 1e-1, 5e-2)
+    check("w32 out vs general", o_new, o_old, 2e-2, 1e-2)
+    check("w32 dqkv vs general", g_new, g_old, 1e-1, 5e-2)
+    check("w32 fwd -> general bwd", g_x, g_old, 1e-1, 5e-2)
+    assert torch.equal(o_x, o_new)
+
+
 def test_attention_layer_golden_block():
     """One reference BloomAttentionLayer forward/backward incl. left padding (golden from the reference itself)."""
     o = ops()
