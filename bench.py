@@ -139,6 +139,8 @@ def main(argv=None):
     ap.add_argument("--cpu-baseline", default="full", choices=["full", "short"], help="short: skip the 24-layer S=1024 CPU sample")
     ap.add_argument("--comm-dtype", default="fp32", choices=["fp32", "bf16"],
                     help="N > 1: wire dtype of the gradient buckets (bf16 halves the xGMI bytes; gradients then carry bf16 rounding)")
+    ap.add_argument("--ddp-backend", default=os.environ.get("CTMI_DDP_BACKEND", "torch"), choices=["torch", "rccl"],
+                    help="N > 1: gradient collectives through torch.distributed (default) or the library's own RCCL communicator (ctmi_ddp_*)")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the per-class HIP-event pass after the timed region")
     ap.add_argument("--no-padded-sample", action="store_true", help="skip the secondary sample with 25 %% of every row right-padded")
     args = ap.parse_args(argv)
@@ -167,6 +169,7 @@ def main(argv=None):
     B, S = args.batch, args.seq
     model = build_model(device, args.dtype)
     comm_dtype = torch.bfloat16 if args.comm_dtype == "bf16" else None
+    os.environ["CTMI_DDP_BACKEND"] = args.ddp_backend
     net = DDP(model, device_ids=[local_rank], comm_dtype=comm_dtype) if world > 1 else model
     opt = AdamW(net.parameters(), lr=1e-5, weight_decay=0.01, decoupled=True)      # == torch.optim.AdamW(lr=1e-5), ft_bloom.py:70
     g = torch.Generator(device=device).manual_seed(999 + rank)                       # per-rank data seed
@@ -280,6 +283,7 @@ def main(argv=None):
                        "comm_dtype": args.comm_dtype if world > 1 else None,
                        "comm": None if world == 1 else {"nccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS"),
                                                         "launch_policy": os.environ.get("CTMI_DDP_LAUNCH_POLICY", "shared"),
+                                                        "ddp_backend": args.ddp_backend,
                                                         "tied_chunk_mb": os.environ.get("CTMI_DDP_TIED_CHUNK_MB", "64")},
                        "padded_sample": padded},
             "timing": {"value_from": "median of the per-step HIP-event times of the timed steps (max over ranks)",

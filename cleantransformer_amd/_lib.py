@@ -19,7 +19,7 @@ F32, BF16 = 0, 1
 EPI_NONE, EPI_GELU, EPI_DGELU, EPI_RELU, EPI_DRELU, EPI_GELUG, EPI_MUL = 0, 1, 2, 3, 4, 5, 6
 MT_MAX = 24
 PROF_CLASSES = ("gemm_fwd", "gemm_dgrad", "gemm_wgrad", "lm_head", "attn_fwd", "attn_bwd", "layernorm", "loss", "optimizer", "reduce", "other")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 
@@ -87,6 +87,13 @@ PROTOTYPES = {
     "ctmi_bloom_block_bwd": (i32, [C.POINTER(BloomBlock), C.POINTER(BloomBlockGrads), vp]),
     "ctmi_ce_soft_fwd": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, i64, i32, i64, i32, vp]),
     "ctmi_ce_soft_bwd": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, vp, i64, i64, i64, i32, vp]),
+    "ctmi_ddp_unique_id": (C.c_int, [C.c_void_p]),
+    "ctmi_ddp_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "ctmi_ddp_destroy": (C.c_int, [C.c_void_p]),
+    "ctmi_ddp_all_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "ctmi_ddp_all_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "ctmi_ddp_broadcast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "ctmi_ddp_wait": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ctmi_dropout_hash": (C.c_uint32, [C.c_uint32]),
     "ctmi_dropout_keep_hash": (C.c_uint32, [C.c_uint32, C.c_uint32]),
     "ctmi_dropout_threshold": (C.c_uint32, [f32]),

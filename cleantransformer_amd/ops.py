@@ -638,6 +638,60 @@ def set_attn_path(mask: int) -> int:
     return int(_lib.load().ctmi_attn_set_path(int(mask)))
 
 
+class DirectComm:
+    """An RCCL communicator owned by the library (include/ctmi355.h ctmi_ddp_*): the data-parallel collectives without the
+    torch.distributed layers, with a per-communicator channel cap (= the CUs the collectives may hold).  Every call orders the
+    collective behind the CURRENT torch stream and returns at once; ``wait()`` makes the current stream wait for everything issued so
+    far.  Buffers handed to a collective must stay referenced until a ``wait()`` that follows it."""
+
+    def __init__(self, unique_id: bytes, rank: int, world: int, max_channels: int = 0):
+        if len(unique_id) != 128:
+            raise ValueError("DirectComm: the unique id is 128 bytes (DirectComm.unique_id() on rank 0)")
+        h = C.c_void_p()
+        idb = C.create_string_buffer(bytes(unique_id), 128)
+        check(_lib.load().ctmi_ddp_create(idb, int(rank), int(world), int(max_channels), C.byref(h)), "ddp_create")
+        self._h, self.rank, self.world, self.max_channels = h, int(rank), int(world), int(max_channels)
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        check(_lib.load().ctmi_ddp_unique_id(buf), "ddp_unique_id")
+        return buf.raw
+
+    def all_reduce(self, t: torch.Tensor) -> None:
+        _need_cuda(t)
+        if not t.is_contiguous() or t.dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("DirectComm.all_reduce: contiguous fp32 / bf16 tensors only")
+        check(_lib.load().ctmi_ddp_all_reduce(self._h, _p(t), t.numel(), dt_code(t.dtype), _stream()), "ddp_all_reduce")
+
+    def all_gather(self, out: torch.Tensor, inp: torch.Tensor) -> None:
+        _need_cuda(out, inp)
+        nb = inp.numel() * inp.element_size()
+        if not (out.is_contiguous() and inp.is_contiguous()) or out.numel() * out.element_size() != nb * self.world:
+            raise ValueError("DirectComm.all_gather: contiguous tensors, out = world x inp")
+        check(_lib.load().ctmi_ddp_all_gather(self._h, _p(inp), _p(out), nb, _stream()), "ddp_all_gather")
+
+    def broadcast(self, t: torch.Tensor, root: int = 0) -> None:
+        _need_cuda(t)
+        if not t.is_contiguous():
+            raise ValueError("DirectComm.broadcast: contiguous tensors only")
+        check(_lib.load().ctmi_ddp_broadcast(self._h, _p(t), t.numel() * t.element_size(), int(root), _stream()), "ddp_broadcast")
+
+    def wait(self) -> None:
+        check(_lib.load().ctmi_ddp_wait(self._h, _stream()), "ddp_wait")
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            _lib.load().ctmi_ddp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def get_launch_policy() -> Tuple[bool, int]:
     sh, r = C.c_int(0), C.c_int(0)
     _lib.load().ctmi_get_launch_policy(C.byref(sh), C.byref(r))

@@ -18,6 +18,11 @@ is built MI355X-first:
     the oversized tied embedding/LM-head gradient travels as one bucket.
 
 It is transport-agnostic (``gloo`` on CPU works and is how the semantics are tested: tests/test_ddp_gloo.py).
+
+``CTMI_DDP_BACKEND=rccl`` (round 3, opt-in): the gradient collectives of the step — bucket all-reduces, the pieces of the tied
+gradient, the row exchange — go straight to an RCCL communicator owned by libctmi355 (``ctmi_ddp_*``, ops.DirectComm) whose
+channel cap is the CU budget of the launch policy; torch.distributed keeps the control plane (the construction-time broadcast,
+the capacity agreement, handing the communicator's id around).
 """
 from __future__ import annotations
 
@@ -29,6 +34,16 @@ import torch
 import torch.distributed as dist
 
 _MiB = 1024 * 1024
+
+
+class _DirectWork:
+    """what `dist.all_reduce(async_op=True)` returns, for a collective issued on the library's communicator"""
+
+    def __init__(self, comm):
+        self.comm = comm
+
+    def wait(self):
+        self.comm.wait()                                            # current stream waits for everything issued on the communicator so far
 
 
 class _Bucket:
@@ -147,7 +162,11 @@ class _TiedGradSync:
         collective is enqueued as soon as its GEMM is — communication starts after 1/16 of the weight-gradient work instead
         of after all of it, and no single collective is larger than 64 MiB)."""
         o = self.owner
-        self.works.append(dist.all_reduce(dw, op=dist.ReduceOp.SUM, group=o.process_group, async_op=True))
+        if o._direct is not None and dw.is_cuda:
+            o._direct.all_reduce(dw)
+            self.works.append(_DirectWork(o._direct))
+        else:
+            self.works.append(dist.all_reduce(dw, op=dist.ReduceOp.SUM, group=o.process_group, async_op=True))
         if o._launch_events is not None and dw.is_cuda:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
@@ -181,6 +200,10 @@ class _TiedGradSync:
             dist.all_gather(lr, hr, group=o.process_group)
             all_ids.copy_(torch.stack(li))
             all_rows.copy_(torch.stack(lr))
+        elif ids.is_cuda and o._direct is not None:                  # the library's communicator
+            o._direct.all_gather(all_ids, ids)
+            o._direct.all_gather(all_rows, drows)
+            o._direct.wait()
         elif ids.is_cuda:                                            # RCCL: straight into the [world, ...] buffers
             dist.all_gather_into_tensor(all_ids, ids, group=o.process_group)
             dist.all_gather_into_tensor(all_rows, drows, group=o.process_group)
@@ -237,6 +260,7 @@ class DistributedDataParallel(torch.nn.Module):
         self.process_group = process_group if process_group is not None else dist.group.WORLD
         self.world_size = dist.get_world_size(self.process_group)
         self._arm_launch_policy()
+        self._direct = self._make_direct_comm()
         self.device_ids = device_ids
         self.broadcast_buffers = broadcast_buffers
         self.bucket_cap_mb = 25 if bucket_cap_mb is None else bucket_cap_mb
@@ -267,6 +291,24 @@ class DistributedDataParallel(torch.nn.Module):
         self._callback_queued = False
         self._launch_events = None                                    # record_launch_events(): [(kind, event)] of this step's collectives
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad_ready) for p in self._params]
+
+    def _make_direct_comm(self):
+        """CTMI_DDP_BACKEND=rccl: an RCCL communicator of libctmi355 for the step's gradient collectives (module docstring).  Its
+        channel cap: CTMI_DDP_MAX_CHANNELS, else the reserved-CU count under CTMI_DDP_LAUNCH_POLICY=reserve, else RCCL's default."""
+        if os.environ.get("CTMI_DDP_BACKEND", "torch").lower() not in ("rccl", "rccl_direct", "direct"):
+            return None
+        if dist.get_backend(self.process_group) != "nccl" or not any(p.is_cuda for p in self.module.parameters()):
+            raise RuntimeError("CTMI_DDP_BACKEND=rccl needs parameters on the GPU and a torch.distributed group on the nccl (RCCL) backend "
+                               "(it carries the communicator's id to the other ranks)")
+        from .. import ops
+        rank = dist.get_rank(self.process_group)
+        box = [ops.DirectComm.unique_id() if rank == 0 else None]
+        src = dist.get_global_rank(self.process_group, 0) if hasattr(dist, "get_global_rank") else 0
+        dist.broadcast_object_list(box, src=src, group=self.process_group)
+        cap = int(os.environ.get("CTMI_DDP_MAX_CHANNELS", "0"))
+        if cap <= 0 and os.environ.get("CTMI_DDP_LAUNCH_POLICY", "shared").lower() == "reserve":
+            cap = max(1, min(128, int(os.environ.get("CTMI_DDP_COMM_CUS", "16"))))
+        return ops.DirectComm(box[0], rank, self.world_size, cap)
 
     def _arm_launch_policy(self):
         """world > 1: the all-reduce kernels will hold CUs under backward — switch the GEMM launcher to a policy that tolerates it
@@ -358,7 +400,11 @@ class DistributedDataParallel(torch.nn.Module):
                 b.comm = torch.empty(b.numel, dtype=self.comm_dtype, device=b.flat.device)
             _cast(b.flat, b.comm)                                   # one pass per bucket; the collective is enqueued behind it
             wire = b.comm
-        b.work = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
+        if self._direct is not None and wire.is_cuda:
+            self._direct.all_reduce(wire)
+            b.work = _DirectWork(self._direct)
+        else:
+            b.work = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
         if self._launch_events is not None and wire.is_cuda:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CTMI_ABI_VERSION 9
+#define CTMI_ABI_VERSION 10
 
 enum ctmi_dtype { CTMI_F32 = 0, CTMI_BF16 = 1 };
 enum ctmi_status { CTMI_OK = 0, CTMI_ERR_ARG = -1, CTMI_ERR_LAUNCH = -2, CTMI_ERR_UNSUPPORTED = -3 };
@@ -100,6 +100,24 @@ enum ctmi_prof_class {
 };
 int ctmi_profile_begin(void);
 int ctmi_profile_end(float* ms /* host [CTMI_PROF_NCLASS] */, int* brackets /* host [CTMI_PROF_NCLASS] */);
+
+/* ---- data-parallel collectives straight on RCCL  (examples/ft_bloom_DDP.py:183 `init_process_group("nccl")`, :99
+ *      `DDP(model, device_ids=[local_rank])`: the gradient all-reduce torch's DDP issues through ProcessGroupNCCL; ABI v10)
+ * One process per GPU.  Rank 0 makes a 128-byte id (ctmi_ddp_unique_id) and hands it to the other ranks by any host channel (the
+ * Python wrapper uses the torch.distributed group the reference already initialises); every rank then creates its communicator with
+ * the SAME id.  max_channels > 0 caps the communicator's RCCL channels — one channel is one workgroup, i.e. one CU held for the length
+ * of a collective — and is meant to equal the reserve_cus of ctmi_set_launch_policy(0, R): the GEMMs then never wait for a CU a
+ * collective holds, and the collectives always find R free CUs.  A communicator owns one stream: every collective is ordered behind
+ * what compute_stream holds at the call and runs asynchronously; ctmi_ddp_wait makes compute_stream wait for everything issued on the
+ * communicator so far (the host never blocks).  Buffers must stay alive until a ctmi_ddp_wait that follows their collective has been
+ * enqueued on the stream that frees / reuses them.  librccl is loaded on first use (no link-time dependency). */
+int ctmi_ddp_unique_id(void* id128 /* host, 128 bytes out */);
+int ctmi_ddp_create(const void* id128 /* host */, int rank, int world, int max_channels, void** comm_out);
+int ctmi_ddp_destroy(void* comm);
+int ctmi_ddp_all_reduce(void* comm, void* buf /* device, in place, SUM */, int64_t count, int dtype /* CTMI_F32 | CTMI_BF16 */, void* compute_stream);
+int ctmi_ddp_all_gather(void* comm, const void* send /* device */, void* recv /* device, world * bytes_per_rank */, int64_t bytes_per_rank, void* compute_stream);
+int ctmi_ddp_broadcast(void* comm, void* buf /* device, in place */, int64_t bytes, int root, void* compute_stream);
+int ctmi_ddp_wait(void* comm, void* compute_stream);
 
 /* column sum: out[n] (+)= sum_m x[m,n]  — bias gradients (autograd of the Linear biases). */
 int ctmi_colsum(const void* x, int64_t ld, float* out, int accumulate, float* ws, int64_t M, int64_t N, int dtype, void* stream);

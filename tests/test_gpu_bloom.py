@@ -313,8 +313,12 @@ def test_full_size_properties_bf16():
     assert 12.0 < losses[0] < 20.0, losses                                                    # > ln V = 12.43
 
 
-def test_ddp_wrapper_on_rccl_single_rank():
-    """One-rank RCCL process group on the GPU: the data-parallel wrapper's collectives (bucket all-reduce from the autograd
+@pytest.mark.parametrize("backend", ["torch", "rccl"])
+def test_ddp_wrapper_on_rccl_single_rank(backend):
+    """(backend = "rccl": the same step with CTMI_DDP_BACKEND=rccl — the gradient collectives go to the library's own RCCL communicator,
+    ctmi_ddp_* / ops.DirectComm, created with a channel cap; plus the raw calls: in-place all-reduce ordered behind a kernel of the
+    compute stream, byte all_gather, broadcast, wait.)
+    One-rank RCCL process group on the GPU: the data-parallel wrapper's collectives (bucket all-reduce from the autograd
     hooks, the tied-gradient early all-reduce, the id / row all_gather_into_tensor) run on the real backend and leave the
     gradients of the plain model unchanged (world = 1: averaging is the identity).  Multi-rank semantics are covered on CPU
     over gloo (tests/test_ddp_gloo.py); this is the check that RCCL accepts the calls, dtypes and stream usage."""
@@ -324,7 +328,24 @@ def test_ddp_wrapper_on_rccl_single_rank():
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, os.getcwd())
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", CTMI_DDP_TIED_EARLY_AT_WORLD1="1", CTMI_DDP_TIED_CHUNK_ROWS="256")
+os.environ["CTMI_DDP_BACKEND"] = "@BACKEND@"
+os.environ["CTMI_DDP_MAX_CHANNELS"] = "8"
 dist.init_process_group("nccl", rank=0, world_size=1)
+if "@BACKEND@" == "rccl":
+    from cleantransformer_amd import ops
+    c = ops.DirectComm(ops.DirectComm.unique_id(), 0, 1, max_channels=4)
+    x = torch.zeros(1 << 20, device="cuda:0")
+    x.add_(3.0)                                      # a kernel on the compute stream the collective has to wait for
+    c.all_reduce(x)
+    y = torch.arange(1000, device="cuda:0", dtype=torch.int64); out = torch.empty(1000, device="cuda:0", dtype=torch.int64)
+    c.all_gather(out, y)
+    z = torch.full((4096,), 7.0, device="cuda:0", dtype=torch.bfloat16)
+    c.all_reduce(z); c.broadcast(z, 0)
+    c.wait()
+    x.mul_(2.0)                                      # ordered behind the collective by wait()
+    torch.cuda.synchronize()
+    assert float(x.min()) == 6.0 and float(x.max()) == 6.0 and torch.equal(out, y) and float(z.float().min()) == 7.0
+    c.close()
 from cleantransformer_amd.models.modeling_bloom import BloomConfig, BloomForCausalLM
 from cleantransformer_amd.trainer.ddp import DistributedDataParallel as DDP
 torch.manual_seed(0)
@@ -339,6 +360,7 @@ am = torch.ones(2, 64, dtype=torch.long, device=dev)
 ref = make()
 (l0, _, _), _ = ref(input_ids=ids, attention_mask=am, labels=ids.clone()); l0.backward()
 m = make(); ddp = DDP(m, device_ids=[0], bucket_cap_mb=0.25)
+assert (ddp._direct is not None) == ("@BACKEND@" == "rccl")
 ddp._tied_sync._pad_rows_for_test = 37          # capacity != local rows: the padded id / row exchange (all_gather_into_tensor) on the real backend
 evs = ddp.record_launch_events()
 for it in range(2):
@@ -359,7 +381,7 @@ print("RCCL_DDP_OK")
     env = dict(os.environ)
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code.replace("@BACKEND@", backend)], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL_DDP_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
