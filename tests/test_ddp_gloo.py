@@ -358,6 +358,22 @@ def test_tied_chunk_rows_policy(monkeypatch):
     assert t.chunk_rows(211, 64) == 64
 
 
+def test_direct_rccl_backend_refuses_a_group_it_cannot_use(monkeypatch):
+    """CTMI_DDP_BACKEND=rccl needs GPU parameters and an RCCL (nccl) process group to hand the communicator's id around: asked for on
+    a gloo / CPU group it fails at construction with a sentence, not later inside a collective."""
+    from cleantransformer_amd.trainer import ddp as D
+
+    class _Owner:
+        process_group, world_size = None, 2
+        module = torch.nn.Linear(4, 4)
+    monkeypatch.setattr(D.dist, "get_backend", lambda g=None: "gloo")
+    monkeypatch.setenv("CTMI_DDP_BACKEND", "rccl")
+    with pytest.raises(RuntimeError, match="nccl"):
+        D.DistributedDataParallel._make_direct_comm(_Owner())
+    monkeypatch.setenv("CTMI_DDP_BACKEND", "torch")
+    assert D.DistributedDataParallel._make_direct_comm(_Owner()) is None
+
+
 def _loop_order_worker(rank, world, port, ret):
     for p in (ROOT, HERE):
         if p not in sys.path:
