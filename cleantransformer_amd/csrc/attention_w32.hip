@@ -190,28 +190,9 @@ __device__ __forceinline__ void store_tile32(const f32x16 (&acc)[HD / 32], float
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-// x[i] = (cc_i > thr) ? fill : x[i] for four elements: four compares into four SGPR pairs, then four selects — hipcc's own
-// v_cmp (VCC) / v_cndmask pairs need a wait state between a compare and ITS select and are emitted back to back.
-template <int R0, int C0>                                                    // elements R0..R0+3 of v, key offsets C0..C0+3
-__device__ __forceinline__ void fill4_future(f32x16& v, int thr, float fill) {
-    constexpr int C1 = C0 + 1, C2 = C0 + 2, C3 = C0 + 3;
-    static_assert(C0 >= 0 && C3 <= 64, "inline integer constants");
-    float a = v[R0], b = v[R0 + 1], c = v[R0 + 2], d = v[R0 + 3];
-    uint64_t m0, m1, m2, m3;
-    asm volatile("v_cmp_lt_i32_e64 %4, %8, %10\n\t"
-                 "v_cmp_lt_i32_e64 %5, %8, %11\n\t"
-                 "v_cmp_lt_i32_e64 %6, %8, %12\n\t"
-                 "v_cmp_lt_i32_e64 %7, %8, %13\n\t"
-                 "v_cndmask_b32_e64 %0, %0, %9, %4\n\t"
-                 "v_cndmask_b32_e64 %1, %1, %9, %5\n\t"
-                 "v_cndmask_b32_e64 %2, %2, %9, %6\n\t"
-                 "v_cndmask_b32_e64 %3, %3, %9, %7"
-                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
-                 : "v"(thr), "v"(fill), "n"(C0), "n"(C1), "n"(C2), "n"(C3));
-    v[R0] = a; v[R0 + 1] = b; v[R0 + 2] = c; v[R0 + 3] = d;
-}
-
-// The same for a fill value that padding keys do not take (GPT-2's -1e4: padding keys keep finfo.min): a padding key's raw score IS
+// x[i] = (cc_i > thr && x[i] > finfo.min) ? fill : x[i] for four elements — the fill that REPLACES a future score by a value padding keys do
+// not take (GPT-2's -1e4: padding keys keep finfo.min).  Compares go into SGPR pairs (hipcc's own v_cmp (VCC) / v_cndmask pairs need a wait
+// state between a compare and ITS select and are emitted back to back).  A padding key's raw score IS
 // finfo.min (its bias absorbs the dot product exactly), so x[i] = (cc_i > thr && x[i] > finfo.min) ? fill : x[i] needs no second look
 // at the key-bias row — which hipcc would otherwise keep live across the score MFMAs (32 registers and 16 copies per tile).
 template <int R0, int C0>
@@ -242,45 +223,6 @@ __device__ __forceinline__ void fill4_future_keepmin(f32x16& v, int thr, float f
     v[R0] = a; v[R0 + 1] = b; v[R0 + 2] = c; v[R0 + 3] = d;
 }
 
-// v[i] = (cc_i > thr  [GT]  or  cc_i < thr  [!GT]) ? 0 : v[i] on TWO accumulators at once (backward: P and dS of the masked pairs), the
-// four compares shared
-template <int R0, int C0, bool GT>
-__device__ __forceinline__ void zero4_pair(f32x16& u, f32x16& v, int thr) {
-    constexpr int C1 = C0 + 1, C2 = C0 + 2, C3 = C0 + 3;
-    static_assert(C0 >= 0 && C3 <= 64, "inline integer constants");
-    float a = u[R0], b = u[R0 + 1], c = u[R0 + 2], d = u[R0 + 3], e = v[R0], f = v[R0 + 1], g = v[R0 + 2], h = v[R0 + 3];
-    uint64_t m0, m1, m2, m3;
-    if constexpr (GT)
-        asm volatile("v_cmp_lt_i32_e64 %8, %12, %13\n\tv_cmp_lt_i32_e64 %9, %12, %14\n\tv_cmp_lt_i32_e64 %10, %12, %15\n\tv_cmp_lt_i32_e64 %11, %12, %16\n\t"
-                     "v_cndmask_b32_e64 %0, %0, 0, %8\n\tv_cndmask_b32_e64 %1, %1, 0, %9\n\tv_cndmask_b32_e64 %2, %2, 0, %10\n\tv_cndmask_b32_e64 %3, %3, 0, %11\n\t"
-                     "v_cndmask_b32_e64 %4, %4, 0, %8\n\tv_cndmask_b32_e64 %5, %5, 0, %9\n\tv_cndmask_b32_e64 %6, %6, 0, %10\n\tv_cndmask_b32_e64 %7, %7, 0, %11"
-                     : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
-                     : "v"(thr), "n"(C0), "n"(C1), "n"(C2), "n"(C3));
-    else
-        asm volatile("v_cmp_gt_i32_e64 %8, %12, %13\n\tv_cmp_gt_i32_e64 %9, %12, %14\n\tv_cmp_gt_i32_e64 %10, %12, %15\n\tv_cmp_gt_i32_e64 %11, %12, %16\n\t"
-                     "v_cndmask_b32_e64 %0, %0, 0, %8\n\tv_cndmask_b32_e64 %1, %1, 0, %9\n\tv_cndmask_b32_e64 %2, %2, 0, %10\n\tv_cndmask_b32_e64 %3, %3, 0, %11\n\t"
-                     "v_cndmask_b32_e64 %4, %4, 0, %8\n\tv_cndmask_b32_e64 %5, %5, 0, %9\n\tv_cndmask_b32_e64 %6, %6, 0, %10\n\tv_cndmask_b32_e64 %7, %7, 0, %11"
-                     : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
-                     : "v"(thr), "n"(C0), "n"(C1), "n"(C2), "n"(C3));
-    u[R0] = a; u[R0 + 1] = b; u[R0 + 2] = c; u[R0 + 3] = d; v[R0] = e; v[R0 + 1] = f; v[R0 + 2] = g; v[R0 + 3] = h;
-}
-// v[i] = (cc_i > thr || x[i] <= finfo.min) ? 0 : v[i]   (dQ, batch rows with all-masked queries: future pairs and padding keys)
-template <int R0, int C0>
-__device__ __forceinline__ void zero4_masked(f32x16& v, const f32x16& x, int thr) {
-    constexpr int C1 = C0 + 1, C2 = C0 + 2, C3 = C0 + 3;
-    static_assert(C0 >= 0 && C3 <= 64, "inline integer constants");
-    float a = v[R0], b = v[R0 + 1], c = v[R0 + 2], d = v[R0 + 3];
-    const float fmin = FINFO_MIN;
-    uint64_t m0, m1, m2, m3, n0, n1, n2, n3;
-    asm volatile("v_cmp_lt_i32_e64 %4, %12, %18\n\tv_cmp_lt_i32_e64 %5, %12, %19\n\tv_cmp_lt_i32_e64 %6, %12, %20\n\tv_cmp_lt_i32_e64 %7, %12, %21\n\t"
-                 "v_cmp_ge_f32_e64 %8, %13, %14\n\tv_cmp_ge_f32_e64 %9, %13, %15\n\tv_cmp_ge_f32_e64 %10, %13, %16\n\tv_cmp_ge_f32_e64 %11, %13, %17\n\t"
-                 "s_or_b64 %4, %4, %8\n\ts_or_b64 %5, %5, %9\n\ts_or_b64 %6, %6, %10\n\ts_or_b64 %7, %7, %11\n\t"
-                 "v_cndmask_b32_e64 %0, %0, 0, %4\n\tv_cndmask_b32_e64 %1, %1, 0, %5\n\tv_cndmask_b32_e64 %2, %2, 0, %6\n\tv_cndmask_b32_e64 %3, %3, 0, %7"
-                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&s"(n0), "=&s"(n1), "=&s"(n2), "=&s"(n3)
-                 : "v"(thr), "v"(fmin), "v"(x[R0]), "v"(x[R0 + 1]), "v"(x[R0 + 2]), "v"(x[R0 + 3]), "n"(C0), "n"(C1), "n"(C2), "n"(C3) : "scc");
-    v[R0] = a; v[R0 + 1] = b; v[R0 + 2] = c; v[R0 + 3] = d;
-}
-
 // The hazard recognizer of hipcc does not look into inline asm: an asm VALU instruction (max3, the fill helpers) that reads an MFMA
 // result gets none of the wait states a compiler-emitted reader would.  With the max tree directly behind the last score MFMA the
 // row maximum was taken over the partial sums of the earlier K-slices (caught by the statistics check of tools/attn_w32_check.py).
@@ -296,13 +238,14 @@ __device__ __forceinline__ void mfma_results_fence() {
 // instruction per ~5 cycles while a SIMD retires one per ~2.35 when two or more of its waves are in vector code; packed fp32
 // (v_pk_*_f32) runs at 12.9 cycles per instruction beside a wave that issues MFMAs (scalar fp32 VALU is untouched by it); a
 // matrix/vector ping-pong of the two waves of a SIMD therefore runs its vector segment at a third of the SIMD's VALU rate (built
-// and measured: slower than the plain loop).  So: a plain loop, one barrier per tile, and FOUR waves per SIMD — two 8-wave
-// workgroups per CU that no barrier couples (head_dim 64: 128 registers) — so that while one wave waits for its MFMAs the others
-// issue VALU; every fp32 operation scalar (this file is built with -fno-slp-vectorize: hipcc would pack adjacent adds and
-// multiplies); the instruction count per score cut to the bone:
-//   * the per-key bias enters as the C operand of the first score MFMA (no bias add),
-//   * scores stay in units of 1/scale ("raw") and p = exp2(raw*c - max*c), c = scale*log2(e): ONE fma + ONE exp2 per score,
-//   * the future-key fill is four compares into SGPR pairs + four selects per four scores (no VCC round trips).
+// and measured: slower than the plain loop).  So: a plain loop, one barrier per tile, and THREE workgroups of four waves per CU
+// (head_dim 64: 150 - 164 registers) that no barrier couples — so that while one wave waits for its MFMAs the others issue VALU;
+// every fp32 operation scalar (this file is built with -fno-slp-vectorize: hipcc would pack adjacent adds and multiplies); the
+// instruction count per score cut to the bone:
+//   * the per-key bias enters as the C operand of the first score MFMA (no bias add) — and so does the finfo.min of the causal
+//     future on the diagonal tile (no select after the MFMAs: at the merge of a masked and an unmasked path hipcc copies the whole
+//     accumulator out, one v_mov per score on every tile),
+//   * scores stay in units of 1/scale ("raw") and p = exp2(raw*c - max*c), c = scale*log2(e): ONE fma + ONE exp2 per score.
 template <int HD, int NW, bool REPLACE>       // REPLACE: future scores are REPLACED by a value other than finfo.min (GPT-2's -1e4)
 __global__ __launch_bounds__(NW * 64, NW == 4 ? (HD == 64 ? 3 : 2) : NW / 4) void attn32_fwd_kernel(AttnP p) {
     using W = WT<HD, NW>;

@@ -39,6 +39,18 @@ def test_attention_training_kernels_keep_three_waves_per_simd(kernels, kernel):
     assert k["vgpr_spill_count"] == 0, (name, k["vgpr_spill_count"])
 
 
+def test_attention_128row_kernels_keep_their_occupancy_without_scratch(kernels):
+    """csrc/attention_w32.hip (the measured path since round 3): forward and dQ at three workgroups per CU (<= 168 VGPRs), dK/dV and
+    the head_dim-128 forward at two (<= 256), and NO scratch anywhere — a scratch reload in the tile loop comes with
+    s_waitcnt vmcnt(0) and drains the LDS-DMA prefetch (the first head_dim-64 forward did exactly that with 5 spilled dwords)."""
+    w32 = {n: k for n, k in kernels.items() if "::attn32_" in n}          # (anonymous namespace)
+    assert len(w32) >= 6, sorted(w32)
+    for name, k in w32.items():
+        cap = 168 if ("attn32_dq_kernel<64" in name or "attn32_fwd_kernel<64" in name) else 256
+        assert k["vgpr_count"] <= cap, (name, k["vgpr_count"])
+        assert k["vgpr_spill_count"] == 0 and k.get("private_segment_fixed_size", 0) == 0, (name, k)
+
+
 def test_attention_head_dim_128_fast_kernels_do_not_spill(kernels):
     for kernel in ("attn_fwd_kernel", "attn_bwd_dq_kernel", "attn_bwd_dkdv_kernel"):
         (name, k), = pick(kernels, f"void {kernel}<unsigned short, 128, false, true, false>").items()
