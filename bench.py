@@ -46,6 +46,18 @@ def _profiled_traffic():
     return None
 
 
+def _profiled_step_traffic():
+    """HBM bytes per STEP, all kernels, from the committed PMC passes over this very command (profiles/rNN_step_traffic.json, newest
+    round first; tools/collect_profiles.sh + tools/summarize_profiles.py).  None if no such file exists."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_step_traffic.json")), reverse=True):
+        try:
+            return float(json.load(open(f))["traffic_bytes_per_step"])
+        except Exception:
+            continue
+    return None
+
+
 def build_model(device, compute_dtype):
     from cleantransformer_amd.models.modeling_bloom import BloomConfig, BloomForCausalLM
     cfg = BloomConfig(vocab_size=V, hidden_size=H, n_layer=L, num_attention_heads=NH, compute_dtype=compute_dtype)
@@ -296,7 +308,9 @@ def main(argv=None):
             # causal-half) over the step time, against the dense bf16 MFMA peak.  The largest single launch is a sub-entry.
             "roofline": {"bound": "mfma", "kernel": "whole SFT step (all kernels; F_tok = 6*N_mm + 6*L*S*H)",
                          "achieved": round(step_tflops, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(step_tflops / PEAK_BF16_TFLOPS, 4), "traffic": None, "flops_per_token": f_tok,
+                         "frac": round(step_tflops / PEAK_BF16_TFLOPS, 4), "traffic": _profiled_step_traffic(),
+                         "traffic_note": "HBM bytes per step, all kernels (separate --pmc FETCH_SIZE / WRITE_SIZE passes over this command, FETCH doubled per the gfx950 note; profiles/r*_step_traffic.json)",
+                         "flops_per_token": f_tok,
                          "largest_launch": {"kernel": "gemm_glds_kernel<bf16,NT,256x256 ping-pong> LM-head forward [T,1024]x[250880,1024]^T",
                                             "achieved": round(head_tflops, 1), "frac": round(head_tflops / PEAK_BF16_TFLOPS, 4),
                                             "avg_launch_ms": round(head_avg, 4), "launches": len(head_ms),

@@ -10,6 +10,9 @@ timeout 600 python bench.py --cpu-baseline ${CPU_BASELINE:-full} > $OUT/${R}_ben
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -- python bench.py --no-cpu-baseline --no-breakdown --no-padded-sample --steps 10 --warmup 3 > $OUT/${R}_bench_under_rocprof.json 2> $OUT/prof_bench.err
 CTMI_WGRAD_STREAM=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench_1stream -- python bench.py --no-cpu-baseline --no-breakdown --no-padded-sample --steps 10 --warmup 3 > $OUT/${R}_bench_1stream_under_rocprof.json 2> $OUT/prof_bench_1stream.err
 for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_step_$c -- python bench.py --no-cpu-baseline --no-breakdown --no-padded-sample --steps 10 --warmup 3 > $OUT/pmc_step_$c.log 2>&1
+done
+for c in FETCH_SIZE WRITE_SIZE; do
   MB_ONLY=lm_head MB_FWD_ONLY=1 timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -- python tools/microbench.py gemm > $OUT/pmc_$c.log 2>&1
 done
 timeout 300 python tools/microbench.py gemm attn ln ce adamw > $OUT/${R}_microbench.txt 2>&1

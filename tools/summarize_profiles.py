@@ -60,6 +60,30 @@ traffic = {
             "(private 4 MiB L2) streams the weight panel for each group of 4 tile rows; they are served by the 256 MiB Infinity Cache.",
 }
 json.dump(traffic, open(os.path.join(dst, f"{rnd}_lmhead_traffic.json"), "w"), indent=1)
+# HBM bytes per step over ALL kernels (PMC passes over the bench command itself: 15 steps traced)
+def step_counter(counter):
+    rows = list(csv.DictReader(open(one(f"pmc_step_{counter}/*/*_counter_collection.csv"))))
+    per = {}
+    for r in rows:
+        if r["Counter_Name"] == counter:
+            k = r["Kernel_Name"].split("(")[0][:90] if not r["Kernel_Name"].startswith("void (anonymous") else r["Kernel_Name"][:90]
+            per[k] = per.get(k, 0.0) + float(r["Counter_Value"])
+    return per
+try:
+    fs, ws = step_counter("FETCH_SIZE"), step_counter("WRITE_SIZE")
+    fetch_b = sum(fs.values()) * 1024 * 2 / steps
+    write_b = sum(ws.values()) * 1024 / steps
+    top = sorted(((fs.get(k, 0.0) * 2048 + ws.get(k, 0.0) * 1024) / steps, k) for k in set(fs) | set(ws))[::-1][:12]
+    json.dump({"command": "python bench.py --no-cpu-baseline --no-breakdown --no-padded-sample --steps 10 --warmup 3 (15 steps traced incl. warm-up)",
+               "fetch_bytes_per_step": fetch_b, "write_bytes_per_step": write_b, "traffic_bytes_per_step": fetch_b + write_b,
+               "note": "separate --pmc FETCH_SIZE / WRITE_SIZE passes (--kernel-trace only); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies the 128-B "
+                       "requests of wide coalesced reads at 64 B); fetches served by the Infinity Cache are included (the counters sit at the L2 boundary)",
+               "top_kernels_bytes_per_step": [{"kernel": k, "bytes": b} for b, k in top]},
+              open(os.path.join(dst, f"{rnd}_step_traffic.json"), "w"), indent=1)
+    print("step traffic: %.1f GB/step (fetch %.1f, write %.1f)" % ((fetch_b + write_b) / 1e9, fetch_b / 1e9, write_b / 1e9))
+except Exception as e:                                                   # (older collections have no step passes)
+    print("no step-traffic passes in this collection:", e)
+
 # the plain result files of the collection travel as they are
 import shutil
 for name in (f"{rnd}_bench_default.json", f"{rnd}_bench_under_rocprof.json", f"{rnd}_bench_1stream_under_rocprof.json",
