@@ -503,7 +503,10 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
 #ifndef CTMI_GEMM_GM256
 #define CTMI_GEMM_GM256 4
 #endif
-    constexpr int GM = (WM == 8) ? CTMI_GEMM_GM256 : 8;
+    // (weight-gradient layout on the 256-row tile = the LM head's [V,H] gradient, four tile columns wide: groups of ONE tile row put the four
+    // workgroups that share a dlogits panel next to each other in the order — 3.55 vs 3.61 ms, profiles/r03_gemm_tile_sweep.txt; the
+    // forward wants 4: 3.85 vs 4.32 ms)
+    constexpr int GM = (WM == 8) ? ((AK && BKM) ? 1 : CTMI_GEMM_GM256) : 8;
     // work item w -> (split, tile origin).  Items w, w+8, w+16, ... run on one XCD (workgroup b lands on XCD b % 8), so
     // each XCD gets a CONTIGUOUS range of the grouped tile order and its private L2 sees the operand panels reused.
     auto decode = [&](int w, int64_t& m0, int64_t& n0, int& split) {
