@@ -859,7 +859,7 @@ int ctmi_attn32_fwd(const AttnP& p, hipStream_t st) {
 
 int ctmi_attn32_bwd(const AttnP& p, hipStream_t st) {
     // head_dim 128: the 32-row accumulators of the backward (dK^T and dV^T: 128 registers) leave one wave per SIMD, and the general
-    // 16-row kernels are faster there (B=4 S=2048 nh=32: 797 vs 915 us) — only the forward takes this path at head_dim 128
+    // 16-row kernels are faster there (B=4 S=2048 nh=32: 797 vs 915 us; after the instruction diet 812 vs 899) — only the forward takes this path at head_dim 128
     if (!w32_ok(p) || !(w32_mask() & 2) || p.hd != 64) return 0;
     const int64_t BH = p.B * p.nh;
     // dQ first: it also publishes delta = rowsum(dO * O) for the dK/dV kernel (same stream: ordered)
