@@ -13,8 +13,15 @@
 #include <cstring>
 #include <dlfcn.h>
 #include <mutex>
+#include <string>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#define CTMI_HAVE_RCCL_HEADER 1
+#else
+#define CTMI_HAVE_RCCL_HEADER 0      // a build host without the RCCL development headers: the ctmi_ddp_* entry points report CTMI_ERR_UNSUPPORTED
+#endif
 
+#if CTMI_HAVE_RCCL_HEADER
 #define CTMI_HIP_OK(call, what) do { hipError_t e__ = (call); if (e__ != hipSuccess) { \
     ctmi_set_error("%s: %s", what, hipGetErrorString(e__)); return CTMI_ERR_LAUNCH; } } while (0)
 #define RC(call) do { int rc__ = (call); if (rc__ != CTMI_OK) return rc__; } while (0)
@@ -33,6 +40,7 @@ struct Rccl {
 };
 Rccl g_rccl;
 std::once_flag g_rccl_once;
+std::string g_rccl_why;                                 // why librccl could not be used (dlerror() text, captured ONCE: a second call returns NULL)
 
 template <typename F> bool sym(void* h, const char* name, F& out) {
     out = reinterpret_cast<F>(dlsym(h, name));
@@ -43,13 +51,16 @@ Rccl* rccl() {
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             g_rccl.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (g_rccl.handle) break;
+            const char* e = dlerror();
+            if (e != nullptr) g_rccl_why = e;
         }
-        if (!g_rccl.handle) return;
+        if (!g_rccl.handle) { if (g_rccl_why.empty()) g_rccl_why = "dlopen failed"; return; }
         Rccl& r = g_rccl;
         r.ok = sym(r.handle, "ncclGetUniqueId", r.GetUniqueId) && sym(r.handle, "ncclCommInitRankConfig", r.CommInitRankConfig) &&
                sym(r.handle, "ncclCommDestroy", r.CommDestroy) && sym(r.handle, "ncclAllReduce", r.AllReduce) &&
                sym(r.handle, "ncclAllGather", r.AllGather) && sym(r.handle, "ncclBroadcast", r.Broadcast) &&
                sym(r.handle, "ncclGetErrorString", r.GetErrorString);
+        if (!r.ok) g_rccl_why = "librccl.so lacks one of the nccl* entry points this library binds";
     });
     return g_rccl.ok ? &g_rccl : nullptr;
 }
@@ -77,7 +88,7 @@ extern "C" int ctmi_ddp_unique_id(void* id128) {
     CTMI_REQUIRE(id128 != nullptr, "ddp_unique_id: null output");
     static_assert(sizeof(ncclUniqueId) == 128, "the ABI hands the id over as 128 bytes");
     Rccl* R = rccl();
-    CTMI_REQUIRE(R != nullptr, "ddp_unique_id: librccl.so could not be loaded (%s)", dlerror() ? dlerror() : "missing symbols");
+    CTMI_REQUIRE(R != nullptr, "ddp_unique_id: librccl.so could not be loaded (%s)", g_rccl_why.c_str());
     ncclUniqueId id;
     RCCL_OK(R->GetUniqueId(&id), "ddp_unique_id");
     std::memcpy(id128, &id, sizeof(id));
@@ -88,7 +99,7 @@ extern "C" int ctmi_ddp_create(const void* id128, int rank, int world, int max_c
     CTMI_REQUIRE(id128 != nullptr && comm_out != nullptr, "ddp_create: null argument");
     CTMI_REQUIRE(world >= 1 && rank >= 0 && rank < world, "ddp_create: rank %d of %d", rank, world);
     Rccl* R = rccl();
-    CTMI_REQUIRE(R != nullptr, "ddp_create: librccl.so could not be loaded");
+    CTMI_REQUIRE(R != nullptr, "ddp_create: librccl.so could not be loaded (%s)", g_rccl_why.c_str());
     Comm* c = new Comm();
     c->rank = rank; c->world = world;
     ncclUniqueId id;
@@ -130,6 +141,7 @@ extern "C" int ctmi_ddp_all_reduce(void* comm, void* buf, int64_t count, int dty
     CTMI_REQUIRE(dtype == CTMI_F32 || dtype == CTMI_BF16, "ddp_all_reduce: dtype %d", dtype);
     Comm* c = reinterpret_cast<Comm*>(comm);
     Rccl* R = rccl();
+    CTMI_REQUIRE(R != nullptr && c->comm != nullptr, "ddp_all_reduce: no RCCL communicator behind this handle");
     std::lock_guard<std::mutex> lk(c->mu);
     RC(fence_in(c, as_stream(compute_stream), "ddp_all_reduce: fence"));
     RCCL_OK(R->AllReduce(buf, buf, (size_t)count, dtype == CTMI_F32 ? ncclFloat : ncclBfloat16, ncclSum, c->comm, c->st), "ddp_all_reduce");
@@ -140,6 +152,7 @@ extern "C" int ctmi_ddp_all_gather(void* comm, const void* send, void* recv, int
     CTMI_REQUIRE(comm != nullptr && send != nullptr && recv != nullptr && bytes_per_rank >= 0, "ddp_all_gather: bad argument");
     Comm* c = reinterpret_cast<Comm*>(comm);
     Rccl* R = rccl();
+    CTMI_REQUIRE(R != nullptr && c->comm != nullptr, "ddp_all_gather: no RCCL communicator behind this handle");
     std::lock_guard<std::mutex> lk(c->mu);
     RC(fence_in(c, as_stream(compute_stream), "ddp_all_gather: fence"));
     RCCL_OK(R->AllGather(send, recv, (size_t)bytes_per_rank, ncclInt8, c->comm, c->st), "ddp_all_gather");
@@ -151,6 +164,7 @@ extern "C" int ctmi_ddp_broadcast(void* comm, void* buf, int64_t bytes, int root
     Comm* c = reinterpret_cast<Comm*>(comm);
     CTMI_REQUIRE(root >= 0 && root < c->world, "ddp_broadcast: root %d of %d", root, c->world);
     Rccl* R = rccl();
+    CTMI_REQUIRE(R != nullptr && c->comm != nullptr, "ddp_broadcast: no RCCL communicator behind this handle");
     std::lock_guard<std::mutex> lk(c->mu);
     RC(fence_in(c, as_stream(compute_stream), "ddp_broadcast: fence"));
     RCCL_OK(R->Broadcast(buf, buf, (size_t)bytes, ncclInt8, root, c->comm, c->st), "ddp_broadcast");
@@ -165,3 +179,14 @@ extern "C" int ctmi_ddp_wait(void* comm, void* compute_stream) {
     CTMI_HIP_OK(hipStreamWaitEvent(as_stream(compute_stream), c->ev_out, 0), "ddp_wait: wait");
     return CTMI_OK;
 }
+
+#else   // !CTMI_HAVE_RCCL_HEADER
+#define CTMI_NO_RCCL(name) do { ctmi_set_error(name ": this libctmi355.so was built without <rccl/rccl.h>; rebuild it on a ROCm image with RCCL"); return CTMI_ERR_UNSUPPORTED; } while (0)
+extern "C" int ctmi_ddp_unique_id(void*) { CTMI_NO_RCCL("ddp_unique_id"); }
+extern "C" int ctmi_ddp_create(const void*, int, int, int, void**) { CTMI_NO_RCCL("ddp_create"); }
+extern "C" int ctmi_ddp_destroy(void*) { return CTMI_OK; }
+extern "C" int ctmi_ddp_all_reduce(void*, void*, int64_t, int, void*) { CTMI_NO_RCCL("ddp_all_reduce"); }
+extern "C" int ctmi_ddp_all_gather(void*, const void*, void*, int64_t, void*) { CTMI_NO_RCCL("ddp_all_gather"); }
+extern "C" int ctmi_ddp_broadcast(void*, void*, int64_t, int, void*) { CTMI_NO_RCCL("ddp_broadcast"); }
+extern "C" int ctmi_ddp_wait(void*, void*) { CTMI_NO_RCCL("ddp_wait"); }
+#endif

@@ -41,7 +41,12 @@
 #ifndef CTMI_PP128_RING
 #define CTMI_PP128_RING 4
 #endif
-constexpr int glds_ring(bool pp, int wm) { return !pp ? 3 : ((wm == 4 && !CTMI_EPI_SHUFFLE) ? CTMI_PP128_RING : 4); }
+// (CTMI_PP256X_RING: ring depth of the 256-row ping-pong tile with the cross-lane epilogue — no patches, so a fifth 32 KiB stage fits the
+// 160 KiB: one more K-step of DMA lead for operands that come from HBM rather than L2; round-4 experiment, tools/chain_probe.py)
+#ifndef CTMI_PP256X_RING
+#define CTMI_PP256X_RING 4
+#endif
+constexpr int glds_ring(bool pp, int wm, bool xlane = false) { return !pp ? 3 : ((wm == 4 && !CTMI_EPI_SHUFFLE) ? CTMI_PP128_RING : ((xlane && wm == 8) ? CTMI_PP256X_RING : 4)); }
 constexpr int glds_patch_bytes(bool pp, int wm, bool xlane = false) { return (pp && !xlane && !(wm == 4 && !CTMI_EPI_SHUFFLE)) ? 4 * 8192 : 0; }
 // XLANE instantiations of the 256-row ping-pong tile: cross-lane epilogue there too (no patches).  Per launch, not per tile: it is the
 // better epilogue for a row-major-B [T,4H]-sized output and the worse one for the logits (see the note above), so the launcher
@@ -77,6 +82,16 @@ constexpr int glds_patch_bytes(bool pp, int wm, bool xlane = false) { return (pp
 #endif
 #ifndef CTMI_PP256_XLANE
 #define CTMI_PP256_XLANE 1
+#endif
+// Ping-pong load phase: issue the stage's LDS-DMA pieces BEFORE the fragment reads (the slot they overwrite was retired by the barrier
+// that opens the phase, so the order inside the phase is free).  Round-4 experiment (profiles/r04_gemm_load_phase.txt).
+#ifndef CTMI_PP_DMA_FIRST
+#define CTMI_PP_DMA_FIRST 0
+#endif
+// Ping-pong priorities: 0 = s_setprio 1 around every MFMA phase (rounds 1-3); 1 = static: the later-dispatched row group (waves 4-7) runs
+// at priority 1 for the whole kernel, no per-phase flips; 2 = no priorities at all.
+#ifndef CTMI_PP_PRIO
+#define CTMI_PP_PRIO 0
 #endif
 
 
@@ -483,7 +498,7 @@ template <typename TO, bool AK, bool BKM, int EPI, int WM, int WGN, bool PP = fa
 __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
     using T = bf16_t;
     constexpr int NW = 2 * WGN;                                             // waves: 2 along M x WGN along N
-    constexpr int BM = WM * 32, BN = WGN * 64, BK = 32, NST = glds_ring(PP, WM);
+    constexpr int BM = WM * 32, BN = WGN * 64, BK = 32, NST = glds_ring(PP, WM, XLANE);
     using TA = GTile<AK, BM>;
     using TB = GTile<BKM, BN>;
     constexpr int STAGE = TA::BYTES + TB::BYTES;
@@ -988,6 +1003,7 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
         wait_stages(inflight - 1);
         __builtin_amdgcn_s_barrier();
         if (wr == 1) __builtin_amdgcn_s_barrier();                            // stagger the two row groups by one phase
+        if constexpr (CTMI_PP_PRIO == 1) { if (wr == 1) __builtin_amdgcn_s_setprio(1); }
         GEMM_TICK(t_pro);
 #if CTMI_GEMM_TIMING
         unsigned long long ph_issue = 0, ph_wait = 0, ph_bar1 = 0, ph_mfma = 0, ph_bar2 = 0;
@@ -1046,29 +1062,29 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
                         const unsigned char* as = smem_raw + AOFF + rd * TA::BYTES;
                         const unsigned char* bs = smem_raw + BOFF + rd * TB::BYTES;
                         short8 af[WM], bf[4];
+                        if constexpr (CTMI_PP_DMA_FIRST) issue_stage(wrb);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) bf[j] = TB::frag(bs, wc * 64 + j * 16, lane);
 #pragma unroll
                         for (int i = 0; i < WM; ++i) af[i] = TA::frag(as, wr * (WM * 16) + i * 16, lane);
-                        issue_stage(wrb);
-                        wait_stages(2);
+                        if constexpr (!CTMI_PP_DMA_FIRST) issue_stage(wrb);
+                        wait_stages(NST - 2);
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         __builtin_amdgcn_sched_barrier(0);
                         __builtin_amdgcn_s_barrier();
                         __builtin_amdgcn_sched_barrier(0);
-                        __builtin_amdgcn_s_setprio(1);
+                        if constexpr (CTMI_PP_PRIO == 0) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                         for (int i = 0; i < WM; ++i)
 #pragma unroll
                             for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(bf[j], af[i], acc[i][j]);
-                        __builtin_amdgcn_s_setprio(0);
+                        if constexpr (CTMI_PP_PRIO == 0) __builtin_amdgcn_s_setprio(0);
                         __builtin_amdgcn_sched_barrier(0);
                         __builtin_amdgcn_s_barrier();
                         __builtin_amdgcn_sched_barrier(0);
-                        rd = (rd + 1) & (NST - 1);
-                        wrb = (wrb + 1) & (NST - 1);
+                        if constexpr ((NST & (NST - 1)) == 0) { rd = (rd + 1) & (NST - 1); wrb = (wrb + 1) & (NST - 1); }
+                        else { rd = rd == NST - 1 ? 0 : rd + 1; wrb = wrb == NST - 1 ? 0 : wrb + 1; }
                     }
-                    static_assert(!CTMI_PP_STEADY || (NST & (NST - 1)) == 0 || !PP, "ring positions wrap by masking");
                     ti += nsteady;
                     tc += nsteady;
                     if (ti == nti) { wi += G; if (wi < nwork) setup_issue(); }
@@ -1085,18 +1101,24 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
 #else
 #define PH_TICK(acc) do { } while (0)
 #endif
+            const bool more = wi < nwork && !(GEMM_DBG(g) & 1);
+            if constexpr (CTMI_PP_DMA_FIRST && !CTMI_PP_SPLIT_DMA) {
+                if (more) {
+                    issue_stage(wrb);
+                    stage_issued(); ++inflight; wrb = wrb == NST - 1 ? 0 : wrb + 1;
+                }
+            }
             if (!(GEMM_DBG(g) & 4) || tc == 0) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) bf[j] = TB::frag(bs, wc * 64 + j * 16, lane);
 #pragma unroll
                 for (int i = 0; i < WM; ++i) af[i] = TA::frag(as, wr * (WM * 16) + i * 16, lane);
             }
-            const bool more = wi < nwork && !(GEMM_DBG(g) & 1);
             if constexpr (CTMI_PP_SPLIT_DMA) {
                 if (more) { issue_A(wrb); ++inflight; }
                 wait_split(inflight - 2, more);
             } else {
-                if (more) {
+                if (more && !CTMI_PP_DMA_FIRST) {
                     issue_stage(wrb);
                     stage_issued(); ++inflight; wrb = wrb == NST - 1 ? 0 : wrb + 1;
                 }
@@ -1109,7 +1131,7 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             PH_TICK(ph_bar1);
-            __builtin_amdgcn_s_setprio(1);
+            if constexpr (CTMI_PP_PRIO == 0) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -1127,7 +1149,7 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
             if constexpr (CTMI_PP_SPLIT_DMA) {
                 if (more) { stage_issued(); wrb = wrb == NST - 1 ? 0 : wrb + 1; }
             }
-            __builtin_amdgcn_s_setprio(0);
+            if constexpr (CTMI_PP_PRIO == 0) __builtin_amdgcn_s_setprio(0);
             PH_TICK(ph_mfma);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -1248,7 +1270,7 @@ static int reserved_cus();
 template <typename TO, bool AK, bool BKM, int EPI, int WM, int WGN, bool PP = false, bool RES = false, bool XLANE = false>
 static void glds_launch(GemmArgs& g, hipStream_t st) {
     constexpr int BM = WM * 32, BN = WGN * 64;
-    const size_t lds = glds_ring(PP, WM) * (size_t)(GTile<AK, BM>::BYTES + GTile<BKM, BN>::BYTES) + glds_patch_bytes(PP, WM, XLANE);
+    const size_t lds = glds_ring(PP, WM, XLANE) * (size_t)(GTile<AK, BM>::BYTES + GTile<BKM, BN>::BYTES) + glds_patch_bytes(PP, WM, XLANE);
     const int64_t nwork = cdiv64(g.M, BM) * cdiv64(g.N, BN) * g.splits;
     // persistent launch: one resident workgroup per occupancy slot (256 CUs x workgroups that fit a CU's 160 KiB LDS),
     // each walking work items bid, bid+G, ... with its DMA stream prefetching across item boundaries
@@ -1348,7 +1370,10 @@ static void pick_tile(int64_t M, int64_t N, int64_t K, bool wgrad, bool bkm, int
     if (wgrad) {
         static int nosplit = -1;
         if (nosplit < 0) { const char* e = getenv("CTMI_WGRAD_NOSPLIT"); nosplit = e ? atoi(e) : 0; }
-        if (t1 >= 1024) tile = 3;                                   // LM head: [V,H]
+        // LM head: [V,H] — and its row windows: the data-parallel path produces the tied gradient in <= 64 MiB pieces of 15 360 / 16 384
+        // rows (trainer/ddp.py chunk_rows: whole rounds of the CUs the policy leaves), 240 / 256 tiles of 256x256; the layer weight
+        // gradients of this geometry have <= 64 such tiles (round-3 advisor: a piece used to fall to the unsplit 128x128 rule below)
+        if (t1 >= 1024 || (t2 >= 128 && M >= 8 * N)) tile = 3;                // (tall: a [rows, H] window, not a square layer gradient)
         else if (nosplit) tile = nosplit == 2 ? 4 : 3;
         else {
             // round 3 (profiles/r03_gemm_tile_sweep.txt): a weight gradient with >= 256 tiles of 128x128 (h->4h and 4h->h) runs them

@@ -36,6 +36,30 @@ __global__ void probe_kernel(int which, const float* __restrict__ in, float* __r
     }
 }
 
+// Shader-clock probe (bench.py's `timing.shader_clock_mhz_*`): every workgroup runs `iters` dependent-free bf16 MFMAs per wave (the load the
+// training step puts on the chip: power is what sets the clock, the guide's "DVFS give-back"), and wave 0 of workgroup 0 brackets them with
+// s_memtime (shader cycles) and s_memrealtime (the constant 100 MHz reference counter): clock = 100 MHz x d(memtime) / d(memrealtime).
+__global__ __launch_bounds__(256) void clock_probe_kernel(int iters, unsigned long long* __restrict__ out) {
+    short8 a, b;
+    for (int j = 0; j < 8; ++j) { a[j] = (short)(0x3f80 + threadIdx.x + j); b[j] = (short)(0x3f00 + 3 * threadIdx.x + j); }
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+        c0 = Mma<bf16_t>::mma(a, b, c0); c1 = Mma<bf16_t>::mma(a, b, c1);
+        c2 = Mma<bf16_t>::mma(a, b, c2); c3 = Mma<bf16_t>::mma(a, b, c3);
+    }
+    asm volatile("" :: "v"(c0), "v"(c1), "v"(c2), "v"(c3));
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[0] = t1 - t0; out[1] = r1 - r0; }
+}
+
+extern "C" int ctmi_clock_probe(int mfma_iters, unsigned long long* out, void* stream) {
+    CTMI_REQUIRE(out && mfma_iters > 0 && mfma_iters <= (1 << 22), "clock_probe: bad args");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(2048), dim3(256), 0, as_stream(stream), mfma_iters, out);
+    CTMI_CHECK_LAUNCH("clock_probe");
+    return CTMI_OK;
+}
+
 extern "C" int ctmi_probe(int which, const float* in, float* out, void* stream) {
     CTMI_REQUIRE(in && out && which >= 0 && which <= 2, "probe: bad args");
     hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(64), 0, as_stream(stream), which, in, out);

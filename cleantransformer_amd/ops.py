@@ -632,6 +632,17 @@ def profile_end():
     return {name: (float(ms[i]), int(cnt[i])) for i, name in enumerate(_lib.PROF_CLASSES)}
 
 
+def clock_probe(device=None, mfma_iters: int = 20000) -> float:
+    """Shader clock in MHz under a short all-CU bf16 MFMA load (include/ctmi355.h ctmi_clock_probe: s_memtime over s_memrealtime in one
+    wave while 2048 workgroups issue matrix instructions).  Synchronises the device: call it outside timed regions."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    out = torch.zeros(2, dtype=torch.int64, device=dev)
+    check(_lib.load().ctmi_clock_probe(int(mfma_iters), _p(out), _stream()), "clock_probe")
+    torch.cuda.synchronize(dev)
+    cyc, ref = out.tolist()
+    return 100.0 * cyc / max(ref, 1)
+
+
 def set_attn_path(mask: int) -> int:
     """Attention kernel family for the bf16 training shapes (include/ctmi355.h ctmi_attn_set_path): bit 0 forward, bit 1 backward on the
     256-row kernels; returns the previous value."""

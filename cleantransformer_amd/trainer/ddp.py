@@ -14,8 +14,10 @@ is built MI355X-first:
   * the all-reduce is issued from the autograd hook through ``torch.distributed`` (backend "nccl" == RCCL on ROCm):
     RCCL runs it on its own HIP stream, fenced against the compute stream by events, so buckets overlap with the
     remaining backward kernels; the compute stream only waits at the end of backward;
-  * on a fully connected xGMI mesh large buckets are what keeps all 7 links busy, hence the 25 MiB default stays and
-    the oversized tied embedding/LM-head gradient travels as one bucket.
+  * on a fully connected xGMI mesh large buckets are what keeps all 7 links busy, hence the 25 MiB default stays; the
+    oversized tied embedding / LM-head gradient does NOT travel as one bucket: its dense part is produced and all-reduced in
+    <= 64 MiB row windows right after the LM-head backward, its embedding part as gathered rows (``_TiedGradSync``); the
+    bucket it owns is only the fallback for accumulation steps.
 
 It is transport-agnostic (``gloo`` on CPU works and is how the semantics are tested: tests/test_ddp_gloo.py).
 
@@ -81,7 +83,7 @@ class _TiedGradSync:
         self.steps = 0                                               # how many backward passes took the early path
         self._tmax = None                                            # agreed row capacity of this step's exchange (announce)
         self._announced = False
-        self._tbuf = self._thost = self._tstream = self._tevent = None
+        self._tbuf = self._thost = self._tstream = self._tevent = self._tall = None
 
     def prescale(self, weight: torch.nn.Parameter):
         """1/world if this backward pass reduces the dense part early (the LM-head weight-gradient GEMM then applies it as
@@ -123,6 +125,19 @@ class _TiedGradSync:
             self._tstream = torch.cuda.Stream(device=device)
             self._tevent = torch.cuda.Event()
         self._tbuf.fill_(int(n_tokens))
+        if o._direct is not None:
+            # ONE communicator carries every collective of the step (round-3 advisor): two RCCL communicators with kernels in
+            # flight on the same device are only guaranteed to make progress if both can be co-resident, which the "reserve"
+            # policy (persistent GEMMs on 256 - R CUs, R channels) does not promise.  all_gather of one int64 per rank, max
+            # taken on the side stream that also carries the result to pinned host memory.
+            if self._tall is None or self._tall.device != self._tbuf.device or self._tall.numel() != o.world_size:
+                self._tall = torch.empty(o.world_size, dtype=torch.int64, device=device)
+            o._direct.all_gather(self._tall, self._tbuf)
+            with torch.cuda.stream(self._tstream):
+                o._direct.wait()                                     # the side stream waits for the collective; the host does not
+                self._thost.copy_(self._tall.max().reshape(1), non_blocking=True)
+                self._tevent.record(self._tstream)
+            return
         work = dist.all_reduce(self._tbuf, op=dist.ReduceOp.MAX, group=o.process_group, async_op=True)
         with torch.cuda.stream(self._tstream):
             work.wait()                                              # the side stream waits for the collective; the host does not
@@ -154,6 +169,20 @@ class _TiedGradSync:
         if nbytes <= 0:
             return V
         rows = max(256, (nbytes // (4 * H)) // 256 * 256)
+        # whole rounds of the CUs the GEMM launcher may use: a piece is a [rows, H] weight gradient on 256 x 256 tiles (csrc/gemm.hip
+        # pick_tile sends such pieces to the LM-head tile), i.e. rows/256 * ceil(H/256) tiles over 256 - reserved CUs — 64 MiB at
+        # H = 1024 is 256 tiles: one round of 256 CUs, but 1.07 rounds of the 240 a "reserve 16" policy leaves (round-3 advisor)
+        try:
+            from .. import ops
+            shared, reserved = ops.get_launch_policy()
+        except Exception:                                            # CPU / gloo semantics tests: no library
+            shared, reserved = True, 0
+        tiles_n = max(1, -(-H // 256))
+        slots = 256 - (0 if shared else reserved)
+        if slots % tiles_n == 0:
+            per_round = slots // tiles_n * 256                       # rows of the table per full round of tiles
+            if rows >= per_round:
+                rows = rows // per_round * per_round
         return min(rows, V)
 
     def begin(self, dw: torch.Tensor) -> None:
@@ -460,6 +489,20 @@ class DistributedDataParallel(torch.nn.Module):
             self._reset_step_state()
             self._arm_launch_policy()
         return self.module(*inputs, **kwargs)
+
+    def close(self) -> None:
+        """Detach from the module: remove the gradient hooks, drop the bucket memory and the library communicator.  bench.py's
+        configuration probe wraps the same model several times (backend x launch policy) and keeps one."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        for b in self._buckets:
+            b.flat = b.comm = b.work = None
+        if self._tied_param is not None and getattr(self._tied_param, "_ct_tied_sync", None) is self._tied_sync:
+            self._tied_param._ct_tied_sync = None
+        if self._direct is not None:
+            self._direct.close()
+            self._direct = None
 
     def bucket_summary(self):
         return [(b.index, len(b.params), b.numel * 4) for b in self._buckets]

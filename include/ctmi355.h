@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CTMI_ABI_VERSION 10
+#define CTMI_ABI_VERSION 11
 
 enum ctmi_dtype { CTMI_F32 = 0, CTMI_BF16 = 1 };
 enum ctmi_status { CTMI_OK = 0, CTMI_ERR_ARG = -1, CTMI_ERR_LAUNCH = -2, CTMI_ERR_UNSUPPORTED = -3 };
@@ -337,6 +337,10 @@ int ctmi_bloom_block_bwd(const ctmi_bloom_block* blk /* host */, const ctmi_bloo
 
 /* ---- hardware probe (diagnostics: dumps MFMA / LDS-transpose lane layouts into out[]; used by tests only) */
 int ctmi_probe(int which, const float* in /* device */, float* out /* device, 256 floats */, void* stream);
+/* shader-clock probe (measurement; no reference counterpart): 2048 workgroups x 4 waves each issue 4*mfma_iters bf16 MFMAs; wave 0 of
+ * workgroup 0 writes out[0] = elapsed shader cycles (s_memtime), out[1] = elapsed ticks of the constant 100 MHz counter (s_memrealtime):
+ * shader clock under matrix load = 100 MHz * out[0] / out[1].  bench.py launches it right before and right after the timed region. */
+int ctmi_clock_probe(int mfma_iters, unsigned long long* out /* device, 2 x u64 */, void* stream);
 
 #ifdef __cplusplus
 }

@@ -88,15 +88,25 @@ def attention(p: Dict[str, Tensor], pre: str, x: Tensor, add_mask: Optional[Tens
         k = torch.cat((past[0], k), dim=-2)
         v = torch.cat((past[1], v), dim=-2)
     present = (k, v)
+    o = attention_core(q, k, v, add_mask).transpose(1, 2).contiguous().view(B, S, H)
+    return conv1d(o, p[pre + "c_proj.weight"], p[pre + "c_proj.bias"]), present
+
+
+def attention_core(q: Tensor, k: Tensor, v: Tensor, add_mask: Optional[Tensor], score_bias: Optional[Tensor] = None) -> Tensor:
+    """modeling_gpt.py:86-95 on split heads q [B,nh,S,hd], k / v [B,nh,Sk,hd]: scores / sqrt(hd), the causal future REPLACED by -1e4
+    (`w*b - 1e4*(1-b)`, :88-89), the additive key mask (:91-92), softmax, P.V -> [B,nh,S,hd].  `score_bias` ([B,nh,1|S,Sk], added to
+    the scaled scores before the replacement) is not part of the reference: the HIP kernels that implement this fill also serve
+    ALiBi models, and the tests check that combination against the same arithmetic."""
+    S, Sk = q.size(-2), k.size(-2)
     w = torch.matmul(q, k.transpose(2, 3)) / math.sqrt(v.size(-1))
-    Sk = k.size(-2)
-    b = torch.tril(torch.ones(Sk, Sk))[Sk - S:Sk, :Sk].view(1, 1, S, Sk)                    # :88
+    if score_bias is not None:
+        w = w + score_bias
+    b = torch.tril(torch.ones(Sk, Sk, dtype=w.dtype))[Sk - S:Sk, :Sk].view(1, 1, S, Sk)     # :88
     w = w * b + -1e4 * (1 - b)                                                              # :89
     if add_mask is not None:
         w = w + add_mask                                                                    # :91-92
     w = torch.softmax(w, dim=-1)
-    o = torch.matmul(w, v).transpose(1, 2).contiguous().view(B, S, H)
-    return conv1d(o, p[pre + "c_proj.weight"], p[pre + "c_proj.bias"]), present
+    return torch.matmul(w, v)
 
 
 def block(p: Dict[str, Tensor], i: int, x: Tensor, add_mask, s: GPTShape, past=None):

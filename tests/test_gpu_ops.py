@@ -51,6 +51,27 @@ def check(name, got, ref, rtol, atol=0.0):
                              f"rel-norm {rel_err(got, ref):.3e}; first bad idx {idx} got {float(got[tuple(idx)])} ref {float(ref[tuple(idx)])}")
 
 
+def check_norm(name, got, ref, rel, row_rel, row_abs_frac=1e-2):
+    """Norm-wise bounds for gradient tensors (round-3 verdict: a 10 % element tolerance lets a wrong scale on a minority of elements
+    through): the global relative error ||got - ref|| / ||ref|| <= rel AND, for every row of the last dimension,
+    ||d_row|| <= row_rel * ||ref_row|| + row_abs_frac * rms_r ||ref_r||  (the absolute term covers rows whose gradient is ~0)."""
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f"{name}: non-finite values"
+    g2, r2 = got.reshape(-1, got.shape[-1]), ref.reshape(-1, ref.shape[-1])
+    glob = float((g2 - r2).norm() / (r2.norm() + 1e-300))
+    rn, dn = r2.norm(dim=1), (g2 - r2).norm(dim=1)
+    scale = float(rn.pow(2).mean().sqrt())
+    excess = dn - (row_rel * rn + row_abs_frac * scale)
+    worst = int(excess.argmax())
+    if os.environ.get("CTMI_TEST_VERBOSE"):
+        print(f"[check_norm] {name}: global {glob:.3e} (bound {rel:.1e}); worst row {worst}: |d| {float(dn[worst]):.3e} |ref| {float(rn[worst]):.3e} "
+              f"rms|ref| {scale:.3e}; max row rel (rows >= rms/10) {float((dn / rn.clamp_min(1e-300))[rn > scale / 10].max()):.3e}")
+    assert glob <= rel, f"{name}: relative norm error {glob:.3e} > {rel:.1e}"
+    assert float(excess[worst]) <= 0, (f"{name}: row {worst}: |got - ref| = {float(dn[worst]):.3e} > {row_rel:.1e} * {float(rn[worst]):.3e} + "
+                                       f"{row_abs_frac:.0e} * {scale:.3e}")
+
+
 def rnd(*shape, seed=0, scale=1.0):
     return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
 
@@ -282,6 +303,10 @@ def test_bloom_attention_fwd_bwd(dtype, rtol, atol, B, S, nh, hd, kind):
     o.attn_bwd(qd, qd[:, hd:], qd[:, 2 * hd:], out, to_dev(go.reshape(B * S, H), dtype), sm, sl,
                dq, dq[:, hd:], dq[:, 2 * hd:], desc, slopes, mask)
     check("attn.dqkv", dq.float().view(B, S, 3 * H), qr.grad, rtol * 5, atol * 5)
+    if dtype == torch.bfloat16:
+        check_norm("attn.dqkv (norms)", dq.float().view(B, S, 3 * H), qr.grad, 1e-2, 2e-2)
+    else:
+        check_norm("attn.dqkv (norms)", dq.float().view(B, S, 3 * H), qr.grad, 5e-5, 2e-4, 1e-4)
 
 
 W32_CASES = [  # B, S, nh, hd, mask kind, future fill (0 = finfo.min: Bloom; -1e4: GPT-2)
@@ -337,15 +362,28 @@ def test_attention_128row_kernels_vs_oracle_and_general_kernels(B, S, nh, hd, ki
     fin = m_old > FMIN / 2
     assert torch.equal(m_new <= FMIN, m_old <= FMIN)                         # all-masked rows carry the same sentinel
     assert float((m_new - m_old)[fin].abs().max()) < 1e-3 and float(((l_new - l_old).abs() / l_old).max()) < 1e-3
+    qr = qkv.clone().requires_grad_(True)
     if fill == 0.0:
-        qr = qkv.clone().requires_grad_(True)
-        ref = _attn_oracle(qr, am, nh)
-        ref.backward(go)
-        check("w32 out vs oracle", o_new.view(B, S, H), ref, 2e-2, 1e-2)
-        check("w32 dqkv vs oracle", g_new.view(B, S, 3 * H), qr.grad, 1e-1, 5e-2)
+        ref = _attn_oracle(qr, am, nh)                                        # modeling_bloom.py:84-116 (finfo.min fill)
+    else:
+        # GPT-2's replacement fill (modeling_gpt.py:88-93): oracle.gpt_ref.attention_core on the same heads, ALiBi as the score bias the
+        # kernel adds before the replacement, the padding keys as the reference's additive finfo.min mask — in fp32, where
+        # `score + finfo.min` is exactly finfo.min and a row whose whole causal window is padding attends uniformly to the FUTURE
+        from oracle import gpt_ref as GR
+        x = qr.view(B, S, nh, 3, hd)
+        q, k, v = (x[..., i, :].transpose(1, 2) for i in range(3))
+        bias = R.build_alibi(am, nh).view(B, nh, 1, S)
+        add = ((1 - am).float() * FMIN).view(B, 1, 1, S)
+        ref = GR.attention_core(q, k, v, add, score_bias=bias).transpose(1, 2).reshape(B, S, H)
+    ref.backward(go)
+    check("w32 out vs oracle", o_new.view(B, S, H), ref, 2e-2, 1e-2)
+    check_norm("w32 out vs oracle (norms)", o_new.view(B, S, H), ref, 8e-3, 2e-2)
+    # measured on MI355X (round 4): global 2.3e-3 - 2.5e-3, worst row 3.7e-3 of its norm: the bounds leave a factor 4 - 5
+    check_norm("w32 dqkv vs oracle", g_new.view(B, S, 3 * H), qr.grad, 1e-2, 2e-2)
+    check_norm("general dqkv vs oracle", g_old.view(B, S, 3 * H), qr.grad, 1e-2, 2e-2)
     check("w32 out vs general", o_new, o_old, 2e-2, 1e-2)
-    check("w32 dqkv vs general", g_new, g_old, 1e-1, 5e-2)
-    check("w32 fwd -> general bwd", g_x, g_old, 1e-1, 5e-2)
+    check_norm("w32 dqkv vs general", g_new.view(B, S, 3 * H), g_old.view(B, S, 3 * H), 5e-3, 1e-2)
+    check_norm("w32 fwd -> general bwd", g_x.view(B, S, 3 * H), g_old.view(B, S, 3 * H), 5e-3, 1e-2)
     assert torch.equal(o_x, o_new)
 
 
@@ -618,6 +656,79 @@ def test_gemm_more_tiles_than_slots():
     dw = o.linear_wgrad(dy2, x2)
     ref = dy2.float().t() @ x2.float()
     assert torch.allclose(dw.float(), ref, rtol=1e-3, atol=1e-2), (dw.float() - ref).abs().max()
+
+
+STEP_GEMMS = [  # name, kind, rows T, out features, in features, epilogue            (BASELINE configs[1]: T = 8 x 1024, H = 1024)
+    ("qkv", "fwd", 8192, 3072, 1024, "bias"), ("dense", "fwd", 8192, 1024, 1024, "bias+res"), ("h4h", "fwd", 8192, 4096, 1024, "gelu"),
+    ("4hh", "fwd", 8192, 1024, 4096, "bias+res"), ("qkv", "dgrad", 8192, 3072, 1024, None), ("dense", "dgrad", 8192, 1024, 1024, None),
+    ("h4h", "dgrad", 8192, 4096, 1024, None), ("4hh", "dgrad", 8192, 1024, 4096, "dgelu"), ("4hh", "dgrad", 8192, 1024, 4096, "mul"),
+    ("qkv", "wgrad", 8192, 3072, 1024, None), ("dense", "wgrad", 8192, 1024, 1024, None), ("h4h", "wgrad", 8192, 4096, 1024, None),
+    ("4hh", "wgrad", 8192, 1024, 4096, None), ("lm_head", "fwd", 8192, 250880, 1024, None), ("lm_head", "dgrad", 8192, 250880, 1024, None),
+    ("lm_head", "wgrad", 8192, 250880, 1024, None)]
+
+
+@pytest.mark.parametrize("name,kind,T,Nout,Kin,epi", STEP_GEMMS, ids=lambda v: str(v))
+def test_gemm_at_the_step_shapes_sampled_vs_fp64(name, kind, T, Nout, Kin, epi):
+    """Every GEMM of the Bloom-560M step (modeling_bloom.py:79,121,256,267,220 and their autograd) at its REAL size — T = 8192 rows,
+    K in {1024, 3072, 4096, 8192, 250 880}: the persistent ping-pong launches, their steady K-loop, the split-K and unsplit
+    weight-gradient tiles, the logits-sized non-temporal epilogue — element by element on a 64 x 64 sample of the output (rows and
+    columns drawn from every tile row / column region incl. the first and last) against an fp64 CPU product of the bf16-rounded
+    operands.  Bound: bf16 outputs one rounding (2^-8 relative of the value) + fp32 accumulation noise (1e-5 of sqrt(K) * sigma^2);
+    fp32 outputs (weight gradients) 2e-5 of the row scale."""
+    o, L = ops(), lib()
+    dev_g = torch.Generator(device=DEV).manual_seed(sum(map(ord, name + kind)) * 7919 + Nout)
+    bfr = lambda *sh, sc=0.5: (torch.randn(*sh, generator=dev_g, device=DEV) * sc).to(torch.bfloat16)   # noqa: E731
+    cpu_g = torch.Generator().manual_seed(7)
+
+    def pick(n, k=64):
+        edge = torch.tensor([0, 1, n - 2, n - 1, 255, 256, n // 2 - 1, n // 2])
+        return torch.unique(torch.cat([edge.clamp(0, n - 1), torch.randint(0, n, (k - len(edge),), generator=cpu_g)]))
+    d64 = lambda t: t.double().cpu()                                                                      # noqa: E731
+    if kind == "fwd":
+        x, w = bfr(T, Kin), bfr(Nout, Kin)
+        bias = torch.randn(Nout, generator=dev_g, device=DEV) if epi else None
+        res = bfr(T, Nout) if epi == "bias+res" else None
+        u = torch.empty(T, Nout, dtype=torch.bfloat16, device=DEV) if epi == "gelu" else None
+        y = o.linear_fwd(x, w, bias, residual=res, epilogue=L.EPI_GELU if epi == "gelu" else L.EPI_NONE, aux_out=u)
+        r, c = pick(T), pick(Nout)
+        ref = d64(x[r.to(DEV)]) @ d64(w[c.to(DEV)]).t()
+        if bias is not None:
+            ref = ref + d64(bias[c.to(DEV)])
+        if epi == "gelu":
+            got_u = d64(u[r.to(DEV)][:, c.to(DEV)])
+            assert float(((got_u - ref).abs() / (ref.abs() + 1)).max()) < 6e-3
+            ref = R.gelu_tanh(got_u)                                             # the activation sees the stored pre-activation
+        if res is not None:
+            ref = ref + d64(res[r.to(DEV)][:, c.to(DEV)])
+        got = d64(y[r.to(DEV)][:, c.to(DEV)])
+        scale, rt = math.sqrt(Kin) * 0.25, 4.5e-3
+    elif kind == "dgrad":
+        dy, w = bfr(T, Nout), bfr(Nout, Kin, sc=0.5 if Nout < 65536 else 0.05)
+        aux = bfr(T, Kin) if epi in ("dgelu", "mul") else None
+        dx = o.linear_dgrad(dy, w, epilogue={"dgelu": L.EPI_DGELU, "mul": L.EPI_MUL}.get(epi, L.EPI_NONE), aux_in=aux)
+        r, c = pick(T), pick(Kin)
+        ref = d64(dy[r.to(DEV)]) @ d64(w[:, c.to(DEV)])
+        sig = 0.25 if Nout < 65536 else 0.025
+        scale, rt = math.sqrt(Nout) * sig, 4.5e-3
+        if aux is not None:
+            a = d64(aux[r.to(DEV)][:, c.to(DEV)])
+            ref = R.gelu_tanh_bwd(ref, a) if epi == "dgelu" else ref * a
+            rt = 6e-3                                                            # + the v_exp / v_rcp form of the derivative
+        got = d64(dx[r.to(DEV)][:, c.to(DEV)])
+    else:
+        dy, x = bfr(T, Nout), bfr(T, Kin)
+        dw = o.linear_wgrad(dy, x)
+        assert dw.dtype == torch.float32 and dw.shape == (Nout, Kin)
+        r, c = pick(Nout), pick(Kin)
+        ref = d64(dy[:, r.to(DEV)]).t() @ d64(x[:, c.to(DEV)])
+        got = d64(dw[r.to(DEV)][:, c.to(DEV)])
+        scale, rt = math.sqrt(T) * 0.25, 2e-5
+    err = (got - ref).abs()
+    bound = rt * ref.abs() + 2e-5 * scale
+    if os.environ.get("CTMI_TEST_VERBOSE"):
+        print(f"[step gemm] {name} {kind} {epi}: max err {float(err.max()):.3e}, max err/bound {float((err / bound).max()):.3f}, scale {scale:.2f}")
+    assert torch.isfinite(got).all()
+    assert bool((err <= bound).all()), f"{name} {kind}: {int((err > bound).sum())}/{err.numel()} sampled elements off, worst {float(err.max()):.3e} (bound there {float(bound.flatten()[err.argmax()]):.3e})"
 
 
 @pytest.mark.parametrize("env", [{"CTMI_GEMM_TILE": "0"}, {"CTMI_GEMM_TILE": "1"}, {"CTMI_GEMM_TILE": "2"}, {"CTMI_GEMM_TILE": "3"},
