@@ -78,8 +78,9 @@ PROTOTYPES = {
     "ctmi_embed_bwd": (i32, [vp, vp, vp, i64, i64, i64, i32, f32, vp]),
     "ctmi_ce_fwd": (i32, [vp, i64, vp, vp, vp, vp, i64, i64, i64, i64, i64, i32, i64, i32, vp]),
     "ctmi_ce_bwd": (i32, [vp, i64, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i32, vp]),
-    "ctmi_ce_fwd_bwd": (i32, [vp, i64, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i32, i64, i32, vp]),
-    "ctmi_scale_if": (i32, [vp, i64, i64, i64, vp, i32, vp]),
+    "ctmi_ce_fwd_bwd": (i32, [vp, i64, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i32, i64, f32, vp, i32, vp]),
+    "ctmi_scale_if": (i32, [vp, i64, i64, i64, vp, f32, vp, i32, vp]),
+    "ctmi_scale_if_passes": (i64, []),
     "ctmi_reduce_jobs": (i32, [C.POINTER(ReduceJob), i32, vp]),
     "ctmi_bloom_block_layout": (i64, [i64, i64, i64, i64, i32, C.POINTER(i64)]),
     "ctmi_bloom_block_fwd": (i32, [C.POINTER(BloomBlock), vp]),

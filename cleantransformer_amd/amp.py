@@ -65,6 +65,11 @@ class GradScaler():
     def _ensure(self, device):
         if self._state is None:
             self._state = torch.tensor([self._init_scale, 0.0, 0.0], dtype=torch.float32, device=device)
+            if self._state.is_cuda:
+                # from the next forward on, the fused loss folds this scale into dlogits (ops.set_expected_loss_grad): the backward of
+                # scaler.scale(loss) then finds its upstream gradient already applied and skips the rescale pass over [T,V]
+                from . import ops
+                ops.set_expected_loss_grad(scale=self._state[0:1])
         return self._state
 
     def is_enabled(self):

@@ -1011,7 +1011,8 @@ template <typename T>
 __global__ __launch_bounds__(1024) void ce_fused_k(const T* __restrict__ logits, int64_t ld, const int64_t* __restrict__ labels,
                                                    float* __restrict__ row_lse, float* __restrict__ row_loss,
                                                    const float* __restrict__ loss_out, T* __restrict__ dlogits, int64_t ldd,
-                                                   int64_t C, int64_t seq, int64_t shift, int64_t ignore) {
+                                                   int64_t C, int64_t seq, int64_t shift, int64_t ignore,
+                                                   float gfac, const float* __restrict__ gdev) {
     constexpr int VEC = 16 / sizeof(T);
     constexpr int NT = 1024, UNR = 4;
     __shared__ float sm_m[16], sm_s[16];
@@ -1091,7 +1092,9 @@ __global__ __launch_bounds__(1024) void ce_fused_k(const T* __restrict__ logits,
         row_loss[row] = live ? (lse - Cvt<T>::to_f(x[t])) : -1.0f;       // -1 marks "no loss"
     }
     // ---- pass 2: gradient, back to front (the tail of the row is the freshest in the caches)
-    const float coef = live ? loss_out[1] : 0.f;
+    // the upstream gradient the caller EXPECTS (1/accumulation steps, a loss scale: gfac * gdev[0]) is folded in here, in fp32, before the one
+    // rounding to the storage type; the backward then rescales only if the actual upstream gradient differs (ctmi_scale_if)
+    const float coef = live ? loss_out[1] * (gdev != nullptr ? gfac * gdev[0] : gfac) : 0.f;
     for (int64_t c = Cv + threadIdx.x; c < C; c += NT)
         d[c] = Cvt<T>::from_f(live ? (__expf(Cvt<T>::to_f(x[c]) - lse) - ((c == t) ? 1.0f : 0.0f)) * coef : 0.f);
     if (!live) {
@@ -1126,7 +1129,8 @@ __global__ __launch_bounds__(1024) void ce_fused_k(const T* __restrict__ logits,
 
 extern "C" int ctmi_ce_fwd_bwd(const void* logits, int64_t ld, const int64_t* labels, float* row_lse, float* row_loss,
                                float* loss_out, void* dlogits, int64_t ldd, int64_t N, int64_t C, int64_t seq, int64_t shift,
-                               int64_t ignore_index, int denom_mode, int64_t denom_rows, int dtype, void* stream) {
+                               int64_t ignore_index, int denom_mode, int64_t denom_rows, float grad_factor, const float* grad_factor_dev,
+                               int dtype, void* stream) {
     ProfScope prof__(CTMI_PROF_LOSS, as_stream(stream));
     CTMI_REQUIRE(logits && labels && row_lse && row_loss && loss_out && dlogits, "ce_fwd_bwd: null pointer");
     CTMI_REQUIRE(N > 0 && C > 0 && seq > 0 && N % seq == 0 && shift >= 0 && ld >= C && ldd >= C, "ce_fwd_bwd: bad shape N=%lld C=%lld seq=%lld", (long long)N, (long long)C, (long long)seq);
@@ -1141,11 +1145,11 @@ extern "C" int ctmi_ce_fwd_bwd(const void* logits, int64_t ld, const int64_t* la
     if (dtype == CTMI_F32) {
         auto kern = &ce_fused_k<float>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hold);
-        hipLaunchKernelGGL(kern, dim3((unsigned)N), dim3(1024), lds_hold, st, (const float*)logits, ld, labels, row_lse, row_loss, loss_out, (float*)dlogits, ldd, C, seq, shift, ignore_index);
+        hipLaunchKernelGGL(kern, dim3((unsigned)N), dim3(1024), lds_hold, st, (const float*)logits, ld, labels, row_lse, row_loss, loss_out, (float*)dlogits, ldd, C, seq, shift, ignore_index, grad_factor, grad_factor_dev);
     } else {
         auto kern = &ce_fused_k<bf16_t>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hold);
-        hipLaunchKernelGGL(kern, dim3((unsigned)N), dim3(1024), lds_hold, st, (const bf16_t*)logits, ld, labels, row_lse, row_loss, loss_out, (bf16_t*)dlogits, ldd, C, seq, shift, ignore_index);
+        hipLaunchKernelGGL(kern, dim3((unsigned)N), dim3(1024), lds_hold, st, (const bf16_t*)logits, ld, labels, row_lse, row_loss, loss_out, (bf16_t*)dlogits, ldd, C, seq, shift, ignore_index, grad_factor, grad_factor_dev);
     }
     CTMI_CHECK_LAUNCH("ce_fused");
     hipLaunchKernelGGL(ce_finalize_k, dim3(1), dim3(1024), 0, st, row_loss, loss_out, N, denom_mode, denom_rows);
@@ -1153,24 +1157,36 @@ extern "C" int ctmi_ce_fwd_bwd(const void* logits, int64_t ld, const int64_t* la
     return CTMI_OK;
 }
 
-// x *= s[0] unless s[0] == 1 exactly (then every workgroup returns after one scalar load): the backward of the fused loss, whose
-// gradient was written for an upstream gradient of 1.
+// x *= s[0] / (applied * applied_dev[0]) unless that ratio is exactly 1 (then every workgroup returns after two scalar loads): the backward of
+// the fused loss, whose gradient was written for the EXPECTED upstream gradient applied * applied_dev[0] (ctmi_ce_fwd_bwd's grad_factor pair;
+// 1 by default).  g_scale_if_passes counts the calls that really rescaled (tests assert "no second pass over [T,V]" with it).
+static __device__ unsigned long long g_scale_if_passes;
 template <typename T>
-__global__ __launch_bounds__(256) void scale_if_k(T* __restrict__ x, int64_t ld, int64_t rows, int64_t cols, const float* __restrict__ sp) {
-    const float s = sp[0];
-    if (s == 1.0f) return;
+__global__ __launch_bounds__(256) void scale_if_k(T* __restrict__ x, int64_t ld, int64_t rows, int64_t cols, const float* __restrict__ sp,
+                                                  float applied, const float* __restrict__ applied_dev) {
+    const float want = sp[0], have = applied_dev != nullptr ? applied * applied_dev[0] : applied;
+    if (want == have) return;
+    const float s = want / have;
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_scale_if_passes, 1ULL);
     for (int64_t r = blockIdx.x; r < rows; r += gridDim.x)
         for (int64_t c = threadIdx.x; c < cols; c += 256) x[r * ld + c] = Cvt<T>::from_f(Cvt<T>::to_f(x[r * ld + c]) * s);
 }
-extern "C" int ctmi_scale_if(void* x, int64_t ld, int64_t rows, int64_t cols, const float* s_dev, int dtype, void* stream) {
+extern "C" int ctmi_scale_if(void* x, int64_t ld, int64_t rows, int64_t cols, const float* s_dev, float applied, const float* applied_dev,
+                             int dtype, void* stream) {
     ProfScope prof__(CTMI_PROF_LOSS, as_stream(stream));
     CTMI_REQUIRE(x && s_dev && rows > 0 && cols > 0 && ld >= cols, "scale_if: bad args");
+    CTMI_REQUIRE(applied != 0.f, "scale_if: the factor already applied must not be 0");
     const unsigned grid = (unsigned)std::min<int64_t>(rows, 4096);
-    if (dtype == CTMI_F32) hipLaunchKernelGGL((scale_if_k<float>), dim3(grid), dim3(256), 0, as_stream(stream), (float*)x, ld, rows, cols, s_dev);
-    else if (dtype == CTMI_BF16) hipLaunchKernelGGL((scale_if_k<bf16_t>), dim3(grid), dim3(256), 0, as_stream(stream), (bf16_t*)x, ld, rows, cols, s_dev);
+    if (dtype == CTMI_F32) hipLaunchKernelGGL((scale_if_k<float>), dim3(grid), dim3(256), 0, as_stream(stream), (float*)x, ld, rows, cols, s_dev, applied, applied_dev);
+    else if (dtype == CTMI_BF16) hipLaunchKernelGGL((scale_if_k<bf16_t>), dim3(grid), dim3(256), 0, as_stream(stream), (bf16_t*)x, ld, rows, cols, s_dev, applied, applied_dev);
     else { ctmi_set_error("scale_if: unsupported dtype %d", dtype); return CTMI_ERR_UNSUPPORTED; }
     CTMI_CHECK_LAUNCH("scale_if");
     return CTMI_OK;
+}
+extern "C" int64_t ctmi_scale_if_passes(void) {
+    unsigned long long v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_scale_if_passes), sizeof(v), 0, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int64_t)v;
 }
 
 // ---- probability targets (the second branch of loss.py:43-46): loss = -sum_{n,c} t[n,c] * log_softmax(x)[n,c]

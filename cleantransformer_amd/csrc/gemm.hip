@@ -93,6 +93,27 @@ constexpr int glds_patch_bytes(bool pp, int wm, bool xlane = false) { return (pp
 #ifndef CTMI_PP_PRIO
 #define CTMI_PP_PRIO 0
 #endif
+// Side-input tile through LDS (round 4; r3 verdict item 2).  The epilogues that read a second [M,N] operand — the activation-
+// derivative input of the 4h->h data gradient (DGELU / MUL / DRELU) and the residual rows of the [T,H]-output forwards — fetched it with
+// global loads when the epilogue started: 64 KiB per 128x256 tile that every CU asks for at the same moment, queued behind the LDS-DMA
+// pieces of the next tile's first stages (vector memory returns in order) — ~12 000 cycles per tile, 119.8 us for a launch whose plain form
+// takes 68.  Here the side tile is a THIRD LDS-DMA operand: every wave issues one 1-KiB piece of it (two tile rows) every third K-step
+// (K-steps 1, 4, ..., 22 of the tile it belongs to — after both row groups have left the previous tile's epilogue, so one 64 KiB buffer
+// serves all tiles), and the epilogue reads it with ds_read_b128 (16-byte chunks XOR-swizzled with the row, conflict-free).  The fetch is
+// spread over ~20 000 cycles of K-loop instead of stalling the epilogue.  Costs the whole 160 KiB of LDS (96 ring + 64 side) for these
+// launches: no co-resident side-stream workgroup while they run.  Tiles with fewer than 32 K-steps or at a matrix edge keep the global loads.
+// MEASURED, NOT ADOPTED (profiles/r04_side_lds.txt, same box, interleaved, both arms with the K-loop wait fix): DGELU data gradient 112-114 us
+// against 96-97 with the register prefetch below (plain: 69), MUL 103-106 vs 94, residual forwards equal, training step 40.1-40.3 vs 39.3-39.4 ms —
+// also in the first version, whose pieces had one K-step instead of three to land (107 vs 92 us).  With the K-loop no longer drained every step
+// the epilogue's own loads are not what these kernels wait for any more; 64 KiB more LDS and 8 more DMA pieces per wave and tile cost more
+// than they hide.  Default 0; the code stays for the next attempt (a side tile in REGISTERS needs 32 VGPRs the 128-row tile has).
+#ifndef CTMI_PP_SIDE_LDS
+#define CTMI_PP_SIDE_LDS 0
+#endif
+constexpr bool glds_side_lds(bool pp, int wm, int epi, bool res) {
+    return CTMI_PP_SIDE_LDS && pp && wm == 4 && !CTMI_EPI_SHUFFLE && CTMI_PP128_RING == 4 &&
+           (epi == CTMI_EPI_DGELU || epi == CTMI_EPI_DRELU || epi == CTMI_EPI_MUL || res);
+}
 
 
 template <typename T> struct Tile;
@@ -508,6 +529,9 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
     constexpr int PA = TA::NINSTR / NW, PB = TB::NINSTR / NW;               // DMA instructions per wave per stage
     constexpr int LOADS = PA + PB;
     static_assert(PP ? (LOADS == 3 || LOADS == 4) : (LOADS == 4 || LOADS == 6), "vmcnt immediates below assume these DMA piece counts");
+    constexpr bool SIDE_LDS = glds_side_lds(PP, WM, EPI, RES);               // side-input tile as a third LDS-DMA operand (see CTMI_PP_SIDE_LDS)
+    constexpr int SIDE_OFF = NST * STAGE;                                     // 64 KiB behind the ring: [128 rows][256 columns] bf16, 512-byte rows
+    static_assert(!SIDE_LDS || (BM == 128 && BN == 256 && NW == 8 && LOADS == 3), "the side-tile schedule is written for the 128x256 ping-pong tile");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
     const int tiles_m = (int)((g.M + BM - 1) / BM);
@@ -613,6 +637,21 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
         if (++ti == nti) { wi += G; if (wi < nwork) setup_issue(); }
     };
 
+    // side-input tile of the output tile being computed: on for interior tiles with >= 32 K-steps (the pieces go out at K-steps 1, 5, .., 29
+    // and have landed two steps after the last of them); wave w's piece i = rows 2*(8w+i), +1 of the tile, lane L -> row 2q + (L>>5),
+    // LDS chunk slot L&31 <- global chunk (L&31) ^ (row&15)
+    bool side_on = false;
+    auto issue_side = [&](int i, const int64_t m0, const int64_t n0) {
+        if constexpr (SIDE_LDS) {
+            constexpr bool AUXS = (EPI == CTMI_EPI_DGELU || EPI == CTMI_EPI_DRELU || EPI == CTMI_EPI_MUL);
+            const T* sp = reinterpret_cast<const T*>(AUXS ? g.aux_in : g.residual);
+            const int q = wid * 8 + i;
+            const int row = 2 * q + (lane_ >> 5);
+            const int c = (lane_ & 31) ^ (row & 15);
+            glds16(sp + (m0 + row) * g.ldc + n0 + c * 8, lds0 + SIDE_OFF + q * 1024);
+        }
+    };
+
     f32x4 acc[WM][4];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
@@ -663,14 +702,26 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
         // instead passes its tile through a private 8 KiB LDS patch as fp32, 32 rows at a time (XOR-swizzled 16-byte
         // chunks, conflict-free both ways), and reads it back with 8 lanes per row: residual / GELU-input / C loads
         // and all stores become 16-byte row-contiguous accesses (8 full 128-byte lines per bf16 store instruction).
-        if (interior && g.vec8) {
+        // Kernels with the cross-lane epilogue take the fast path only in its PLAIN form (no inline residual load, no beta): with the
+        // non-plain variants compiled into the same kernel, hipcc's wait-count pass carried a pending vector-memory event around the
+        // persistent tile loop and put an `s_waitcnt vmcnt(0)` at the head of the STEADY K-LOOP — every K-step drained the whole LDS-DMA
+        // ring, in every 128-row and every XLANE ping-pong kernel (~190 of the step's layer-GEMM launches; found in round 4, see
+        // tools/kernel_isa_scan.py, which now checks every instantiation).  The combinations this excludes (a residual on a kernel that
+        // was not instantiated for it, beta with a bf16 output) do not occur on the training path; they take the guarded epilogue below.
+#ifndef CTMI_PP_FAST_NONPLAIN
+#define CTMI_PP_FAST_NONPLAIN 0     // 1 = rounds 1-3 (non-plain variants of the cross-lane epilogue compiled in): A/B builds, profiles/r04_kloop_vmcnt0.txt
+#endif
+        constexpr bool USE_DIRECT = ((!CTMI_EPI_SHUFFLE && WM == 4) || XLANE) && !CTMI_PP_FAST_NONPLAIN;
+        constexpr bool RES_IN_KERNEL = RES && WM == 4 && !(EPI == CTMI_EPI_DGELU || EPI == CTMI_EPI_DRELU || EPI == CTMI_EPI_MUL);   // == PRE_RES below
+        const bool plain_tile = (RES_IN_KERNEL || R == nullptr) && !g.beta;
+        if (interior && g.vec8 && (!USE_DIRECT || plain_tile)) {
             unsigned char* scr = smem_raw + NST * STAGE + wc * 8192;          // the two row groups never overlap in time
             const int64_t mw = m0 + wr * (WM * 16), nw = n0 + wc * 64;
-            f32x4 bias4[4];
-            if (g.bias != nullptr) {
+            // (round 4: in the cross-lane epilogue the bias switch is a compile-time variant too, with the loads inside the variant that uses them)
+            auto load_bias4 = [&](f32x4 (&b4)[4]) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) bias4[j] = *reinterpret_cast<const f32x4*>(g.bias + nw + j * 16 + (lane >> 4) * 4);
-            }
+                for (int j = 0; j < 4; ++j) b4[j] = *reinterpret_cast<const f32x4*>(g.bias + nw + j * 16 + (lane >> 4) * 4);
+            };
             // the side input of a pass (GELU-derivative input, or the residual rows when the kernel is instantiated with
             // RES) is fetched one pass ahead, into the registers the previous pass's accumulators just freed: loaded
             // where it is used, each of the 16 row groups of a tile would expose a full global-load latency
@@ -773,6 +824,8 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
             // compile-time variants: as branches inside it they cut every 8-row step into its own basic block, so hipcc
             // could not batch the LDS reads and each step exposed an LDS round trip plus a 64-bit multiply for its address.
             auto shuffle = [&](auto plain_c, auto nt_flag) {
+                f32x4 bias4[4];
+                if (g.bias != nullptr) load_bias4(bias4);
                 uint4 pre[2][PRE ? 4 : 1];
                 auto prefetch = [&](int p, int slot) {
                     if constexpr (PRE) {
@@ -820,15 +873,27 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
             // leaves every lane with 8 consecutive columns of its row (lane group q: columns 32*jp + 16*(q&1) + 8*(q>>1))
             // — 16-byte bf16 stores / side-input loads, 64 contiguous bytes per row and instruction, with no LDS round
             // trip (4 swaps per 8 values instead of 2 ds_write_b128 + 2 ds_read_b128 and their waits).
-            auto direct = [&](auto plain_c, auto nt_flag) {
+            auto direct = [&](auto plain_c, auto nt_flag, auto bias_c) {
+                constexpr bool BIAS = decltype(bias_c)::value;
+                f32x4 bias4[4];
+                if constexpr (BIAS) load_bias4(bias4);
                 const int q = lane >> 4;
                 const int64_t offL = (mw + (lane & 15)) * g.ldc + nw + 16 * (q & 1) + 8 * (q >> 1);
                 const int64_t row16 = 16 * g.ldc;
                 uint4 pre[2][PRE ? 4 : 1];
+                // side tile in LDS (SIDE_LDS, this tile's side_on): row wr*64 + 16 i + (lane&15), chunk wc*8 + 4 jp + 2 (q&1) + (q>>1), stored at
+                // chunk ^ (row & 15): two lane-constant addresses (jp = 0 / 1) + an immediate per i
+                const unsigned char* sl0 = smem_raw + SIDE_OFF + (wr * 64 + (lane & 15)) * 512 + (((wc * 8 + 2 * (q & 1) + (q >> 1)) ^ (lane & 15)) << 4);
+                const unsigned char* sl1 = smem_raw + SIDE_OFF + (wr * 64 + (lane & 15)) * 512 + (((wc * 8 + 4 + 2 * (q & 1) + (q >> 1)) ^ (lane & 15)) << 4);
                 auto prefetch = [&](int p, int slot) {
                     if constexpr (PRE) {
+                        if (SIDE_LDS && side_on) {
 #pragma unroll
-                        for (int it = 0; it < 4; ++it) pre[slot][it] = *reinterpret_cast<const uint4*>(side + offL + (p * 2 + (it >> 1)) * row16 + 32 * (it & 1));
+                            for (int it = 0; it < 4; ++it) pre[slot][it] = *reinterpret_cast<const uint4*>(((it & 1) ? sl1 : sl0) + (p * 2 + (it >> 1)) * (16 * 512));
+                        } else {
+#pragma unroll
+                            for (int it = 0; it < 4; ++it) pre[slot][it] = *reinterpret_cast<const uint4*>(side + offL + (p * 2 + (it >> 1)) * row16 + 32 * (it & 1));
+                        }
                     }
                 };
                 prefetch(0, 0);
@@ -839,7 +904,7 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
                     for (int it = 0; it < 4; ++it) {
                         const int i = p * 2 + (it >> 1), jp = it & 1;
                         f32x4 a = acc[i][2 * jp] * g.alpha, b = acc[i][2 * jp + 1] * g.alpha;
-                        if (g.bias != nullptr) { a += bias4[2 * jp]; b += bias4[2 * jp + 1]; }
+                        if constexpr (BIAS) { a += bias4[2 * jp]; b += bias4[2 * jp + 1]; }
                         // (inline asm, not __builtin_amdgcn_permlane16_swap: in the 256-row instantiations hipcc merged the four
                         // swaps of a register quad into one and replicated its result — caught by the forced-tile parity test.
                         // One statement per quad; the leading s_nop 1 is the "VALU write -> v_permlane read" hazard pad.)
@@ -859,9 +924,18 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
             };
             const bool plain = (PRE_RES || R == nullptr) && !g.beta;
             constexpr bool CAN_NT = sizeof(TO) == 2 && EPI == CTMI_EPI_NONE && !RES;
-            if constexpr ((!CTMI_EPI_SHUFFLE && WM == 4) || XLANE) {
-                if (plain) direct(std::true_type{}, std::integral_constant<bool, CAN_NT>{});
-                else direct(std::false_type{}, std::false_type{});
+            if constexpr (CTMI_PP_FAST_NONPLAIN && ((!CTMI_EPI_SHUFFLE && WM == 4) || XLANE)) {
+                if (g.bias != nullptr) {
+                    if (plain) direct(std::true_type{}, std::integral_constant<bool, CAN_NT>{}, std::true_type{});
+                    else direct(std::false_type{}, std::false_type{}, std::true_type{});
+                } else {
+                    if (plain) direct(std::true_type{}, std::integral_constant<bool, CAN_NT>{}, std::false_type{});
+                    else direct(std::false_type{}, std::false_type{}, std::false_type{});
+                }
+            } else if constexpr (USE_DIRECT) {
+                static_assert(RES_IN_KERNEL == PRE_RES, "the plain test in front of the fast path must match the variant compiled here");
+                if (g.bias != nullptr) direct(std::true_type{}, std::integral_constant<bool, CAN_NT>{}, std::true_type{});
+                else direct(std::true_type{}, std::integral_constant<bool, CAN_NT>{}, std::false_type{});
             } else {
                 if (plain) shuffle(std::true_type{}, std::integral_constant<bool, CAN_NT>{});
                 else shuffle(std::false_type{}, std::false_type{});
@@ -1012,6 +1086,14 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
         int64_t m0, n0; int split;
         decode(cw, m0, n0, split);
         ntc = (int)((min(g.K, (int64_t)(split + 1) * g.k_per_split) - (int64_t)split * g.k_per_split) / BK);
+        int snext = 1, sidx = 0, slast = -8;                                     // next K-step that issues a side piece, pieces issued for this tile, step of the newest
+        auto arm_side = [&]() {
+            if constexpr (SIDE_LDS) {
+                side_on = g.vec_c && g.vec8 && (m0 + BM <= g.M) && (n0 + BN <= g.N) && ntc >= 32 && g.splits == 1 && !GEMM_DBG(g);
+                snext = 1; sidx = 0; slast = -8;
+            }
+        };
+        arm_side();
         for (;;) {
             bool tile_done = false;
             if constexpr (CTMI_PP_UNROLL && NST == 4 && !CTMI_PP_SPLIT_DMA && !CTMI_GEMM_TIMING) {
@@ -1057,6 +1139,7 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
             if constexpr (CTMI_PP_STEADY && !CTMI_PP_SPLIT_DMA && !CTMI_GEMM_TIMING) {
                 if (inflight == NST - 1 && wi < nwork && !GEMM_DBG(g)) {
                     const int nsteady = min(ntc - tc, nti - ti);                  // >= 1 on both sides here
+                    int sc = tc;                                                  // K-step of the tile (side-tile schedule)
 #pragma unroll 1
                     for (int n = nsteady; n > 0; --n) {
                         const unsigned char* as = smem_raw + AOFF + rd * TA::BYTES;
@@ -1068,7 +1151,20 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
 #pragma unroll
                         for (int i = 0; i < WM; ++i) af[i] = TA::frag(as, wr * (WM * 16) + i * 16, lane);
                         if constexpr (!CTMI_PP_DMA_FIRST) issue_stage(wrb);
-                        wait_stages(NST - 2);
+                        bool swin = false;
+                        if constexpr (SIDE_LDS) {
+                            // AFTER the stage: the piece is then younger than the stage needed three steps from now, so (vector memory
+                            // returns in order) it has the same three K-steps to land as a ring stage.  One piece every third step, steps
+                            // 1, 4, .., 22: while the newest piece is at most two steps old it sits among the operations allowed to stay in
+                            // flight (two stages of three pieces + it = 7; pieces are >= 3 steps apart, so never two); the last one has landed
+                            // by step 25.  (Issued BEFORE the stage — the
+                            // first version — a piece had to land within ONE step: the kernel was 15 % slower than the register prefetch.)
+                            if (side_on && sc >= snext && sidx < 8) { issue_side(sidx, m0, n0); ++sidx; snext = sc + 3; slast = sc; }
+                            swin = sc - slast <= 2;                               // a side piece issued at this or one of the two previous steps
+                            ++sc;
+                        }
+                        if (SIDE_LDS && swin) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+                        else wait_stages(NST - 2);
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         __builtin_amdgcn_sched_barrier(0);
                         __builtin_amdgcn_s_barrier();
@@ -1122,7 +1218,11 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
                     issue_stage(wrb);
                     stage_issued(); ++inflight; wrb = wrb == NST - 1 ? 0 : wrb + 1;
                 }
+                if constexpr (SIDE_LDS) {
+                    if (side_on && tc >= snext && sidx < 8) { issue_side(sidx, m0, n0); ++sidx; snext = tc + 3; slast = tc; }
+                }
                 PH_TICK(ph_issue);
+                // (generic steps ignore the side piece in their count: the plain wait is merely stricter by that one piece — loads return in order)
                 wait_stages(inflight - 2);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1167,6 +1267,7 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
             decode(cw, m0, n0, split);
             ntc = (int)((min(g.K, (int64_t)(split + 1) * g.k_per_split) - (int64_t)split * g.k_per_split) / BK);
             tc = 0;
+            arm_side();
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -1270,7 +1371,8 @@ static int reserved_cus();
 template <typename TO, bool AK, bool BKM, int EPI, int WM, int WGN, bool PP = false, bool RES = false, bool XLANE = false>
 static void glds_launch(GemmArgs& g, hipStream_t st) {
     constexpr int BM = WM * 32, BN = WGN * 64;
-    const size_t lds = glds_ring(PP, WM, XLANE) * (size_t)(GTile<AK, BM>::BYTES + GTile<BKM, BN>::BYTES) + glds_patch_bytes(PP, WM, XLANE);
+    const size_t lds = glds_ring(PP, WM, XLANE) * (size_t)(GTile<AK, BM>::BYTES + GTile<BKM, BN>::BYTES) + glds_patch_bytes(PP, WM, XLANE) +
+                       (glds_side_lds(PP, WM, EPI, RES) ? 65536 : 0);
     const int64_t nwork = cdiv64(g.M, BM) * cdiv64(g.N, BN) * g.splits;
     // persistent launch: one resident workgroup per occupancy slot (256 CUs x workgroups that fit a CU's 160 KiB LDS),
     // each walking work items bid, bid+G, ... with its DMA stream prefetching across item boundaries
@@ -1344,6 +1446,14 @@ extern "C" int ctmi_get_launch_policy(int* shared, int* reserve_cus) {
 #ifndef CTMI_WGRAD_ITEMS
 #define CTMI_WGRAD_ITEMS 256     // (same-box A/B vs 512: -0.15 ms per step — half the fp32 slab traffic) split-K target of the layer weight gradients: work items (tiles x splits) to aim for
 #endif
+// smallest number of 256x256 output tiles for which a forward / data-gradient GEMM takes the 256-row ping-pong tile (below: 128x256 if
+// that fills the chip).  350 since round 1 (384 = the QKV forward: 1.5 rounds of 256 CUs on tile 3, 3 full rounds of 768 on tile 4);
+// CTMI_TILE3_MIN overrides it for sweeps — every rule of rounds 1-3 was measured with the K-loop drain of the cross-lane kernels in place.
+static int64_t tile3_min() {
+    static int64_t v = -1;
+    if (v < 0) { const char* e = getenv("CTMI_TILE3_MIN"); v = e ? std::max(1, atoi(e)) : 350; }
+    return v;
+}
 static void pick_tile(int64_t M, int64_t N, int64_t K, bool wgrad, bool bkm, int epi, int max_splits, int& tile, int& splits) {
     static int force = -2, force_split = -2;
     if (force == -2) { const char* e = getenv("CTMI_GEMM_TILE"); force = e ? atoi(e) : -1; }
@@ -1389,7 +1499,7 @@ static void pick_tile(int64_t M, int64_t N, int64_t K, bool wgrad, bool bkm, int
             while (splits < max_splits && tiles * splits < items && K / (splits * 2) >= 1024) splits *= 2;
         }
     } else if (K >= 32768 && max_splits >= 2 && t2 * 2 >= 192) { tile = 3; splits = 2; }
-    else if (t2 >= 350) tile = 3;
+    else if (t2 >= tile3_min()) tile = 3;
     else if (t4 >= 256 && (CTMI_TILE_RULES_R3 || !bkm || K <= 1024)) tile = 4;                                  // (round 3: also K-major B with long K — 919 vs 861 TF/s on the QKV data gradient)
     else if (t1 >= 700) tile = 1;
     else tile = 0;
@@ -1599,3 +1709,12 @@ extern "C" int ctmi_gemm(const void* A, int64_t lda, int a_kmajor, const void* B
     return gemm_dispatch_bf16(g, a_kmajor, b_kmajor, epilogue, out_f32, fast, as_stream(stream));
 }
 #endif  // CTMI_GEMM_HAS(0)
+
+// -DCTMI_GEMM_PART=9 (tools only): nothing but ONE explicit instantiation, chosen with -DCTMI_ONE_KERNEL="...": a seconds-long compile for
+// reading the ISA of a single kernel (tools/kernel_isa_scan.py)
+#if CTMI_GEMM_PART == 9
+#ifndef CTMI_ONE_KERNEL
+#define CTMI_ONE_KERNEL bf16_t, false, true, 0, 4, 4, true, false, false
+#endif
+template __global__ void gemm_glds_kernel<CTMI_ONE_KERNEL>(GemmArgs);
+#endif

@@ -398,8 +398,12 @@ class ShiftedCrossEntropyFn(torch.autograd.Function):
         ctx.shape = (B, S, V)
         ctx.fused = bool(_FUSED_CE and ctx.needs_input_grad[0] and ops.ce_fused_ok(l2))
         if ctx.fused:
-            loss_out, _, dl = ops.ce_fwd_bwd(l2, lab, seq=S, shift=1, ignore_index=-100, denom_mode=0)
-            ctx.dl, ctx.used = dl, False
+            # the upstream gradient the loop announced (1 / accumulation steps, a GradScaler's device scale; 1 otherwise) rides in this pass
+            fac, fdev = ops.current_expected_loss_grad()
+            if fdev is not None and fdev.device != l2.device:
+                fdev = None
+            loss_out, _, dl = ops.ce_fwd_bwd(l2, lab, seq=S, shift=1, ignore_index=-100, denom_mode=0, grad_factor=fac, grad_factor_dev=fdev)
+            ctx.dl, ctx.used, ctx.applied = dl, False, (fac, fdev)
             return loss_out[0].clone()
         loss_out, row_lse = ops.ce_fwd(l2, lab, seq=S, shift=1, ignore_index=-100, denom_mode=0)
         ctx.save_for_backward(l2, lab, row_lse, loss_out)
@@ -415,7 +419,7 @@ class ShiftedCrossEntropyFn(torch.autograd.Function):
                 raise RuntimeError("the fused loss node keeps ONE gradient buffer and rescales it in place: it cannot be "
                                    "backpropagated twice (set CTMI_FUSED_CE=0 for retain_graph workflows)")
             ctx.used = True
-            d = ops.scale_if_(ctx.dl, g)                                  # no-op on the device for loss.backward() (gout == 1)
+            d = ops.scale_if_(ctx.dl, g, *ctx.applied)                    # no-op on the device when gout is what the forward was told to expect
             ctx.dl = None
             return d.view(B, S, V), None
         l2, lab, row_lse, loss_out = ctx.saved_tensors

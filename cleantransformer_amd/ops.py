@@ -6,6 +6,7 @@ library or a failing launch raises (there is no eager/CPU fallback).
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import math
 import threading
@@ -315,9 +316,46 @@ def ce_soft_bwd(logits2d: Tensor, target: Tensor, row_lse: Tensor, row_tsum: Ten
     return out
 
 
+# The upstream gradient the training loop is about to send into the loss node, when it is known BEFORE the forward: 1 / accumulation steps
+# (trainer.py:468-504 backpropagates `loss / ga`), the loss scale of a GradScaler (ft_bloom_DDP.py:123-127: a device scalar), or both.
+# The fused loss folds it into dlogits in its one pass (fp32, one rounding); its backward then rescales only if the gradient that actually
+# arrives is a different number.  Process-wide (the training loop is single-threaded on the forward side).
+_EXPECTED_LOSS_GRAD = {"factor": 1.0, "dev": None}
+
+
+def set_expected_loss_grad(factor: Optional[float] = None, scale: Optional[Tensor] = None) -> None:
+    """Persistent form (amp.GradScaler registers its device scale here); `None` leaves a field as it is, `scale=False` clears it."""
+    if factor is not None:
+        if not factor > 0.0:
+            raise ValueError("expected loss gradient factor must be > 0")
+        _EXPECTED_LOSS_GRAD["factor"] = float(factor)
+    if scale is False:
+        _EXPECTED_LOSS_GRAD["dev"] = None
+    elif scale is not None:
+        if scale.numel() != 1 or scale.dtype != torch.float32:
+            raise ValueError("expected loss gradient scale: one fp32 element on the device")
+        _EXPECTED_LOSS_GRAD["dev"] = scale
+
+
+@contextlib.contextmanager
+def expected_loss_grad(factor: float = 1.0):
+    """`with ops.expected_loss_grad(1 / ga): loss = model(...); (loss / ga).backward()` — the Trainer's accumulation micro-steps."""
+    old = _EXPECTED_LOSS_GRAD["factor"]
+    set_expected_loss_grad(factor=factor)
+    try:
+        yield
+    finally:
+        _EXPECTED_LOSS_GRAD["factor"] = old
+
+
+def current_expected_loss_grad():
+    return _EXPECTED_LOSS_GRAD["factor"], _EXPECTED_LOSS_GRAD["dev"]
+
+
 def ce_fwd_bwd(logits2d: Tensor, labels: Tensor, seq: int, shift: int, ignore_index: int = -100, denom_mode: int = 0,
-               denom_rows: int = 0):
-    """Loss and dlogits (for an upstream gradient of 1) in one pass -> loss_out fp32[2], row_lse fp32[N], dlogits [N,C]."""
+               denom_rows: int = 0, grad_factor: float = 1.0, grad_factor_dev: Optional[Tensor] = None):
+    """Loss and dlogits (for the upstream gradient grad_factor * grad_factor_dev[0]; default 1) in one pass -> loss_out fp32[2],
+    row_lse fp32[N], dlogits [N,C]."""
     N, Cn = logits2d.shape
     dev = logits2d.device
     row_lse = torch.empty(N, dtype=torch.float32, device=dev)
@@ -325,8 +363,8 @@ def ce_fwd_bwd(logits2d: Tensor, labels: Tensor, seq: int, shift: int, ignore_in
     loss_out = torch.empty(2, dtype=torch.float32, device=dev)
     dl = torch.empty((N, Cn), dtype=logits2d.dtype, device=dev)
     check(_lib.load().ctmi_ce_fwd_bwd(_p(logits2d), logits2d.stride(0), _p(labels), _p(row_lse), _p(row_loss), _p(loss_out), _p(dl),
-                                      dl.stride(0), N, Cn, seq, shift, ignore_index, denom_mode, denom_rows, dt_code(logits2d.dtype),
-                                      _stream()), "ce_fwd_bwd")
+                                      dl.stride(0), N, Cn, seq, shift, ignore_index, denom_mode, denom_rows, float(grad_factor),
+                                      _p(grad_factor_dev), dt_code(logits2d.dtype), _stream()), "ce_fwd_bwd")
     return loss_out, row_lse, dl
 
 
@@ -337,11 +375,17 @@ def ce_fused_ok(logits2d: Tensor) -> bool:
         and logits2d.data_ptr() % 16 == 0
 
 
-def scale_if_(x2d: Tensor, s_dev: Tensor) -> Tensor:
-    """x2d *= s_dev[0], skipped on the device when the scalar is exactly 1."""
+def scale_if_(x2d: Tensor, s_dev: Tensor, applied: float = 1.0, applied_dev: Optional[Tensor] = None) -> Tensor:
+    """x2d *= s_dev[0] / (applied * applied_dev[0]), skipped on the device when the two are exactly equal."""
     rows, cols = x2d.shape
-    check(_lib.load().ctmi_scale_if(_p(x2d), x2d.stride(0), rows, cols, _p(s_dev), dt_code(x2d.dtype), _stream()), "scale_if")
+    check(_lib.load().ctmi_scale_if(_p(x2d), x2d.stride(0), rows, cols, _p(s_dev), float(applied), _p(applied_dev), dt_code(x2d.dtype),
+                                    _stream()), "scale_if")
     return x2d
+
+
+def scale_if_passes() -> int:
+    """How many scale_if_ calls of this process really rescaled their tensor (include/ctmi355.h ctmi_scale_if_passes; synchronises)."""
+    return int(_lib.load().ctmi_scale_if_passes())
 
 
 # ------------------------------------------------------------------------------------------------ one Bloom block per call

@@ -304,8 +304,11 @@ class Trainer():
     def training_step(self, model, inputs):
         """trainer.py:543-556; the division by gradient_accumulation_steps is accelerate's ``backward`` (:555)."""
         model.train()
-        loss = self.compute_loss(model, self._prepare_inputs(inputs))
         ga = self.args.gradient_accumulation_steps
+        # the fused loss writes dlogits in its forward pass: tell it the upstream gradient this step will send (1/ga), so the backward of
+        # `loss / ga` does not pay a second pass over [T,V] (and bf16 dlogits are rounded once, not twice)
+        with ops.expected_loss_grad(1.0 / ga):
+            loss = self.compute_loss(model, self._prepare_inputs(inputs))
         (loss / ga if ga > 1 else loss).backward()
         return loss.detach() / ga
 

@@ -196,14 +196,20 @@ int ctmi_ce_bwd(const void* logits, int64_t ld, const int64_t* labels, const flo
                 int64_t N, int64_t C, int64_t seq, int64_t shift, int64_t ignore_index, int dtype, void* stream);
 
 /* Training path: loss and dlogits in ONE pass over the logits (the loss forward of modeling_bloom.py:224-230 and the first
- * step of loss.backward()): same arguments and results as ctmi_ce_fwd, plus dlogits written for an upstream gradient of 1
- * (ctmi_ce_bwd with gout = NULL).  Rows must be 16-byte aligned (ld, ldd multiples of 16 bytes). */
+ * step of loss.backward()): same arguments and results as ctmi_ce_fwd, plus dlogits written for the upstream gradient the caller
+ * EXPECTS, grad_factor * (grad_factor_dev ? grad_factor_dev[0] : 1) — 1 for a plain loss.backward(); 1/accumulation_steps for
+ * trainer.py:468-504's `loss / ga`; the loss scale (a device scalar) for ft_bloom_DDP.py:123-127's scaler.scale(loss) — applied in
+ * fp32 before the single rounding to the storage type.  Rows must be 16-byte aligned (ld, ldd multiples of 16 bytes). */
 int ctmi_ce_fwd_bwd(const void* logits, int64_t ld, const int64_t* labels, float* row_lse, float* row_loss,
                     float* loss_out, void* dlogits, int64_t ldd, int64_t N, int64_t C, int64_t seq, int64_t shift,
-                    int64_t ignore_index, int denom_mode, int64_t denom_rows, int dtype, void* stream);
-/* x[rows, cols] (ld) *= s_dev[0], skipped on the device when s_dev[0] == 1: applies the upstream gradient of the loss to a
- * dlogits produced by ctmi_ce_fwd_bwd (autograd of `loss * k`, e.g. GradScaler.scale(loss), ft_bloom_DDP.py:124). */
-int ctmi_scale_if(void* x, int64_t ld, int64_t rows, int64_t cols, const float* s_dev, int dtype, void* stream);
+                    int64_t ignore_index, int denom_mode, int64_t denom_rows, float grad_factor, const float* grad_factor_dev /* device, may be NULL */,
+                    int dtype, void* stream);
+/* The backward of that node: x[rows, cols] (ld) *= s_dev[0] / (applied * applied_dev[0]) where s_dev[0] is the ACTUAL upstream
+ * gradient and (applied, applied_dev) the pair ctmi_ce_fwd_bwd was given; skipped on the device when the two are equal (the
+ * expected case: no second pass over [T,V]).  ctmi_scale_if_passes() = how many calls did rescale (process lifetime; tests). */
+int ctmi_scale_if(void* x, int64_t ld, int64_t rows, int64_t cols, const float* s_dev, float applied, const float* applied_dev /* device, may be NULL */,
+                  int dtype, void* stream);
+int64_t ctmi_scale_if_passes(void);
 
 /* probability targets, the second branch of loss.py:43-46: loss = -sum t * log_softmax(x) (÷ denom_rows for 'mean': denom_mode 1;
  * 'sum': denom_mode 2).  target fp32 [N, C] (ldt).  row_tsum keeps sum_c t[n,c] for the backward:

@@ -379,18 +379,24 @@ def sgd_step(params, grads, bufs, shadows, *, lr, momentum, dampening, weight_de
         p.sub_(lr * gg)
 
 
-def ce_fwd_bwd(logits2d, labels, seq, shift, ignore_index=-100, denom_mode=0, denom_rows=0):
+def ce_fwd_bwd(logits2d, labels, seq, shift, ignore_index=-100, denom_mode=0, denom_rows=0, grad_factor=1.0, grad_factor_dev=None):
     loss_out, lse = ce_fwd(logits2d, labels, seq, shift, ignore_index, denom_mode, denom_rows)
-    return loss_out, lse, ce_bwd(logits2d, labels, lse, loss_out, None, seq, shift, ignore_index)
+    g = torch.tensor([float(grad_factor) * (float(grad_factor_dev[0]) if grad_factor_dev is not None else 1.0)])
+    return loss_out, lse, ce_bwd(logits2d, labels, lse, loss_out, g, seq, shift, ignore_index)
 
 
 def ce_fused_ok(logits2d):
     return logits2d.stride(1) == 1 and logits2d.stride(0) == logits2d.shape[1]
 
 
-def scale_if_(x2d, s_dev):
-    if float(s_dev[0]) != 1.0:
-        x2d.copy_((x2d.float() * s_dev[0]).to(x2d.dtype))
+SCALE_IF_PASSES = [0]
+
+
+def scale_if_(x2d, s_dev, applied=1.0, applied_dev=None):
+    have = float(applied) * (float(applied_dev[0]) if applied_dev is not None else 1.0)
+    if float(s_dev[0]) != have:
+        SCALE_IF_PASSES[0] += 1
+        x2d.copy_((x2d.float() * (float(s_dev[0]) / have)).to(x2d.dtype))
     return x2d
 
 

@@ -135,6 +135,48 @@ def test_fused_loss_node_autograd_scaling_and_double_backward_guard():
         loss2.backward()
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_loss_folds_the_expected_upstream_gradient(dtype):
+    """trainer.py:468-504 backpropagates `loss / ga`, ft_bloom_DDP.py:123-127 `scaler.scale(loss)`: when the loop announces that factor
+    before the forward (ops.expected_loss_grad / ops.set_expected_loss_grad) the fused loss writes dlogits for it in its one pass and the
+    backward does NOT rescale — no second pass over [T,V] (ctmi_scale_if_passes does not move) — and bf16 dlogits equal the fp32 gradient
+    times the factor rounded ONCE.  A gradient that differs from the announcement is still applied correctly (one rescale pass)."""
+    from cleantransformer_amd.models.modeling_bloom import ShiftedCrossEntropyFn
+    o = ops()
+    B, S, V = 2, 16, 1024
+    x0 = rnd(B, S, V, seed=19).to(DEV).to(dtype)
+    lab = torch.randint(0, V, (B, S), generator=torch.Generator().manual_seed(2)).to(DEV)
+    ref = x0.detach().cpu().double().requires_grad_(True)
+    torch.nn.functional.cross_entropy(ref[:, :-1].reshape(-1, V), lab.cpu()[:, 1:].reshape(-1)).backward()
+    g64 = ref.grad                                                                    # d loss / d logits for an upstream gradient of 1
+    scale_dev = torch.full((1,), 1024.0, device=DEV)
+    for fac, sdev, upstream, rescales in ((0.25, None, 0.25, 0), (1.0, scale_dev, 1024.0, 0), (0.5, scale_dev, 512.0, 0), (0.25, None, 1.0, 1)):
+        o.set_expected_loss_grad(factor=1.0, scale=False)
+        if sdev is not None:
+            o.set_expected_loss_grad(scale=sdev)
+        before = o.scale_if_passes()
+        x = x0.clone().requires_grad_(True)
+        with o.expected_loss_grad(fac):
+            loss = ShiftedCrossEntropyFn.apply(x, lab)
+        (loss * upstream).backward()
+        torch.cuda.synchronize()
+        assert o.scale_if_passes() - before == rescales, (fac, sdev is not None, upstream)
+        want = g64 * upstream
+        if dtype == torch.float32:
+            assert relerr(x.grad, want) < 2e-6
+        elif rescales == 0:
+            # one rounding of the fp32 product: the kernel's fp32 softmax differs from fp64 by ~1e-7 relative, so allow the neighbouring
+            # bf16 value where the exact product sits within that of a rounding boundary
+            got, w32 = x.grad.float().cpu(), want.float()
+            exact = w32.to(torch.bfloat16).float()
+            ulp = (exact.abs() * 2.0 ** -7).clamp_min(1e-30)
+            assert float(((got - exact).abs() / ulp).max()) <= 1.0 + 1e-3
+            assert float((got != exact).float().mean()) < 2e-3, float((got != exact).float().mean())
+        else:
+            assert relerr(x.grad, want) < 8e-3
+    o.set_expected_loss_grad(factor=1.0, scale=False)
+
+
 # ------------------------------------------------------------------------------------------------ one block per call
 def _block_inputs(B, S, H, nh, dtype, seed, pad):
     o = ops()

@@ -97,7 +97,10 @@ def test_gradient_accumulation_equals_the_full_batch_step(monkeypatch, tmp_path)
     common = dict(device="cpu", learning_rate=1e-5, weight_decay=0.01, lr_scheduler_type="constant", max_grad_norm=None, logging_steps=1,
                   save_strategy="no")
     a = make(TrainingArguments(output_dir=str(tmp_path / "a"), max_steps=1, gradient_accumulation_steps=2, per_device_train_batch_size=2, **common), halves)
+    passes = emu.SCALE_IF_PASSES[0]
     a.train()
+    # round 4: training_step announces 1/ga to the fused loss, so the backward of `loss / ga` finds its factor already in dlogits
+    assert emu.SCALE_IF_PASSES[0] == passes, "the accumulation micro-steps must not rescale dlogits in a second pass"
     b = make(TrainingArguments(output_dir=str(tmp_path / "b"), max_steps=1, per_device_train_batch_size=4, **common), [full])
     b.train()
     assert abs(a.state.log_history[0]["loss"] - b.state.log_history[0]["loss"]) <= 1.01e-4
