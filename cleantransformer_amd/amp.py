@@ -38,6 +38,8 @@ def autocast(device_type=None, dtype=None, enabled=True, cache_enabled=None):
       * ``autocast()`` with the default dtype (what ft_bloom_DDP.py writes) warns once that the model's compute dtype is used instead
         (bf16 has fp32's exponent range: the GradScaler around it stays exact and never has to back off)."""
     global _warned_default
+    if isinstance(device_type, bool):        # torch.cuda.amp.autocast's first positional argument is `enabled` (torch.autocast's is device_type):
+        enabled, device_type = device_type, None     # autocast(False) must mean "off", not device_type=False (round-3 advisor)
     if enabled:
         if dtype is torch.float16:
             raise NotImplementedError("cleantransformer_amd has no fp16 compute path (bf16 / fp32 MFMA kernels only): use "

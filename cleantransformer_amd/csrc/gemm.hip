@@ -640,6 +640,22 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
     // side-input tile of the output tile being computed: on for interior tiles with >= 32 K-steps (the pieces go out at K-steps 1, 5, .., 29
     // and have landed two steps after the last of them); wave w's piece i = rows 2*(8w+i), +1 of the tile, lane L -> row 2q + (L>>5),
     // LDS chunk slot L&31 <- global chunk (L&31) ^ (row&15)
+    // Early side-input prefetch (round 4; r3 verdict item 2): the activation-derivative input / residual rows of BOTH epilogue passes are
+    // requested when the DMA stream crosses to the next output tile — three K-steps before this tile's epilogue — into the 32 registers the
+    // 128-row tile has to spare, instead of at the start of the epilogue (where they queued behind the next tile's first stages and then paid
+    // a full HBM latency per pass).  Ordinary loads: hipcc tracks them; the counted waits of the K-steps in between allow for them.
+    // MEASURED, NOT ADOPTED (profiles/r04_side_early.txt, same box, interleaved): DGELU data gradient 102-103 us against 97 with the prefetch at
+    // the start of the epilogue, MUL 97-100 vs 97-99, training step 39.54-39.77 vs 39.20-39.33 ms.  Neither WHEN the side tile is requested
+    // (this), nor through WHAT (the LDS variant above), nor its arithmetic (MUL = one multiply costs what dGELU costs) moves the ~27 us over the
+    // plain kernel: 64 MiB more from HBM in a 70 us launch whose 256 workgroups finish their tiles together.  Default 0.
+#ifndef CTMI_PP_SIDE_EARLY
+#define CTMI_PP_SIDE_EARLY 0
+#endif
+    constexpr bool SIDE_EARLY = CTMI_PP_SIDE_EARLY && CTMI_PP_STEADY && !CTMI_PP_SPLIT_DMA && !CTMI_GEMM_TIMING && !SIDE_LDS && PP && WM == 4 && !CTMI_EPI_SHUFFLE &&
+                                LOADS == 3 && ((EPI == CTMI_EPI_DGELU || EPI == CTMI_EPI_DRELU || EPI == CTMI_EPI_MUL) || RES);
+    uint4 sp00, sp01, sp02, sp03, sp10, sp11, sp12, sp13;                      // (eight named values, not an array: as an array captured by the epilogue lambda hipcc kept it in scratch memory)
+    sp00 = sp01 = sp02 = sp03 = sp10 = sp11 = sp12 = sp13 = make_uint4(0u, 0u, 0u, 0u);
+    bool spre_on = false;
     bool side_on = false;
     auto issue_side = [&](int i, const int64_t m0, const int64_t n0) {
         if constexpr (SIDE_LDS) {
@@ -896,10 +912,19 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
                         }
                     }
                 };
-                prefetch(0, 0);
+                bool early = false;
+                if constexpr (SIDE_EARLY && PRE) {
+                    early = spre_on;
+                    if (early) {
+                        pre[0][0] = sp00; pre[0][1] = sp01; pre[0][2] = sp02; pre[0][3] = sp03;
+                        pre[1][0] = sp10; pre[1][1] = sp11; pre[1][2] = sp12; pre[1][3] = sp13;
+                        spre_on = false;
+                    }
+                }
+                if (!early) prefetch(0, 0);
 #pragma unroll
                 for (int p = 0; p < WM / 2; ++p) {
-                    if (p + 1 < WM / 2) prefetch(p + 1, (p + 1) & 1);
+                    if (p + 1 < WM / 2 && !early) prefetch(p + 1, (p + 1) & 1);
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {
                         const int i = p * 2 + (it >> 1), jp = it & 1;
@@ -1086,8 +1111,14 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
         int64_t m0, n0; int split;
         decode(cw, m0, n0, split);
         ntc = (int)((min(g.K, (int64_t)(split + 1) * g.k_per_split) - (int64_t)split * g.k_per_split) / BK);
+        bool early_ok = false;                                                    // this tile's epilogue will take the fast cross-lane path with a side input
         int snext = 1, sidx = 0, slast = -8;                                     // next K-step that issues a side piece, pieces issued for this tile, step of the newest
         auto arm_side = [&]() {
+            if constexpr (SIDE_EARLY) {
+                constexpr bool AUXS = (EPI == CTMI_EPI_DGELU || EPI == CTMI_EPI_DRELU || EPI == CTMI_EPI_MUL);
+                early_ok = g.vec_c && g.vec8 && (m0 + BM <= g.M) && (n0 + BN <= g.N) && g.splits == 1 && !g.beta && (AUXS ? g.residual == nullptr : true) && ntc >= 4;
+                spre_on = false;
+            }
             if constexpr (SIDE_LDS) {
                 side_on = g.vec_c && g.vec8 && (m0 + BM <= g.M) && (n0 + BN <= g.N) && ntc >= 32 && g.splits == 1 && !GEMM_DBG(g);
                 snext = 1; sidx = 0; slast = -8;
@@ -1137,7 +1168,26 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
                 }
             }
             if constexpr (CTMI_PP_STEADY && !CTMI_PP_SPLIT_DMA && !CTMI_GEMM_TIMING) {
-                if (inflight == NST - 1 && wi < nwork && !GEMM_DBG(g)) {
+                // (a loop since round 4: after the DMA stream's switch to the next work item the remaining K-steps of THIS tile run steady too,
+                // in the same pass — the early side-input prefetch below is issued there and consumed by this tile's epilogue further down)
+                while (!tile_done && inflight == NST - 1 && wi < nwork && !GEMM_DBG(g)) {
+                    int spre_steps = 0;                                           // steady steps whose counted wait must allow the 8 prefetch loads
+                    if constexpr (SIDE_EARLY) {
+                        if (!spre_on && early_ok && ntc - tc <= 3) {
+                            constexpr bool AUXS = (EPI == CTMI_EPI_DGELU || EPI == CTMI_EPI_DRELU || EPI == CTMI_EPI_MUL);
+                            const T* sp = reinterpret_cast<const T*>(AUXS ? g.aux_in : g.residual);
+                            int ln = lane_;
+                            asm volatile("" : "+v"(ln));                          // (as in the epilogue: keep this address arithmetic out of the loops above)
+                            const int q = ln >> 4;
+                            const int64_t offL = (m0 + wr * (WM * 16) + (ln & 15)) * g.ldc + n0 + wc * 64 + 16 * (q & 1) + 8 * (q >> 1);
+                            const int64_t row16 = 16 * g.ldc;
+                            auto ld = [&](int pp, int it) { return *reinterpret_cast<const uint4*>(sp + offL + (pp * 2 + (it >> 1)) * row16 + 32 * (it & 1)); };
+                            sp00 = ld(0, 0); sp01 = ld(0, 1); sp02 = ld(0, 2); sp03 = ld(0, 3);
+                            sp10 = ld(1, 0); sp11 = ld(1, 1); sp12 = ld(1, 2); sp13 = ld(1, 3);
+                            spre_on = true;
+                            spre_steps = 2;                                       // the loads are younger than the stage a step waits for during two steps
+                        }
+                    }
                     const int nsteady = min(ntc - tc, nti - ti);                  // >= 1 on both sides here
                     int sc = tc;                                                  // K-step of the tile (side-tile schedule)
 #pragma unroll 1
@@ -1164,6 +1214,7 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
                             ++sc;
                         }
                         if (SIDE_LDS && swin) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+                        else if (SIDE_EARLY && spre_steps > 0) { asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); --spre_steps; }   // 2 stages x 3 pieces + 8 loads
                         else wait_stages(NST - 2);
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         __builtin_amdgcn_sched_barrier(0);

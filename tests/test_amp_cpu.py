@@ -119,6 +119,11 @@ def test_autocast_refuses_fp16_and_accepts_the_implemented_dtypes():
             pass
         with amp.autocast(dtype=torch.float16, enabled=False):
             pass
+        with amp.autocast(False, dtype=torch.float16):        # torch.cuda.amp.autocast(enabled, ...): the first positional argument is `enabled`
+            pass
+    with pytest.raises(NotImplementedError):
+        with amp.autocast(True, dtype=torch.float16):
+            pass
     amp._warned_default = False
     with pytest.warns(UserWarning, match="fp16"):
         with amp.autocast():

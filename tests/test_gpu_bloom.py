@@ -86,6 +86,30 @@ def test_tiny_forward_backward_matches_reference_golden():
     assert abs(gn - TINY["traj"][0, 1]) <= 1e-4 * gn
 
 
+def test_presents_after_backward_and_inplace_on_a_block_output_fail_loudly():
+    """INTEGRATION.md §5 (round-3 advisor): after a differentiated forward the K/V presents are views of the block's activation slab —
+    reading them before backward() works and matches the reference's tensors, reading them for the FIRST time after backward() raises a
+    RuntimeError that says what to do; an in-place op on the hidden states (the output of a custom autograd node) is refused by torch at the op
+    itself ("... is a view and is being modified inplace ... You can fix this by cloning") instead of producing a wrong gradient."""
+    V, H, L, nh, B, S = tiny_shape()
+    m = build(V, H, L, nh)
+    ids, am = T(TINY["ids"]).to(DEV), T(TINY["mask"]).to(DEV)
+    (loss, _, _), presents = m(input_ids=ids, attention_mask=am, labels=ids.clone())
+    k0, v0 = presents[0]                                                        # read before backward: fine, and stays valid afterwards
+    loss.backward()
+    assert k0.shape == (B, nh, S, H // nh) and torch.isfinite(k0).all() and torch.isfinite(v0).all()
+    with pytest.raises(RuntimeError, match="before backward"):
+        presents[1][0]
+    m.zero_grad()
+    (loss, _, hidden), _ = m(input_ids=ids, attention_mask=am, labels=ids.clone())
+    with pytest.raises(RuntimeError, match="inplace"):                          # torch refuses at the op: "... is a view and is being modified inplace"
+        hidden.add_(1.0)
+    loss.backward()                                                             # the graph is intact
+    with torch.no_grad():                                                       # evaluation: eager copies, valid forever
+        (_, _, _), pres = m(input_ids=ids, attention_mask=am, labels=ids.clone())
+    assert pres[L - 1][1].is_contiguous()
+
+
 @pytest.mark.parametrize("which", ["fused", "torch"])
 def test_tiny_four_step_trajectory(which):
     """ft_bloom.py:84-90 loop, 4 steps: loss_t and ||g||_t vs the reference run with torch.optim.AdamW(lr=1e-5)."""

@@ -32,16 +32,20 @@ def rnd(*s):
 
 
 def run(name, kind, fn, flops):
-    for _ in range(3):
-        fn()
+    """fn: one callable (warm: the same buffers every launch) or a list of callables over different buffers (cold: what the 24 layers of a
+    training step look like to the caches); the tick counters hold the LAST launch."""
+    fns = fn if isinstance(fn, (list, tuple)) else [fn]
+    for f in fns[:3] if len(fns) > 1 else fns * 3:
+        f()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 10 if len(fns) == 1 else len(fns)
     e0.record()
-    for _ in range(10):
-        fn()
+    for i in range(reps):
+        fns[i % len(fns)]()
     e1.record()
     torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 100.0
+    us = e0.elapsed_time(e1) * 1e3 / reps
     t = ticks(kind, 256)
     live = t[:, 3] > 0
     t = t[live]
@@ -81,3 +85,16 @@ run("qkv dgrad K=3072", "nn", lambda: ops.linear_dgrad(dy3, wq), 2.0 * T * 3 * H
 V = 250880
 wv = rnd(V, H)
 run("lm_head fwd", "nt", lambda: ops.linear_fwd(x, wv, None), 2.0 * T * V * H)
+
+if os.environ.get("ANATOMY_COLD", "1") != "0":
+    L = 24
+    print("--- cold: a different input, weight and output buffer per launch (24 sets), counters of the last launch")
+    xs, outs3, outs4, outs1 = [rnd(T, H) for _ in range(L)], [torch.empty(T, 3 * H, dtype=BF, device=DEV) for _ in range(L)], \
+        [torch.empty(T, 4 * H, dtype=BF, device=DEV) for _ in range(L)], [torch.empty(T, H, dtype=BF, device=DEV) for _ in range(L)]
+    wqs, w1s, w2s = [rnd(3 * H, H) for _ in range(L)], [rnd(4 * H, H) for _ in range(L)], [rnd(H, 4 * H) for _ in range(L)]
+    g4s = [rnd(T, 4 * H) for _ in range(L)]
+    run("qkv fwd (cold)", "nt", [(lambda i=i: ops.linear_fwd(xs[i], wqs[i], None, out=outs3[i])) for i in range(L)], 2.0 * T * 3 * H * H)
+    run("h4h fwd plain (cold)", "nt", [(lambda i=i: ops.linear_fwd(xs[i], w1s[i], b1, out=outs4[i])) for i in range(L)], 2.0 * T * 4 * H * H)
+    run("4hh fwd K=4096 +res (cold)", "nt", [(lambda i=i: ops.linear_fwd(g4s[i], w2s[i], None, residual=xs[i], out=outs1[i])) for i in range(L)], 2.0 * T * 4 * H * H)
+    run("4hh dgrad plain (cold)", "nn", [(lambda i=i: ops.linear_dgrad(xs[i], w2s[i])) for i in range(L)], 2.0 * T * 4 * H * H)
+    run("h4h dgrad K=4096 (cold)", "nn", [(lambda i=i: ops.linear_dgrad(g4s[i], w1s[i])) for i in range(L)], 2.0 * T * 4 * H * H)
