@@ -19,7 +19,7 @@ F32, BF16 = 0, 1
 EPI_NONE, EPI_GELU, EPI_DGELU, EPI_RELU, EPI_DRELU, EPI_GELUG, EPI_MUL = 0, 1, 2, 3, 4, 5, 6
 MT_MAX = 24
 PROF_CLASSES = ("gemm_fwd", "gemm_dgrad", "gemm_wgrad", "lm_head", "attn_fwd", "attn_bwd", "layernorm", "loss", "optimizer", "reduce", "other")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 
@@ -55,7 +55,7 @@ class BloomBlockGrads(C.Structure):
     """ctmi_bloom_block_grads (include/ctmi355.h)."""
     _fields_ = [("dout", vp), ("dx", vp)] + [("d" + n, vp) for n in BLK_PARAMS] + \
                [("ws", vp), ("ws_bytes", i64), ("splitk_ws", vp), ("splitk_ws_bytes", i64), ("side_stream", vp),
-                ("side_splitk_ws", vp), ("side_splitk_ws_bytes", i64)]
+                ("side_splitk_ws", vp), ("side_splitk_ws_bytes", i64), ("defer_join", i32)]
 
 
 # name -> (restype, argtypes); must mirror include/ctmi355.h exactly (checked by tests/test_abi.py)

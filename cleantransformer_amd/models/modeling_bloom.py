@@ -145,8 +145,11 @@ class BloomBlockFn(torch.autograd.Function):
         # back into the current stream before the call returns, so everything downstream (autograd accumulation, DDP hooks,
         # optimizer) is ordered.
         ctx.kv.release()
+        side = _WGRAD_SIDE_STREAM and x2.is_cuda
+        # single process, no accumulation pending, no gradient hooks: the side stream is joined once, at the end of the backward pass
+        defer = side and ops.params_allow_deferred_grads((ln1_w, ln1_b, wqkv, bqkv, wd, bd, ln2_w, ln2_b, w1, b1, w2, b2))
         dx, g = ops.bloom_block_bwd(ops.BlockActs.rebuild(slab, ctx.geo), x2, params, ctx.actx.mask, ctx.actx.slopes, ctx.eps, ctx.post_ln_res, dout2,
-                                    use_side_stream=_WGRAD_SIDE_STREAM and x2.is_cuda)
+                                    use_side_stream=side, defer_join=defer)
         return (dx.view(B, S, H), *g, None, None, None, None)
 
 

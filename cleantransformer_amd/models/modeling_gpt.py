@@ -187,7 +187,8 @@ class GPT2BlockFn(torch.autograd.Function):
         params = (n1w.detach(), n1b.detach(), ops.compute_weight(wa, cd), ba.detach(), ops.compute_weight(wp, cd), bp.detach(),
                   n2w.detach(), n2b.detach(), ops.compute_weight(wf, cd), bf.detach(), ops.compute_weight(wo, cd), bo.detach())
         ctx.kv.release()
-        dx, g = ops.bloom_block_bwd(ops.BlockActs.rebuild(slab, ctx.geo), x2, params, ctx.mask, None, ctx.eps, False, dout2)
+        defer = x2.is_cuda and ops.params_allow_deferred_grads((n1w, n1b, wa, ba, wp, bp, n2w, n2b, wf, bf, wo, bo))
+        dx, g = ops.bloom_block_bwd(ops.BlockActs.rebuild(slab, ctx.geo), x2, params, ctx.mask, None, ctx.eps, False, dout2, defer_join=defer)
         return (dx.view(B, S, H), *g, None, None, None, None, None)
 
 

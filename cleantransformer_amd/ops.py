@@ -7,6 +7,7 @@ library or a failing launch raises (there is no eager/CPU fallback).
 from __future__ import annotations
 
 import contextlib
+import os
 import ctypes as C
 import math
 import threading
@@ -411,15 +412,33 @@ def block_layout(B: int, S: int, H: int, nh: int, dtype: torch.dtype) -> _BlockL
     return lay
 
 
-def _block_ws(device, nbytes: int) -> Tensor:
-    """Scratch of the block backward (intermediate gradients, partial rows): one buffer per device, grown on demand.  The
-    backward of consecutive blocks is ordered on the compute stream (and joins its side stream before returning), so they
-    may share it."""
-    ws = _BLOCK_WS.get(device)
+def _block_ws(device, nbytes: int, slot: int = 0) -> Tensor:
+    """Scratch of the block backward (intermediate gradients, partial rows): grown on demand, one buffer per device and slot.  With the
+    side stream joined inside every call consecutive blocks share slot 0; with the join deferred to the end of the backward pass
+    (bloom_block_bwd(defer_join=True)) they alternate between two slots, each guarded by the event of the call that used it last."""
+    ws = _BLOCK_WS.get((device, slot))
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _BLOCK_WS[device] = ws
+        _BLOCK_WS[(device, slot)] = ws
     return ws
+
+
+# deferred join of the weight-gradient side stream: per device [next slot, {slot: event of the last call that used it}, callback queued?]
+_DEFER = {}
+_LAST_DEFERRED_GRAD_PTRS = []
+_DEFER_JOIN = os.environ.get("CTMI_WGRAD_DEFER_JOIN", "1") != "0"
+
+
+def params_allow_deferred_grads(params) -> bool:
+    """The parameter gradients of a block may complete on the side stream AFTER the autograd node has returned only if nothing touches them
+    before the end of the backward pass: no accumulation into an existing .grad (AccumulateGrad would read them on the compute stream), no
+    gradient hooks (the data-parallel wrapper's bucket copy runs in one)."""
+    if not _DEFER_JOIN:
+        return False
+    for p in params:
+        if p.grad is not None or getattr(p, "_post_accumulate_grad_hooks", None) or getattr(p, "_backward_hooks", None):
+            return False
+    return True
 
 
 class BlockActs:
@@ -543,8 +562,10 @@ def bloom_block_fwd(x2: Tensor, params, mask: Optional[MaskInfo], slopes: Option
 
 
 def bloom_block_bwd(acts: BlockActs, x2: Tensor, params, mask: Optional[MaskInfo], slopes: Optional[Tensor], eps: float,
-                    post_ln_res: bool, dout2: Tensor, use_side_stream: bool = True):
-    """Backward of bloom_block_fwd -> (dx [T,H] in the compute dtype, the 12 fp32 parameter gradients in BLK_PARAMS order)."""
+                    post_ln_res: bool, dout2: Tensor, use_side_stream: bool = True, defer_join: bool = False):
+    """Backward of bloom_block_fwd -> (dx [T,H] in the compute dtype, the 12 fp32 parameter gradients in BLK_PARAMS order).
+    defer_join (only from inside a backward pass, with the side stream): the parameter gradients complete on the side stream; the compute
+    stream waits for it ONCE, in a callback at the end of the backward pass (see params_allow_deferred_grads for when that is sound)."""
     _need_cuda(x2, dout2)
     B, S, H, nh = acts.B, acts.S, acts.H, acts.nh
     dev = x2.device
@@ -559,7 +580,22 @@ def bloom_block_bwd(acts: BlockActs, x2: Tensor, params, mask: Optional[MaskInfo
     g.dout, g.dx = dout2.data_ptr(), dx.data_ptr()
     for name, t in zip(_lib.BLK_PARAMS, grads):
         setattr(g, "d" + name, t.data_ptr())
-    ws = _block_ws(dev, acts.lay.bwd_ws_bytes)
+    defer_join = bool(defer_join and use_side_stream)
+    main = torch.cuda.current_stream(dev)
+    st = None
+    slot = 0
+    if defer_join:
+        st = _DEFER.setdefault(dev, [0, {}, False])
+        slot = st[0]
+        st[0] ^= 1
+        prev = st[1].get(slot)
+        if prev is not None:
+            main.wait_event(prev)                                   # the side-stream work of the call that last used this scratch (two blocks ago)
+    elif dev in _DEFER and _DEFER[dev][1]:
+        for ev in _DEFER[dev][1].values():                          # a joined call after deferred ones shares slot 0: let their side work finish first
+            main.wait_event(ev)
+        _DEFER[dev][1].clear()
+    ws = _block_ws(dev, acts.lay.bwd_ws_bytes, slot)
     g.ws, g.ws_bytes = ws.data_ptr(), ws.numel()
     sk = _splitk_ws(dev)
     g.splitk_ws, g.splitk_ws_bytes = sk.data_ptr(), sk.numel() * 4
@@ -569,7 +605,26 @@ def bloom_block_bwd(acts: BlockActs, x2: Tensor, params, mask: Optional[MaskInfo
             sk2 = _splitk_ws(dev)
         g.side_stream = side.cuda_stream
         g.side_splitk_ws, g.side_splitk_ws_bytes = sk2.data_ptr(), sk2.numel() * 4
+    g.defer_join = int(defer_join)
     check(_lib.load().ctmi_bloom_block_bwd(C.byref(d), C.byref(g), _stream()), "bloom_block_bwd")
+    if defer_join:
+        ev = torch.cuda.Event()
+        ev.record(side)
+        st[1][slot] = ev
+        # memory the side stream still reads or writes was allocated on the compute stream: keep the caching allocator from handing it out
+        # again before the side stream has passed this point
+        acts.slab.record_stream(side)
+        dout2.record_stream(side)
+        for t in grads:
+            t.record_stream(side)
+        _LAST_DEFERRED_GRAD_PTRS[:] = [t.data_ptr() for t in grads]   # (tests: autograd must ADOPT these tensors as .grad, not copy them on the compute stream)
+        if not st[2]:
+            st[2] = True
+
+            def _join(main=main, side=side, st=st):
+                st[2] = False
+                main.wait_stream(side)                              # THE join: optimizer, clipping, hooks of the caller see finished gradients
+            torch.autograd.Variable._execution_engine.queue_callback(_join)
     return dx, grads
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CTMI_ABI_VERSION 11
+#define CTMI_ABI_VERSION 12
 
 enum ctmi_dtype { CTMI_F32 = 0, CTMI_BF16 = 1 };
 enum ctmi_status { CTMI_OK = 0, CTMI_ERR_ARG = -1, CTMI_ERR_LAUNCH = -2, CTMI_ERR_UNSUPPORTED = -3 };
@@ -337,6 +337,11 @@ typedef struct ctmi_bloom_block_grads {
                                            data-gradient chain; joined back into `stream` before the call returns (host-side
                                            enqueue: the call itself never blocks) */
     void* side_splitk_ws; int64_t side_splitk_ws_bytes;
+    int defer_join;                     /* (ABI v12) 0: the side stream is joined into `stream` before the call returns.  1 (needs side_stream): NO
+                                           join — the parameter gradients and the bias / LayerNorm-affine reductions complete on side_stream; the
+                                           caller makes `stream` wait for side_stream before anything reads them (one join at the end of the
+                                           backward pass), and must not reuse `ws`, the slab or `dout` on `stream` before side_stream has drained
+                                           this call's work (alternate two workspaces) */
 } ctmi_bloom_block_grads;
 int64_t ctmi_bloom_block_bwd_ws(int64_t B, int64_t S, int64_t H, int64_t nh, int dtype);
 int ctmi_bloom_block_bwd(const ctmi_bloom_block* blk /* host */, const ctmi_bloom_block_grads* gr /* host */, void* stream);

@@ -474,7 +474,7 @@ def bloom_block_fwd(x2, params, mask, slopes, eps, post_ln_res, B, S, nh, flags=
                      stat_l=stat_l, h1=h1, mean2=mean2, rstd2=rstd2, ln2=ln2, u=u, g=g, out=out)
 
 
-def bloom_block_bwd(a, x2, params, mask, slopes, eps, post_ln_res, dout2, use_side_stream=True, K=None):
+def bloom_block_bwd(a, x2, params, mask, slopes, eps, post_ln_res, dout2, use_side_stream=True, K=None, defer_join=False):
     """The kernel sequence ctmi_bloom_block_bwd issues (csrc/block.hip), on the emulated kernels (or on K = ops, see above)."""
     K = K or _THIS
     layernorm_bwd, gemm, attn_bwd, colsum = K.layernorm_bwd, K.gemm, K.attn_bwd, K.colsum

@@ -110,6 +110,55 @@ def test_presents_after_backward_and_inplace_on_a_block_output_fail_loudly():
     assert pres[L - 1][1].is_contiguous()
 
 
+def test_deferred_side_stream_join_equals_joined_backward_bit_for_bit():
+    """Round 4: with no accumulation pending and no gradient hooks the weight-gradient side stream is joined ONCE, at the end of the backward
+    pass (ops.bloom_block_bwd(defer_join=True); two alternating scratch buffers, record_stream on what the side stream still touches).  Same
+    kernels, same order per stream: every gradient must be bit-identical to the per-block join (CTMI_WGRAD_DEFER_JOIN=0 semantics), autograd
+    must ADOPT the gradient tensors (a copy on the compute stream would read them before the side stream has written them), and with an
+    existing .grad (accumulation) the node must fall back to the joined form."""
+    from cleantransformer_amd import ops as o
+    V, H, L, nh, B, S = 512, 256, 6, 4, 4, 256                                     # large enough for the side stream to lag the main stream
+    torch.manual_seed(3)
+    params = {n: (torch.randn(s) * 0.05 if len(s) > 1 else (torch.ones(s) if "layernorm.weight" in n or "ln_f.weight" in n else torch.zeros(s)))
+              for n, s in ((n, R.param_shape(R.BloomShape(V, H, L, nh), n)) for n in R.param_names(R.BloomShape(V, H, L, nh)))}
+    ids = torch.randint(0, V, (B, S), generator=torch.Generator().manual_seed(4)).to(DEV)
+    am = torch.ones(B, S, dtype=torch.long, device=DEV)
+
+    def run(defer, steps=1, zero=True):
+        old = o._DEFER_JOIN
+        o._DEFER_JOIN = defer
+        try:
+            m = build(V, H, L, nh, compute_dtype="bf16", params=params)
+            for _ in range(steps):
+                if zero:
+                    m.zero_grad(set_to_none=True)
+                (loss, _, _), _ = m(input_ids=ids, attention_mask=am, labels=ids.clone())
+                o._LAST_DEFERRED_GRAD_PTRS[:] = []
+                loss.backward()
+            torch.cuda.synchronize()
+            return m, {n: p.grad.clone() for n, p in m.named_parameters()}
+        finally:
+            o._DEFER_JOIN = old
+    m1, g_join = run(False)
+    assert o._LAST_DEFERRED_GRAD_PTRS == []
+    m2, g_def = run(True)
+    assert len(o._LAST_DEFERRED_GRAD_PTRS) == 12                                  # the last block that ran its backward (block 0) deferred
+    blk0 = [p for n, p in m2.named_parameters() if n.startswith("bloom.blocks.0.")]
+    assert sorted(p.grad.data_ptr() for p in blk0) == sorted(o._LAST_DEFERRED_GRAD_PTRS), "autograd copied a deferred gradient instead of adopting it"
+    def same(a, b, n):
+        if n == "bloom.word_embeddings.weight":                                   # tied table: the embedding backward adds its rows with fp32 atomics
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), n                  # (summation order varies from run to run, joined or not)
+        else:
+            assert torch.equal(a, b), n
+    for n in g_join:
+        same(g_join[n], g_def[n], n)
+    # accumulation: the second backward finds .grad set -> joined form, and the sum is exact
+    _, g_acc = run(True, steps=2, zero=False)
+    assert o._LAST_DEFERRED_GRAD_PTRS == []
+    for n in g_join:
+        same(g_acc[n], g_join[n] * 2, n)
+
+
 @pytest.mark.parametrize("which", ["fused", "torch"])
 def test_tiny_four_step_trajectory(which):
     """ft_bloom.py:84-90 loop, 4 steps: loss_t and ||g||_t vs the reference run with torch.optim.AdamW(lr=1e-5)."""
