@@ -1497,6 +1497,19 @@ extern "C" int ctmi_get_launch_policy(int* shared, int* reserve_cus) {
 #ifndef CTMI_WGRAD_ITEMS
 #define CTMI_WGRAD_ITEMS 256     // (same-box A/B vs 512: -0.15 ms per step — half the fp32 slab traffic) split-K target of the layer weight gradients: work items (tiles x splits) to aim for
 #endif
+// layer weight-gradient rule (CTMI_WGRAD_RULE): 0 = round 3 (128x128 / 256x128 free-running tiles, co-resident with the data gradients),
+// 1 = 128x256 ping-pong unsplit, 2 (default since round 4) = the same with split-K up to CTMI_WGRAD_ITEMS4 (128) work items: at Bloom-560M the
+// QKV gradient (96 tiles) splits two ways, the dense one (32 tiles) four ways, the two [4H,H] ones (128 tiles) stay whole
+static int wgrad_rule() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("CTMI_WGRAD_RULE"); v = e ? std::max(0, atoi(e)) : 2; }
+    return v;
+}
+static int64_t wgrad_items4() {
+    static int64_t v = -1;
+    if (v < 0) { const char* e = getenv("CTMI_WGRAD_ITEMS4"); v = e ? std::max(1, atoi(e)) : 128; }
+    return v;
+}
 // smallest number of 256x256 output tiles for which a forward / data-gradient GEMM takes the 256-row ping-pong tile (below: 128x256 if
 // that fills the chip).  350 since round 1 (384 = the QKV forward: 1.5 rounds of 256 CUs on tile 3, 3 full rounds of 768 on tile 4);
 // CTMI_TILE3_MIN overrides it for sweeps — every rule of rounds 1-3 was measured with the K-loop drain of the cross-lane kernels in place.
@@ -1536,6 +1549,16 @@ static void pick_tile(int64_t M, int64_t N, int64_t K, bool wgrad, bool bkm, int
         // gradients of this geometry have <= 64 such tiles (round-3 advisor: a piece used to fall to the unsplit 128x128 rule below)
         if (t1 >= 1024 || (t2 >= 128 && M >= 8 * N)) tile = 3;                // (tall: a [rows, H] window, not a square layer gradient)
         else if (nosplit) tile = nosplit == 2 ? 4 : 3;
+        else if (wgrad_rule() >= 1) {
+            // round 4: with the K-loop drain of the 128-row ping-pong kernels fixed AND the side stream no longer joined after every block
+            // (ctmi_bloom_block_grads.defer_join) the layer weight gradients run fastest in the step on the 128x256 ping-pong tile, unsplit:
+            // 96 / 32 / 128 / 128 workgroups that take whole CUs next to the data-gradient chain instead of sharing them — 37.33-37.49 vs
+            // 38.10-38.17 ms with the round-3 rule below (128x128 free-running, co-resident), same box, interleaved (profiles/r04_wgrad_rule.txt).
+            // wgrad_rule() = 2 adds a split along K where that leaves fewer than CTMI_WGRAD_ITEMS4 work items: 37.30-37.38 vs 37.53-37.63 (128 items;
+            // 256: 38.15-38.30, 64: 37.60-37.70).
+            tile = 4;
+            if (wgrad_rule() >= 2) { while (splits < max_splits && t4 * splits < wgrad_items4() && K / (splits * 2) >= 1024) splits *= 2; }
+        }
         else {
             // round 3 (profiles/r03_gemm_tile_sweep.txt): a weight gradient with >= 256 tiles of 128x128 (h->4h and 4h->h) runs them
             // UNSPLIT (CTMI_WGRAD_ITEMS_TILE0 = 256).  Alone on the GPU that is the slowest choice (602-621 TF/s, one workgroup per
