@@ -377,7 +377,7 @@ def main(argv=None):
                        "ms_per_step_min": round(min(per_step_ms), 3), "ms_per_step_max": round(max(per_step_ms), 3),
                        "wall_s_timed_region": round(dt, 4),
                        "shader_clock_mhz_before": round(clock_before, 1), "shader_clock_mhz_after": round(clock_after, 1),
-                       "shader_clock_note": "ctmi_clock_probe: s_memtime / s_memrealtime of one wave while 2048 workgroups issue bf16 MFMAs (~0.7 ms), "
+                       "shader_clock_note": "ctmi_clock_probe: s_memtime / s_memrealtime of one wave while 2048 workgroups issue bf16 MFMAs (~6 ms), "
                                             "launched right before / right after the timed region; the 2.5 PF peak assumes 2400 MHz",
                        "smi_before": smi_before, "smi_after": smi_after},
             "final_loss": round(final_loss, 4), "host_enqueue_ms_per_step": round(host_enqueue_ms, 2),

@@ -5,7 +5,7 @@ set -u
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/evidence; rm -rf $OUT; mkdir -p $OUT
-R=${ROUND:-r03}
+R=${ROUND:-r04}
 timeout 600 python bench.py --cpu-baseline ${CPU_BASELINE:-full} > $OUT/${R}_bench_default.json 2> $OUT/bench_default.err
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -- python bench.py --no-cpu-baseline --no-breakdown --no-padded-sample --steps 10 --warmup 3 > $OUT/${R}_bench_under_rocprof.json 2> $OUT/prof_bench.err
 CTMI_WGRAD_STREAM=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench_1stream -- python bench.py --no-cpu-baseline --no-breakdown --no-padded-sample --steps 10 --warmup 3 > $OUT/${R}_bench_1stream_under_rocprof.json 2> $OUT/prof_bench_1stream.err
@@ -23,3 +23,5 @@ timeout 400 python tools/bench_bloom7b1.py > $OUT/${R}_bloom7b1_1gpu_bench.txt 2
 timeout 120 python tools/blaslt_probe.py > $OUT/${R}_vendor_gemm_reference.txt 2>&1
 find $OUT -name "*_kernel_trace.csv" -size +20M -delete
 ls -R $OUT | head -40
+timeout 300 python tools/chain_probe.py 24 > $OUT/${R}_chain_probe.txt 2>&1
+bash tools/pmc_gemm.sh > $OUT/${R}_pmc_lmhead_mfma.txt 2>&1

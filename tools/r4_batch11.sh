@@ -1,0 +1,10 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+O=gpurun_out/r4b11; rm -rf $O; mkdir -p $O
+B="python bench.py --no-cpu-baseline --no-breakdown --no-padded-sample"
+for i in 1 2 3; do
+  for e in "" "CTMI_GEMM_PERSIST=0" "CTMI_GEMM_RESERVE_CUS=16" "CTMI_GEMM_RESERVE_CUS=32" "CTMI_GEMM_RESERVE_CUS=64" "CTMI_WGRAD_STREAM=0"; do
+    echo "== bench [$e]" | tee -a $O/bench.txt; env $e $B 2>/dev/null | tail -1 | grep -o '"ms_per_step": [0-9.]*' | tee -a $O/bench.txt
+  done
+done
