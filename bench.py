@@ -258,6 +258,8 @@ def main(argv=None):
                     dist.all_reduce(tt, op=dist.ReduceOp.MAX)                # slowest rank; failed anywhere = failed
                     rec["ms_per_step"] = round(float(tt[0]), 3) if float(tt[1]) < -0.5 else None
                     comm_candidates.append(rec)
+                    if rank == 0:                                             # progress on stderr: survives in the log if a later candidate hangs
+                        print(f"[bench] comm candidate {rec}", file=sys.stderr, flush=True)
                     if isinstance(holder["net"], DDP):
                         holder["net"].close()
                     holder["net"] = model
