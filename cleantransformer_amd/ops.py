@@ -118,7 +118,20 @@ def side_stream(device) -> "torch.cuda.Stream":
     the dgrad / attention-backward chain (they feed nothing downstream in backward)."""
     st = _SIDE_STREAMS.get(device)
     if st is None:
-        st = torch.cuda.Stream(device=device)
+        prio = os.environ.get("CTMI_SIDE_STREAM_PRIORITY")               # "low" / "high" / an integer: hipStreamCreateWithPriority (experiments)
+        if prio is None:
+            st = torch.cuda.Stream(device=device)
+        else:
+            hip = C.CDLL("libamdhip64.so")
+            lo, hi = C.c_int(0), C.c_int(0)
+            hip.hipDeviceGetStreamPriorityRange(C.byref(lo), C.byref(hi))   # least, greatest (numerically: greatest priority is the smaller number)
+            val = lo.value if prio == "low" else (hi.value if prio == "high" else int(prio))
+            h = C.c_void_p()
+            with torch.cuda.device(device):
+                if hip.hipStreamCreateWithPriority(C.byref(h), C.c_uint(1), C.c_int(val)) != 0:
+                    raise _lib.CtmiError("hipStreamCreateWithPriority failed")
+            st = torch.cuda.ExternalStream(h.value, device=device)
+            st._ctmi_priority = (val, lo.value, hi.value)
         _SIDE_STREAMS[device] = st
     return st
 
@@ -423,7 +436,7 @@ def _block_ws(device, nbytes: int, slot: int = 0) -> Tensor:
     return ws
 
 
-# deferred join of the weight-gradient side stream: per device [next slot, {slot: event of the last call that used it}, callback queued?]
+# deferred join of the weight-gradient side stream: per device [next slot, {slot: event of the last call that used it}]
 _DEFER = {}
 _LAST_DEFERRED_GRAD_PTRS = []
 _DEFER_JOIN = os.environ.get("CTMI_WGRAD_DEFER_JOIN", "1") != "0"
@@ -585,7 +598,7 @@ def bloom_block_bwd(acts: BlockActs, x2: Tensor, params, mask: Optional[MaskInfo
     st = None
     slot = 0
     if defer_join:
-        st = _DEFER.setdefault(dev, [0, {}, False])
+        st = _DEFER.setdefault(dev, [0, {}])
         slot = st[0]
         st[0] ^= 1
         prev = st[1].get(slot)
@@ -618,13 +631,10 @@ def bloom_block_bwd(acts: BlockActs, x2: Tensor, params, mask: Optional[MaskInfo
         for t in grads:
             t.record_stream(side)
         _LAST_DEFERRED_GRAD_PTRS[:] = [t.data_ptr() for t in grads]   # (tests: autograd must ADOPT these tensors as .grad, not copy them on the compute stream)
-        if not st[2]:
-            st[2] = True
-
-            def _join(main=main, side=side, st=st):
-                st[2] = False
-                main.wait_stream(side)                              # THE join: optimizer, clipping, hooks of the caller see finished gradients
-            torch.autograd.Variable._execution_engine.queue_callback(_join)
+        # THE join, at the end of this backward pass: optimizer, clipping, scaler of the caller see finished gradients.  One callback per deferred
+        # call (a few microseconds of host time each, the waits after the first are no-ops): no "already queued" flag that a backward pass
+        # which raised half-way could leave set.
+        torch.autograd.Variable._execution_engine.queue_callback(lambda main=main, side=side: main.wait_stream(side))
     return dx, grads
 
 
