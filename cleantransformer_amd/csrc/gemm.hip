@@ -90,8 +90,10 @@ constexpr int glds_patch_bytes(bool pp, int wm, bool xlane = false) { return (pp
 #endif
 // Ping-pong priorities: 0 = s_setprio 1 around every MFMA phase (rounds 1-3); 1 = static: the later-dispatched row group (waves 4-7) runs
 // at priority 1 for the whole kernel, no per-phase flips; 2 = no priorities at all.
+// (1 since round 4: three same-box A/B runs, each 0.1 - 0.15 ms per step in its favour — 39.49 / 39.71 vs 39.61 / 39.88 on the round-3 kernels,
+// 37.17 - 37.30 vs 37.28 - 37.47 on the final ones; the guide's "static priority for the younger half, no per-segment flips")
 #ifndef CTMI_PP_PRIO
-#define CTMI_PP_PRIO 0
+#define CTMI_PP_PRIO 1
 #endif
 // Side-input tile through LDS (round 4; r3 verdict item 2).  The epilogues that read a second [M,N] operand — the activation-
 // derivative input of the 4h->h data gradient (DGELU / MUL / DRELU) and the residual rows of the [T,H]-output forwards — fetched it with
