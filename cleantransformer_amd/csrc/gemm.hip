@@ -759,7 +759,13 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
                 constexpr bool NT = decltype(nt_flag)::value;
                 if (EPI == CTMI_EPI_GELU) {
                     const uint4 tb = pack16<T>(v);
-                    *reinterpret_cast<uint4*>(AUXO + off) = tb;
+                    // the pre-activation is kept for the BACKWARD only (a whole forward and half a backward away): CTMI_GELU_AUX_NT writes it
+                    // non-temporally, so that the activation next to it — the A operand of the very next GEMM — is what stays in the caches
+#ifndef CTMI_GELU_AUX_NT
+#define CTMI_GELU_AUX_NT 1      // (same box, interleaved: forward chain of 24 blocks 6.16 / 6.26 -> 6.07 / 6.05 ms, step 37.01-37.35 -> 36.83-37.08 ms)
+#endif
+                    if constexpr (CTMI_GELU_AUX_NT && sizeof(T) == 2) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, tb), reinterpret_cast<u32x4*>(AUXO + off));   // (the builtin, not asm: hipcc's hazard recognizer does not see into asm, and a first asm version — no wait state between the 16-byte store and the next write of its data registers — stored garbage in a few rows; tests/test_gpu_ops.py::test_gemm_at_the_step_shapes_sampled_vs_fp64 caught it)
+                    else *reinterpret_cast<uint4*>(AUXO + off) = tb;
                     unpack16<T>(tb, v);
 #pragma unroll
                     for (int r = 0; r < 8; r += 2) { const f32x2 y = gelu_tanh_pk(f32x2{v[r], v[r + 1]}); v[r] = y[0]; v[r + 1] = y[1]; }
@@ -819,8 +825,18 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
                             for (int r = 0; r < 4; ++r) { v[r] += c0v[r]; v[4 + r] += c1v[r]; }
                         }
                     }
-                    *reinterpret_cast<f32x4*>(Cf) = f32x4{v[0], v[1], v[2], v[3]};
-                    *reinterpret_cast<f32x4*>(Cf + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                    // weight gradients (both operands K-major, fp32 out): written once, read by the optimizer a whole backward later —
+                    // CTMI_WGRAD_NT stores them non-temporally
+#ifndef CTMI_WGRAD_NT
+#define CTMI_WGRAD_NT 0
+#endif
+                    if constexpr (CTMI_WGRAD_NT && AK && BKM && PLAIN) {
+                        asm volatile("global_store_dwordx4 %0, %1, off nt\n\tglobal_store_dwordx4 %0, %2, off offset:16 nt\n\ts_nop 1"
+                                     :: "v"(Cf), "v"(f32x4{v[0], v[1], v[2], v[3]}), "v"(f32x4{v[4], v[5], v[6], v[7]}) : "memory");
+                    } else {
+                        *reinterpret_cast<f32x4*>(Cf) = f32x4{v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(Cf + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                    }
                 } else {
                     if constexpr (!PLAIN) {
                         if (g.beta) {
@@ -834,7 +850,7 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
                     // logits-sized outputs (>> the 256 MiB Infinity Cache) are written non-temporally so they do
                     // not push the operand panels out of L2 (asm: hipcc would merge a plain and a nontemporal store
                     // to one address into one plain store)
-                    if (NT && g.nt_c) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(C + off), "v"(__builtin_bit_cast(u32x4, pk)) : "memory");
+                    if (NT && g.nt_c) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" :: "v"(C + off), "v"(__builtin_bit_cast(u32x4, pk)) : "memory");
                     else *reinterpret_cast<uint4*>(C + off) = pk;
                 }
             };
@@ -910,7 +926,15 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
                             for (int it = 0; it < 4; ++it) pre[slot][it] = *reinterpret_cast<const uint4*>(((it & 1) ? sl1 : sl0) + (p * 2 + (it >> 1)) * (16 * 512));
                         } else {
 #pragma unroll
-                            for (int it = 0; it < 4; ++it) pre[slot][it] = *reinterpret_cast<const uint4*>(side + offL + (p * 2 + (it >> 1)) * row16 + 32 * (it & 1));
+                            for (int it = 0; it < 4; ++it) {
+                                const uint4* sp_ = reinterpret_cast<const uint4*>(side + offL + (p * 2 + (it >> 1)) * row16 + 32 * (it & 1));
+#ifndef CTMI_SIDE_NT
+#define CTMI_SIDE_NT 0
+#endif
+                                // the activation-derivative input is read here for the last time (CTMI_SIDE_NT: non-temporal load; not the residual rows)
+                                if constexpr (CTMI_SIDE_NT && PRE_AUX) pre[slot][it] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(sp_)));
+                                else pre[slot][it] = *sp_;
+                            }
                         }
                     }
                 };

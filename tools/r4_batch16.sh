@@ -1,0 +1,10 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+O=gpurun_out/r4b16; rm -rf $O; mkdir -p $O
+for v in wnt sident; do CTMI_LIB_PATH=$PWD/cleantransformer_amd/lib/variants/$v/libctmi355.so timeout 300 python -m pytest tests/test_gpu_ops.py -x -q -m gpu -k "gemm_forward or step_shapes" 2>&1 | tail -1 | tee -a $O/tests.txt; done
+B="python bench.py --no-cpu-baseline --no-breakdown --no-padded-sample"
+for i in 1 2 3 4; do
+  echo "== bench default" | tee -a $O/bench.txt; $B 2>/dev/null | tail -1 | grep -o '"ms_per_step": [0-9.]*' | tee -a $O/bench.txt
+  for v in wnt sident both; do echo "== bench $v" | tee -a $O/bench.txt; CTMI_LIB_PATH=$PWD/cleantransformer_amd/lib/variants/$v/libctmi355.so $B 2>/dev/null | tail -1 | grep -o '"ms_per_step": [0-9.]*' | tee -a $O/bench.txt; done
+done
