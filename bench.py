@@ -11,6 +11,7 @@ before the timed region.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -310,6 +311,11 @@ def main(argv=None):
     clock_after = ops.clock_probe(device)                                  # ... and right after the timed steps
     smi_after = _smi_snapshot() if rank == 0 else None
     final_loss = float(loss.detach())
+    if not (math.isfinite(final_loss) and 0.0 < final_loss < 2.0 * math.log(V)):
+        # A timing of garbage is not a measurement — and it is not even conservative: MFMAs on NaN operands draw less power, the chip clocks
+        # higher and EVERY kernel of the step runs ~8 % faster (measured in round 4 on a build with a data race: profiles/r04_k2_pairs.txt).
+        raise SystemExit(f"bench.py: the loss after the timed steps is {final_loss} (random-init start: ~{math.log(V):.1f}) — "
+                         f"the step computes garbage; refusing to report a throughput for it")
     med_ms = sorted(per_step_ms)[len(per_step_ms) // 2]
     if world > 1:
         tt = torch.tensor([dt, med_ms], dtype=torch.float64, device=device)

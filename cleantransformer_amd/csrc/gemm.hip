@@ -46,7 +46,15 @@
 #ifndef CTMI_PP256X_RING
 #define CTMI_PP256X_RING 4
 #endif
-constexpr int glds_ring(bool pp, int wm, bool xlane = false) { return !pp ? 3 : ((wm == 4 && !CTMI_EPI_SHUFFLE) ? CTMI_PP128_RING : ((xlane && wm == 8) ? CTMI_PP256X_RING : 4)); }
+// CTMI_PP_K2 (round 4): the 128-row ping-pong tile consumes TWO 32-k ring stages per phase — 16 fragment reads + 6 DMA pieces | 32 MFMAs —
+// instead of one (8 + 3 | 16).  A phase of that tile costs ~730 cycles whatever it contains (r03_gemm_anatomy.txt) against 272 cycles of MFMAs:
+// most of it is latency (LDS round trip, DMA issue, two barriers) that a phase pays once, so twice the work per phase nearly halves it per FLOP.
+// Needs a 6-stage ring (144 KiB: no co-resident workgroup — none wanted since the weight gradients moved to this tile) and 32 more registers.
+#ifndef CTMI_PP_K2
+#define CTMI_PP_K2 1
+#endif
+constexpr bool glds_k2(bool pp, int wm) { return CTMI_PP_K2 && pp && wm == 4 && !CTMI_EPI_SHUFFLE; }
+constexpr int glds_ring(bool pp, int wm, bool xlane = false) { return !pp ? 3 : (glds_k2(pp, wm) ? 6 : ((wm == 4 && !CTMI_EPI_SHUFFLE) ? CTMI_PP128_RING : ((xlane && wm == 8) ? CTMI_PP256X_RING : 4))); }
 constexpr int glds_patch_bytes(bool pp, int wm, bool xlane = false) { return (pp && !xlane && !(wm == 4 && !CTMI_EPI_SHUFFLE)) ? 4 * 8192 : 0; }
 // XLANE instantiations of the 256-row ping-pong tile: cross-lane epilogue there too (no patches).  Per launch, not per tile: it is the
 // better epilogue for a row-major-B [T,4H]-sized output and the worse one for the logits (see the note above), so the launcher
@@ -531,6 +539,9 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
     constexpr int PA = TA::NINSTR / NW, PB = TB::NINSTR / NW;               // DMA instructions per wave per stage
     constexpr int LOADS = PA + PB;
     static_assert(PP ? (LOADS == 3 || LOADS == 4) : (LOADS == 4 || LOADS == 6), "vmcnt immediates below assume these DMA piece counts");
+    constexpr bool K2 = glds_k2(PP, WM) && CTMI_PP_STEADY && !CTMI_PP_SPLIT_DMA && !CTMI_GEMM_TIMING;   // two ring stages per phase (see CTMI_PP_K2)
+    constexpr int FILL = K2 ? NST - 2 : NST - 1;                              // stages in flight between K-steps (K2: two slots stay free for the pair to issue)
+    constexpr int LAND = K2 ? 2 : 1;                                          // stages that have LANDED when a K-step starts (a pair reads two): every counted wait keeps that
     constexpr bool SIDE_LDS = glds_side_lds(PP, WM, EPI, RES);               // side-input tile as a third LDS-DMA operand (see CTMI_PP_SIDE_LDS)
     constexpr int SIDE_OFF = NST * STAGE;                                     // 64 KiB behind the ring: [128 rows][256 columns] bf16, 512-byte rows
     static_assert(!SIDE_LDS || (BM == 128 && BN == 256 && NW == 8 && LOADS == 3), "the side-tile schedule is written for the 128x256 ping-pong tile");
@@ -655,6 +666,7 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
 #endif
     constexpr bool SIDE_EARLY = CTMI_PP_SIDE_EARLY && CTMI_PP_STEADY && !CTMI_PP_SPLIT_DMA && !CTMI_GEMM_TIMING && !SIDE_LDS && PP && WM == 4 && !CTMI_EPI_SHUFFLE &&
                                 LOADS == 3 && ((EPI == CTMI_EPI_DGELU || EPI == CTMI_EPI_DRELU || EPI == CTMI_EPI_MUL) || RES);
+    static_assert(!(K2 && (SIDE_LDS || SIDE_EARLY)), "the side-input experiments spell their counted waits for one stage per phase: build them with -DCTMI_PP_K2=0");
     uint4 sp00, sp01, sp02, sp03, sp10, sp11, sp12, sp13;                      // (eight named values, not an array: as an array captured by the epilogue lambda hipcc kept it in scratch memory)
     sp00 = sp01 = sp02 = sp03 = sp10 = sp11 = sp12 = sp13 = make_uint4(0u, 0u, 0u, 0u);
     bool spre_on = false;
@@ -1121,11 +1133,11 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         };
 #pragma unroll 1
-        for (int s = 0; s < NST - 1 && wi < nwork; ++s) {
+        for (int s = 0; s < FILL && wi < nwork; ++s) {
             issue_stage(wrb);
             stage_issued(); ++inflight; wrb = wrb == NST - 1 ? 0 : wrb + 1;
         }
-        wait_stages(inflight - 1);
+        wait_stages(inflight - LAND);
         __builtin_amdgcn_s_barrier();
         if (wr == 1) __builtin_amdgcn_s_barrier();                            // stagger the two row groups by one phase
         if constexpr (CTMI_PP_PRIO == 1) { if (wr == 1) __builtin_amdgcn_s_setprio(1); }
@@ -1196,7 +1208,54 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
             if constexpr (CTMI_PP_STEADY && !CTMI_PP_SPLIT_DMA && !CTMI_GEMM_TIMING) {
                 // (a loop since round 4: after the DMA stream's switch to the next work item the remaining K-steps of THIS tile run steady too,
                 // in the same pass — the early side-input prefetch below is issued there and consumed by this tile's epilogue further down)
-                while (!tile_done && inflight == NST - 1 && wi < nwork && !GEMM_DBG(g)) {
+                while (!tile_done && inflight == FILL && wi < nwork && !GEMM_DBG(g)) {
+                    if constexpr (K2) {
+                        // pairs of K-steps while both sides (this tile, the DMA stream's work item) have two left: stages rd, rd+1 are read, the pair
+                        // rd+4, rd+5 goes into the two free slots, the counted wait leaves exactly that pair in flight (rd+2, rd+3 have landed for
+                        // the next pair), 32 MFMAs: first all sixteen accumulators with stage rd, then again with rd+1 (no back-to-back dependency)
+                        const int npair = min(ntc - tc, nti - ti) >> 1;
+#pragma unroll 1
+                        for (int n = npair; n > 0; --n) {
+                            const int rd1 = rd == NST - 1 ? 0 : rd + 1;
+                            short8 af0[WM], bf0[4], af1[WM], bf1[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) bf0[j] = TB::frag(smem_raw + BOFF + rd * TB::BYTES, wc * 64 + j * 16, lane);
+#pragma unroll
+                            for (int i = 0; i < WM; ++i) af0[i] = TA::frag(smem_raw + AOFF + rd * TA::BYTES, wr * (WM * 16) + i * 16, lane);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) bf1[j] = TB::frag(smem_raw + BOFF + rd1 * TB::BYTES, wc * 64 + j * 16, lane);
+#pragma unroll
+                            for (int i = 0; i < WM; ++i) af1[i] = TA::frag(smem_raw + AOFF + rd1 * TA::BYTES, wr * (WM * 16) + i * 16, lane);
+                            issue_stage(wrb);
+                            wrb = wrb == NST - 1 ? 0 : wrb + 1;
+                            issue_stage(wrb);
+                            wrb = wrb == NST - 1 ? 0 : wrb + 1;
+                            wait_stages(2);
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            __builtin_amdgcn_sched_barrier(0);
+                            __builtin_amdgcn_s_barrier();
+                            __builtin_amdgcn_sched_barrier(0);
+                            if constexpr (CTMI_PP_PRIO == 0) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(bf0[j], af0[i], acc[i][j]);
+#pragma unroll
+                            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(bf1[j], af1[i], acc[i][j]);
+                            if constexpr (CTMI_PP_PRIO == 0) __builtin_amdgcn_s_setprio(0);
+                            __builtin_amdgcn_sched_barrier(0);
+                            __builtin_amdgcn_s_barrier();
+                            __builtin_amdgcn_sched_barrier(0);
+                            rd = rd1 == NST - 1 ? 0 : rd1 + 1;
+                        }
+                        ti += 2 * npair;
+                        tc += 2 * npair;
+                        if (ti == nti) { wi += G; if (wi < nwork) setup_issue(); }
+                        if (tc == ntc) { tile_done = true; break; }
+                        if (npair > 0) continue;                                  // re-evaluate: the next run may again hold pairs
+                    }
                     int spre_steps = 0;                                           // steady steps whose counted wait must allow the 8 prefetch loads
                     if constexpr (SIDE_EARLY) {
                         if (!spre_on && early_ok && ntc - tc <= 3) {
@@ -1241,7 +1300,7 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
                         }
                         if (SIDE_LDS && swin) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
                         else if (SIDE_EARLY && spre_steps > 0) { asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); --spre_steps; }   // 2 stages x 3 pieces + 8 loads
-                        else wait_stages(NST - 2);
+                        else wait_stages(FILL - LAND);                            // (one stage consumed, one issued: FILL - LAND of the FILL younger ones may fly)
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         __builtin_amdgcn_sched_barrier(0);
                         __builtin_amdgcn_s_barrier();
@@ -1300,7 +1359,7 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
                 }
                 PH_TICK(ph_issue);
                 // (generic steps ignore the side piece in their count: the plain wait is merely stricter by that one piece — loads return in order)
-                wait_stages(inflight - 2);
+                wait_stages(inflight - 1 - LAND);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             PH_TICK(ph_wait);

@@ -184,7 +184,9 @@ def test_layernorm_module_golden_and_multidim():
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-GEMM_SHAPES = [(128, 128, 64), (256, 384, 128), (100, 72, 40), (64, 211, 64), (37, 19, 211), (130, 260, 1000), (512, 1024, 1024), (512, 768, 256)]
+GEMM_SHAPES = [(128, 128, 64), (256, 384, 128), (100, 72, 40), (64, 211, 64), (37, 19, 211), (130, 260, 1000), (512, 1024, 1024), (512, 768, 256),
+               (256, 512, 96), (160, 288, 352), (1184, 1568, 32)]   # odd numbers of 32-wide K-steps (3 / 5 / 9 / 11 / 37 / 49) and a single one: the
+#                                                                     128-row ping-pong tile consumes K-steps in PAIRS and falls back to single steps
 
 
 @pytest.mark.parametrize("dtype,rtol,atol", [(torch.float32, 1e-5, 1e-5), (torch.bfloat16, 1.2e-2, 1.2e-2)])
@@ -635,12 +637,14 @@ def test_scale_and_scale_copy_bit_exact():
         assert torch.equal(y.cpu(), want)
 
 
-def test_gemm_more_tiles_than_slots():
+@pytest.mark.parametrize("K", [192, 160, 224])
+def test_gemm_more_tiles_than_slots(K):
     """Persistent launches: more output tiles than resident workgroups, so workgroups walk several tiles and the DMA stream, the
     cross-tile prefetch run across tile boundaries.  All three operand layouts,
-    bf16, against torch on the same device in fp32."""
+    bf16, against torch on the same device in fp32.  K = 160 / 224: an ODD number of K-steps per tile (5 / 7), so on the tile that consumes
+    K-steps in pairs the DMA stream (four stages ahead) changes work items in the middle of a pair and single steps alternate with pairs."""
     o = ops()
-    M, N, K = 4096, 4352, 192                                 # 16 x 17 = 272 tiles of 256 x 256 (> 256 CUs), 3 K-step pairs
+    M, N = 4096, 4352                                         # 16 x 17 = 272 tiles of 256 x 256 (> 256 CUs), 6 / 5 / 7 K-steps each
     g = torch.Generator().manual_seed(11)
     x = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
     w = (torch.randn(N, K, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
@@ -729,6 +733,48 @@ def test_gemm_at_the_step_shapes_sampled_vs_fp64(name, kind, T, Nout, Kin, epi):
         print(f"[step gemm] {name} {kind} {epi}: max err {float(err.max()):.3e}, max err/bound {float((err / bound).max()):.3f}, scale {scale:.2f}")
     assert torch.isfinite(got).all()
     assert bool((err <= bound).all()), f"{name} {kind}: {int((err > bound).sum())}/{err.numel()} sampled elements off, worst {float(err.max()):.3e} (bound there {float(bound.flatten()[err.argmax()]):.3e})"
+
+
+@pytest.mark.parametrize("name,kind,T,Nout,Kin,epi", [c for c in STEP_GEMMS if not (c[0] == "lm_head" and c[1] == "fwd")], ids=lambda v: str(v))
+def test_gemm_with_cold_operands_equals_warm_bit_for_bit(name, kind, T, Nout, Kin, epi):
+    """A race detector for the LDS-DMA rings.  The counted waits of the K-loops (`s_waitcnt vmcnt(N)`) are hand-written: one that is too
+    loose reads a ring stage before it has landed — and with L2-warm operands (every other GEMM test: operands just generated or used) the
+    stage has ALWAYS landed by then, so the result is right.  Round 4 shipped such a wait for an hour (the first two-stages-per-phase build
+    of the 128-row tile read stage 1 after waiting for stage 0 only): 82 GEMM parity tests green, NaN loss in the training step, where
+    operands come from HBM.  The kernels are deterministic (split-K partials are reduced in a fixed order), so: the result with operands
+    evicted from L2 and the memory-side cache (3 GiB written in between) must equal the warm result bit for bit, six times."""
+    o, L = ops(), lib()
+    dev_g = torch.Generator(device=DEV).manual_seed(sum(map(ord, name + kind)) * 104729 + Kin)
+    bfr = lambda *sh, sc=0.5: (torch.randn(*sh, generator=dev_g, device=DEV) * sc).to(torch.bfloat16)   # noqa: E731
+    if kind == "fwd":
+        x, w = bfr(T, Kin), bfr(Nout, Kin)
+        bias = torch.randn(Nout, generator=dev_g, device=DEV) if epi else None
+        res = bfr(T, Nout) if epi == "bias+res" else None
+
+        def run():
+            u = torch.empty(T, Nout, dtype=torch.bfloat16, device=DEV) if epi == "gelu" else None
+            y = o.linear_fwd(x, w, bias, residual=res, epilogue=L.EPI_GELU if epi == "gelu" else L.EPI_NONE, aux_out=u)
+            return (y, u) if u is not None else (y,)
+    elif kind == "dgrad":
+        dy, w = bfr(T, Nout), bfr(Nout, Kin, sc=0.5 if Nout < 65536 else 0.05)
+        aux = bfr(T, Kin) if epi in ("dgelu", "mul") else None
+
+        def run():
+            return (o.linear_dgrad(dy, w, epilogue={"dgelu": L.EPI_DGELU, "mul": L.EPI_MUL}.get(epi, L.EPI_NONE), aux_in=aux),)
+    else:
+        dy, x = bfr(T, Nout), bfr(T, Kin)
+
+        def run():
+            return (o.linear_wgrad(dy, x),)
+    run()
+    warm = run()
+    assert all(bool(torch.isfinite(t.float()).all()) for t in warm)
+    evict = torch.empty(3 << 28, dtype=torch.int32, device=DEV)               # 3 GiB of stores: > 256 MiB Infinity Cache + 32 MiB of L2s
+    for i in range(6):
+        evict.fill_(i)
+        cold = run()
+        for a, b in zip(cold, warm):
+            assert torch.equal(a, b), f"{name} {kind} {epi}: run {i} with cold operands differs from the warm result in {int((a != b).sum())} elements"
 
 
 @pytest.mark.parametrize("env", [{"CTMI_GEMM_TILE": "0"}, {"CTMI_GEMM_TILE": "1"}, {"CTMI_GEMM_TILE": "2"}, {"CTMI_GEMM_TILE": "3"},
