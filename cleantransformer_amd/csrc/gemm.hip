@@ -53,6 +53,14 @@
 #ifndef CTMI_PP_K2
 #define CTMI_PP_K2 1
 #endif
+// CTMI_PP_SPLIT2 (round 4 experiment, 256-row ping-pong tiles): in the STEADY loop a wave issues only its two A pieces of the new stage in the
+// load phase and its two B pieces inside the MFMA phase (after the 8th and the 24th of the 32 MFMAs).  Why: the load phase (12 fragment reads
+// + 4 pieces, ~830 cycles) is longer than the partner group's 544 cycles of MFMAs, and most of it is the four pieces — four waves issuing
+// beside fragment reads get ~44 B/clk out of the CU's DMA path, eight waves 64 (profiles/r04_dma_issue_probe.txt).  At K-step boundaries the
+// ring is in the same state as without the split (r3's CTMI_PP_SPLIT_DMA did this in the generic step only, with its bookkeeping).
+#ifndef CTMI_PP_SPLIT2
+#define CTMI_PP_SPLIT2 0
+#endif
 constexpr bool glds_k2(bool pp, int wm) { return CTMI_PP_K2 && pp && wm == 4 && !CTMI_EPI_SHUFFLE; }
 constexpr int glds_ring(bool pp, int wm, bool xlane = false) { return !pp ? 3 : (glds_k2(pp, wm) ? 6 : ((wm == 4 && !CTMI_EPI_SHUFFLE) ? CTMI_PP128_RING : ((xlane && wm == 8) ? CTMI_PP256X_RING : 4))); }
 constexpr int glds_patch_bytes(bool pp, int wm, bool xlane = false) { return (pp && !xlane && !(wm == 4 && !CTMI_EPI_SHUFFLE)) ? 4 * 8192 : 0; }
@@ -541,6 +549,7 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
     static_assert(PP ? (LOADS == 3 || LOADS == 4) : (LOADS == 4 || LOADS == 6), "vmcnt immediates below assume these DMA piece counts");
     constexpr bool K2 = glds_k2(PP, WM) && CTMI_PP_STEADY && !CTMI_PP_SPLIT_DMA && !CTMI_GEMM_TIMING;   // two ring stages per phase (see CTMI_PP_K2)
     constexpr int FILL = K2 ? NST - 2 : NST - 1;                              // stages in flight between K-steps (K2: two slots stay free for the pair to issue)
+    constexpr bool SPLIT2 = CTMI_PP_SPLIT2 && PP && WM == 8 && PA == 2 && PB == 2 && CTMI_PP_STEADY && !CTMI_PP_SPLIT_DMA && !CTMI_GEMM_TIMING && !CTMI_PP_DMA_FIRST;
     constexpr int LAND = K2 ? 2 : 1;                                          // stages that have LANDED when a K-step starts (a pair reads two): every counted wait keeps that
     constexpr bool SIDE_LDS = glds_side_lds(PP, WM, EPI, RES);               // side-input tile as a third LDS-DMA operand (see CTMI_PP_SIDE_LDS)
     constexpr int SIDE_OFF = NST * STAGE;                                     // 64 KiB behind the ring: [128 rows][256 columns] bf16, 512-byte rows
@@ -1285,7 +1294,8 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
                         for (int j = 0; j < 4; ++j) bf[j] = TB::frag(bs, wc * 64 + j * 16, lane);
 #pragma unroll
                         for (int i = 0; i < WM; ++i) af[i] = TA::frag(as, wr * (WM * 16) + i * 16, lane);
-                        if constexpr (!CTMI_PP_DMA_FIRST) issue_stage(wrb);
+                        if constexpr (SPLIT2) issue_A(wrb);
+                        else if constexpr (!CTMI_PP_DMA_FIRST) issue_stage(wrb);
                         bool swin = false;
                         if constexpr (SIDE_LDS) {
                             // AFTER the stage: the piece is then younger than the stage needed three steps from now, so (vector memory
@@ -1300,6 +1310,7 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
                         }
                         if (SIDE_LDS && swin) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
                         else if (SIDE_EARLY && spre_steps > 0) { asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); --spre_steps; }   // 2 stages x 3 pieces + 8 loads
+                        else if constexpr (SPLIT2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // stage c+2 whole (4 pieces) + the two A pieces just issued may fly
                         else wait_stages(FILL - LAND);                            // (one stage consumed, one issued: FILL - LAND of the FILL younger ones may fly)
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         __builtin_amdgcn_sched_barrier(0);
@@ -1309,7 +1320,16 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
 #pragma unroll
                         for (int i = 0; i < WM; ++i)
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(bf[j], af[i], acc[i][j]);
+                            for (int j = 0; j < 4; ++j) {
+                                acc[i][j] = Mma<T>::mma(bf[j], af[i], acc[i][j]);
+                                if constexpr (SPLIT2) {
+                                    if (i * 4 + j == 7 || i * 4 + j == 23) {
+                                        __builtin_amdgcn_sched_barrier(0);
+                                        issue_B(wrb, i * 4 + j == 7 ? 0 : 1);
+                                        __builtin_amdgcn_sched_barrier(0);
+                                    }
+                                }
+                            }
                         if constexpr (CTMI_PP_PRIO == 0) __builtin_amdgcn_s_setprio(0);
                         __builtin_amdgcn_sched_barrier(0);
                         __builtin_amdgcn_s_barrier();
