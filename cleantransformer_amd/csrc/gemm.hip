@@ -36,8 +36,9 @@
 #endif
 // LDS-DMA ring depth.  Free-running tiles: 3 stages.  Ping-pong: 4 stages + 4 x 8 KiB epilogue patches; the 128-row tile's
 // cross-lane epilogue needs no patches (96 KiB).  Its 24 KiB stages would fit six times into 160 KiB (five K-steps of prefetch
-// instead of three): measured same-box, that is neutral per kernel and 0.3 ms/step WORSE in the training step — the 64 KiB it
-// leaves free is what lets a weight-gradient workgroup of the side stream share the CU.  CTMI_PP128_RING keeps the knob.
+// instead of three): measured same-box in round 3, that was neutral per kernel and 0.3 ms/step WORSE in the training step — the 64 KiB it
+// left free let a weight-gradient workgroup of the side stream share the CU.  CTMI_PP128_RING keeps the knob for -DCTMI_PP_K2=0 builds;
+// since round 4 the tile runs the two-stages-per-phase schedule below on a 6-stage ring (and the weight gradients take whole CUs).
 #ifndef CTMI_PP128_RING
 #define CTMI_PP128_RING 4
 #endif
@@ -1678,7 +1679,8 @@ static void pick_tile(int64_t M, int64_t N, int64_t K, bool wgrad, bool bkm, int
             while (splits < max_splits && tiles * splits < items && K / (splits * 2) >= 1024) splits *= 2;
         }
     } else if (K >= 32768 && max_splits >= 2 && t2 * 2 >= 192) { tile = 3; splits = 2; }
-    else if (t2 >= tile3_min()) tile = 3;
+    else if (t2 >= tile3_min()) tile = 3;                                         // (also where 256x256 tiles fill their last round badly — QKV forward: 384
+                                                                                  // tiles = 1.5 rounds; onto 768 tiles of 128x256 it is +4 % alone and 0.1 ms WORSE in the step, round 4)
     else if (t4 >= 256 && (CTMI_TILE_RULES_R3 || !bkm || K <= 1024)) tile = 4;                                  // (round 3: also K-major B with long K — 919 vs 861 TF/s on the QKV data gradient)
     else if (t1 >= 700) tile = 1;
     else tile = 0;
