@@ -47,6 +47,9 @@ def main():
         loss = step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    import math
+    if not math.isfinite(float(loss.detach())):                          # a timing of garbage is not a measurement (bench.py has the long version)
+        raise SystemExit(f"{__file__}: the loss after the timed steps is {float(loss.detach())}; refusing to report a throughput for it")
     Hh, Ll, Vv = bench.H, bench.L, bench.V
     n_mm = Ll * 12 * Hh * Hh + Vv * Hh
     f_tok = 6.0 * n_mm + 6.0 * Ll * S * Hh
@@ -55,7 +58,7 @@ def main():
         "metric": "SFT tokens/sec/step Bloom-7B1 bf16 (1 GPU)", "value": round(tok_s, 1), "unit": "tokens/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"Bloom-7B1 geometry ({Ll}L, H=4096, nh=32, V=250880) SFT step, B={B} S={S}, fp32 master/grads/Adam"},
-        "final_loss": round(float(loss), 4), "hbm_gb_allocated": round(torch.cuda.max_memory_allocated() / 2**30, 1),
+        "final_loss": round(float(loss.detach()), 4), "hbm_gb_allocated": round(torch.cuda.max_memory_allocated() / 2**30, 1),
         "roofline": {"bound": "mfma", "peak": 2500.0, "unit": "TFLOP/s", "step_achieved": round(tok_s * f_tok / 1e12, 1),
                      "step_frac": round(tok_s * f_tok / 1e12 / 2500.0, 4), "flops_per_token": f_tok}}))
 

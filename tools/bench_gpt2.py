@@ -63,6 +63,9 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ops.set_timer(None)
+    import math
+    if not math.isfinite(float(loss.detach())):                          # a timing of garbage is not a measurement (bench.py has the long version)
+        raise SystemExit(f"{__file__}: the loss after the timed steps is {float(loss.detach())}; refusing to report a throughput for it")
     n_mm = L * 12 * H * H + V * H
     f_tok = 6.0 * n_mm + 6.0 * L * S * H                                  # attention counted causal-half, as SURVEY §8(d)
     tok_s = B * S * args.steps / dt
@@ -72,7 +75,7 @@ def main():
         "metric": "LM training tokens/sec/step GPT-2-medium bf16", "value": round(tok_s, 1), "unit": "tokens/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"GPT-2-medium (24L, n_embd=1024, nh=16, V=50257) LM-head training step, B={B} S={S} (BASELINE configs[3])"},
-        "final_loss": round(float(loss), 4),
+        "final_loss": round(float(loss.detach()), 4),
         "roofline": {"bound": "mfma", "kernel": "LM-head forward [T,1024]x[50257,1024]^T", "achieved": round(2.0 * B * S * H * V / (head_avg * 1e-3) / 1e12, 1),
                      "peak": PEAK, "unit": "TFLOP/s", "avg_launch_ms": round(head_avg, 4),
                      "step_achieved": round(tok_s * f_tok / 1e12, 1), "step_frac": round(tok_s * f_tok / 1e12 / PEAK, 4), "flops_per_token": f_tok}}))
