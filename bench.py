@@ -81,6 +81,53 @@ def _smi_snapshot():
         return None
 
 
+class _PowerSampler:
+    """rocm-smi package power / shader clock of GPU 0, sampled by a thread (one rocm-smi process per sample, ~10 per second) while the steps run.
+    Round 4 found the step power-limited — the package at ~1.3 kW of its 1.4 kW cap, the firmware paying with the shader clock
+    (profiles/r04_power_samples.txt) — so the line carries the evidence itself.  Best effort: `summary()` is None without the tool."""
+
+    def __init__(self):
+        import shutil
+        import threading
+        self.exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+        self.power, self.sclk, self._stop = [], [], False
+        self.thread = threading.Thread(target=self._run, daemon=True) if os.path.exists(self.exe) else None
+
+    def _run(self):
+        import re
+        import subprocess
+        while not self._stop:
+            try:
+                r = subprocess.run([self.exe, "-d", "0", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=10)
+                m = re.search(r"Package Power \(W\): ([0-9.]+)", r.stdout)
+                c = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", r.stdout)
+                if m:
+                    self.power.append(float(m.group(1)))
+                if c:
+                    self.sclk.append(int(c.group(1)))
+            except Exception:
+                return
+
+    def start(self):
+        if self.thread is not None:
+            self.thread.start()
+        return self
+
+    def stop(self):
+        self._stop = True
+        if self.thread is not None:
+            self.thread.join(timeout=15)
+
+    def summary(self):
+        if not self.power:
+            return None
+        busy = [p for p in self.power[1:]] or self.power                    # the first sample may predate the first step
+        med = lambda v: sorted(v)[len(v) // 2]                                # noqa: E731
+        return {"samples": len(busy), "package_power_w_median": med(busy), "package_power_w_max": max(busy),
+                "sclk_mhz_median": med(self.sclk) if self.sclk else None,
+                "note": "rocm-smi sampled ~10 x per second during the timed steps (its figure is a moving average: the first samples still see the idle gap before them; cap: smi_before)"}
+
+
 def build_model(device, compute_dtype):
     from cleantransformer_amd.models.modeling_bloom import BloomConfig, BloomForCausalLM
     cfg = BloomConfig(vocab_size=V, hidden_size=H, n_layer=L, num_attention_heads=NH, compute_dtype=compute_dtype)
@@ -306,8 +353,11 @@ def main(argv=None):
     clock_before = ops.clock_probe(device)                                 # shader clock under MFMA load, chip warm from the warm-up steps
     timer = ops.KernelTimer(["lm_head_fwd"])
     ops.set_timer(timer)
+    sampler = _PowerSampler().start() if rank == 0 else None
     dt, per_step_ms, host_loop_s, loss = timed_steps(args.steps)
     ops.set_timer(None)
+    if sampler is not None:
+        sampler.stop()
     clock_after = ops.clock_probe(device)                                  # ... and right after the timed steps
     smi_after = _smi_snapshot() if rank == 0 else None
     final_loss = float(loss.detach())
@@ -387,7 +437,7 @@ def main(argv=None):
                        "shader_clock_mhz_before": round(clock_before, 1), "shader_clock_mhz_after": round(clock_after, 1),
                        "shader_clock_note": "ctmi_clock_probe: s_memtime / s_memrealtime of one wave while 2048 workgroups issue bf16 MFMAs (~6 ms), "
                                             "launched right before / right after the timed region; the 2.5 PF peak assumes 2400 MHz",
-                       "smi_before": smi_before, "smi_after": smi_after},
+                       "smi_before": smi_before, "smi_after": smi_after, "power_while_stepping": sampler.summary() if sampler is not None else None},
             "final_loss": round(final_loss, 4), "host_enqueue_ms_per_step": round(host_enqueue_ms, 2),
             "host_loop_ms_per_step_in_timed_region": round(host_loop_s / args.steps * 1e3, 2),
             # the step-level fraction — algorithmic FLOPs of the whole step (6 N_mm + 6 L S H per token, attention
