@@ -117,7 +117,10 @@ def main(argv):
     for zeros in modes:
         tag = " [zero operands]" if zeros else ""
         if "gemm" in which or "vendor" in which or "wgrad" in which:
+            only = os.environ.get("EP_ONLY")                               # e.g. EP_ONLY=4hh,h4h
             for name, N, K in (("qkv", 3 * H, H), ("h4h", 4 * H, H), ("4hh", H, 4 * H), ("lm_head", V, H)):
+                if only and name not in only.split(","):
+                    continue
                 x, w, dy = rnd(T, K, zeros=zeros), rnd(N, K, zeros=zeros), rnd(T, N, zeros=zeros)
                 fl = 2.0 * T * N * K
                 if "wgrad" in which:                                     # weight gradients only (tile / split rules come from the environment: CTMI_WGRAD_RULE, ...)
