@@ -10,7 +10,8 @@ invisible in the source and in any parity test; this tool makes it visible.
 
 For every kernel of csrc/gemm.hip (three translation-unit parts) and csrc/attention_w32.hip: compile to assembly (device only), find the
 innermost loops that contain >= 8 MFMAs and >= 1 LDS-DMA instruction in <= 400 lines (the steady loops), and report every `s_waitcnt` with
-`vmcnt(0)` in them that is NOT inside an inline-asm region.  Exit status 1 if there is any.
+`vmcnt(0)` in them that is NOT inside an inline-asm region — and every hand-written (inline-asm) `vmcnt(N)` of a steady loop whose N is not a
+multiple of the pieces the loop issues per trip (a miscounted immediate).  Exit status 1 if there is any.
 
     python tools/kernel_isa_scan.py            # all kernels
     python tools/kernel_isa_scan.py --one "bf16_t, false, true, 0, 4, 4, true, false, false" [-DFLAG=1 ...]   # one GEMM instantiation (seconds)
@@ -74,7 +75,7 @@ def scan(path):
             nd = sum(("global_load_lds" in x) or ("buffer_load" in x and " lds" in x) for x in body)
             if nm < 8 or nd < 1:
                 continue
-            in_asm, bad = False, []
+            in_asm, bad, counted = False, [], []
             for j, x in enumerate(body):
                 if "ASMSTART" in x:
                     in_asm = True
@@ -82,7 +83,11 @@ def scan(path):
                     in_asm = False
                 elif not in_asm and re.search(r"s_waitcnt\b.*vmcnt\(0\)", x):
                     bad.append(s + j + 1)
-            res.append((s + 1, e - s, nm, nd, bad))
+                elif in_asm:
+                    m = re.search(r"s_waitcnt\b.*vmcnt\((\d+)\)", x)
+                    if m:
+                        counted.append(int(m.group(1)))
+            res.append((s + 1, e - s, nm, nd, bad, counted))
         out.append((names[k].replace("unsigned short", "bf16"), res))
     return out
 
@@ -104,8 +109,15 @@ def main(argv):
     seen = set()
     for f in files:
         for kern, loops in scan(f):
-            for (s, n, nm, nd, bad) in loops:
+            for (s, n, nm, nd, bad, counted) in loops:
                 nloops += 1
+                # the hand-counted wait of a steady loop leaves a WHOLE number of trips' pieces in flight (each trip issues `nd` pieces): an
+                # immediate that is not a multiple of nd is a miscount (the side-piece experiments, built with their flags, are the exception)
+                odd = [c for c in counted if n <= 200 and c > 0 and c % nd]
+                if odd and (f, s) not in seen:
+                    seen.add((f, s))
+                    nbad += 1
+                    print(f"BAD  {kern}: steady loop at {os.path.basename(f)}:{s} issues {nd} LDS-DMA pieces per trip but waits with vmcnt{odd}")
                 key = (f, tuple(bad))
                 if bad and key not in seen:
                     seen.add(key)
@@ -114,7 +126,7 @@ def main(argv):
                     nnote += not steady
                     print(f"{'BAD ' if steady else 'note'} {kern}: {'steady loop' if steady else 'K-loop with in-body tile switch'} at {os.path.basename(f)}:{s} "
                           f"({n} lines, {nm} MFMAs, {nd} LDS-DMA pieces) has compiler-made vmcnt(0) at lines {bad}")
-    print(f"{nloops} loops scanned in {len(files)} assembly files ({tmp}): {nbad} steady loops with a compiler-made s_waitcnt vmcnt(0), {nnote} notes")
+    print(f"{nloops} loops scanned in {len(files)} assembly files ({tmp}): {nbad} steady loops flagged (compiler-made s_waitcnt vmcnt(0) / miscounted hand-written wait), {nnote} notes")
     return 1 if nbad or not nloops else 0
 
 
