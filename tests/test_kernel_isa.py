@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_no_compiler_made_vmcnt0_in_a_steady_k_loop():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_isa_scan.py")], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
-    assert " 0 steady loops with" in r.stdout, r.stdout[-2000:]
+    assert " 0 steady loops flagged" in r.stdout, r.stdout[-2000:]
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
@@ -26,3 +26,12 @@ def test_the_lint_sees_the_round3_structure():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_isa_scan.py"), "--one", "bf16_t, false, true, 0, 4, 4, true, false, false",
                         "-DCTMI_PP_FAST_NONPLAIN=1", "-DCTMI_PP_SIDE_LDS=0"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 1 and "BAD " in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_the_lint_sees_a_wait_that_is_not_a_whole_number_of_trips():
+    """second class (round 4): a steady loop's hand-written `vmcnt(N)` must leave a whole number of trips' LDS-DMA pieces in flight.  The
+    side-input-through-LDS experiment (one extra piece every third K-step, waits spelled vmcnt(7)) is the build that breaks the rule on purpose."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_isa_scan.py"), "--one", "bf16_t, false, true, 2, 4, 4, true, false, false",
+                        "-DCTMI_PP_SIDE_LDS=1", "-DCTMI_PP_K2=0"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 1 and "pieces per trip but waits with vmcnt" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
