@@ -24,115 +24,19 @@
 #endif
 #define CTMI_GEMM_HAS(p) (CTMI_GEMM_PART == -1 || CTMI_GEMM_PART == (p))
 
-// Ping-pong epilogue re-layout.  0 (default): 128-row tiles (WM = 4) re-layout across lanes with v_permlane16_swap, 256-row tiles
-// through the per-wave LDS patches; 1: LDS patches everywhere (A/B builds).  Same-box A/B of "cross-lane everywhere" against
-// "patches everywhere" (bf16, T = 8192): 256x256 tiles — row-major-B [T,4H] output +9 % (939 -> 1019 TF/s), K-major-B [T,4H]
-// output neutral, logits-sized output 8 % SLOWER (64-byte instead of 128-byte row segments per store instruction; 3.80 ->
-// 4.13 ms, which decides it for this tile); 128x256 tiles — +2 % per kernel (inside the noise), 189 -> 159 VGPRs, and no
-// patches: 96 instead of 128 KiB of LDS, which is what a side-stream weight-gradient workgroup needs to share the CU (the
-// side stream's gain in the step went from 0.6 to 1.2 ms).
-#ifndef CTMI_EPI_SHUFFLE
-#define CTMI_EPI_SHUFFLE 0
-#endif
-// LDS-DMA ring depth.  Free-running tiles: 3 stages.  Ping-pong: 4 stages + 4 x 8 KiB epilogue patches; the 128-row tile's
-// cross-lane epilogue needs no patches (96 KiB).  Its 24 KiB stages would fit six times into 160 KiB (five K-steps of prefetch
-// instead of three): measured same-box in round 3, that was neutral per kernel and 0.3 ms/step WORSE in the training step — the 64 KiB it
-// left free let a weight-gradient workgroup of the side stream share the CU.  CTMI_PP128_RING keeps the knob for -DCTMI_PP_K2=0 builds;
-// since round 4 the tile runs the two-stages-per-phase schedule below on a 6-stage ring (and the weight gradients take whole CUs).
-#ifndef CTMI_PP128_RING
-#define CTMI_PP128_RING 4
-#endif
-// (CTMI_PP256X_RING: ring depth of the 256-row ping-pong tile with the cross-lane epilogue — no patches, so a fifth 32 KiB stage fits the
-// 160 KiB: one more K-step of DMA lead for operands that come from HBM rather than L2; round-4 experiment, tools/chain_probe.py)
-#ifndef CTMI_PP256X_RING
-#define CTMI_PP256X_RING 4
-#endif
-// CTMI_PP_K2 (round 4): the 128-row ping-pong tile consumes TWO 32-k ring stages per phase — 16 fragment reads + 6 DMA pieces | 32 MFMAs —
-// instead of one (8 + 3 | 16).  A phase of that tile costs ~730 cycles whatever it contains (r03_gemm_anatomy.txt) against 272 cycles of MFMAs:
-// most of it is latency (LDS round trip, DMA issue, two barriers) that a phase pays once, so twice the work per phase nearly halves it per FLOP.
-// Needs a 6-stage ring (144 KiB: no co-resident workgroup — none wanted since the weight gradients moved to this tile) and 32 more registers.
-#ifndef CTMI_PP_K2
-#define CTMI_PP_K2 1
-#endif
-// CTMI_PP_SPLIT2 (round 4 experiment, 256-row ping-pong tiles): in the STEADY loop a wave issues only its two A pieces of the new stage in the
-// load phase and its two B pieces inside the MFMA phase (after the 8th and the 24th of the 32 MFMAs).  Why: the load phase (12 fragment reads
-// + 4 pieces, ~830 cycles) is longer than the partner group's 544 cycles of MFMAs, and most of it is the four pieces — four waves issuing
-// beside fragment reads get ~44 B/clk out of the CU's DMA path, eight waves 64 (profiles/r04_dma_issue_probe.txt).  At K-step boundaries the
-// ring is in the same state as without the split (r3's CTMI_PP_SPLIT_DMA did this in the generic step only, with its bookkeeping).
-#ifndef CTMI_PP_SPLIT2
-#define CTMI_PP_SPLIT2 0
-#endif
-constexpr bool glds_k2(bool pp, int wm) { return CTMI_PP_K2 && pp && wm == 4 && !CTMI_EPI_SHUFFLE; }
-constexpr int glds_ring(bool pp, int wm, bool xlane = false) { return !pp ? 3 : (glds_k2(pp, wm) ? 6 : ((wm == 4 && !CTMI_EPI_SHUFFLE) ? CTMI_PP128_RING : ((xlane && wm == 8) ? CTMI_PP256X_RING : 4))); }
-constexpr int glds_patch_bytes(bool pp, int wm, bool xlane = false) { return (pp && !xlane && !(wm == 4 && !CTMI_EPI_SHUFFLE)) ? 4 * 8192 : 0; }
-// XLANE instantiations of the 256-row ping-pong tile: cross-lane epilogue there too (no patches).  Per launch, not per tile: it is the
-// better epilogue for a row-major-B [T,4H]-sized output and the worse one for the logits (see the note above), so the launcher
-// picks by output size (forward layout, no residual, not logits-sized).  Same-box A/B in round 2: h->4h forward with GELU 75.9 vs
-// 78.1 us, plain 67.7-69.3 vs 69.4-70.2, QKV forward +0.5 %; training step 42.56 vs 42.65 ms (3 interleaved runs each).
-// Ping-pong schedule: issue the B-operand LDS-DMA pieces of a stage inside the MFMA phase (between the matrix instructions) instead of
-// in the load phase with the A pieces.  tools/gemm_anatomy.py: a phase costs 730-830 cycles whatever its matrix work (272 / 544
-// cycles of MFMA) — the load phase (fragment reads + 3-4 DMA issues at ~150 cycles each beside ds_reads) sets the pace; a DMA issue among
-// bare MFMAs costs ~60.
-#ifndef CTMI_PP_SPLIT_DMA
-#define CTMI_PP_SPLIT_DMA 0    // measured (profiles/r03_gemm_split_dma.txt): 256-row tiles 3-10 % slower, 128-row tiles 5 % faster in the K-loop; not adopted
-#endif
-// Ping-pong schedule: four K-steps per trip with compile-time ring positions (the ring has four stages) and the steady-state waits
-// spelled out, instead of one generic step per trip.  tools/gemm_anatomy.py (profiles/r03_gemm_anatomy.txt): the LOAD segment of a
-// phase pair takes ~590 cycles against 544 cycles of MFMAs in the other row group — ~60 instructions at ~5 cycles of issue each plus
-// four LDS-DMA stalls — and about half of those instructions are ring / work-item bookkeeping the generic step recomputes.
-// Built and measured (profiles/r03_gemm_unroll.txt): the unrolled body itself compiles to 12 reads + the DMA block + two waits per
-// step, but hipcc renames the 128 accumulator registers across the four steps and restores them through scratch at the back edge
-// (256-row tiles 6x slower); 128-row tiles +2-5 % at K >= 3072 and -8...-23 % at K = 1024.  Off.
-#ifndef CTMI_PP_UNROLL
-#define CTMI_PP_UNROLL 0
-#endif
-// Ping-pong schedule: a STEADY inner loop — as many K-steps as fit before either side (the MFMA side's tile, the DMA side's work item,
-// three stages ahead) reaches a boundary — with one trip counter and none of the generic step's per-step checks (more work? item
-// switch? ring fill? ablation switches?).  The generic step stays for ring fill / drain.  tools/gemm_anatomy.py: the load segment of a
-// step (~64 instructions, half of them bookkeeping, at ~5 cycles of issue each + four LDS-DMA stalls) is longer than the 544 cycles
-// of MFMAs it should hide behind.
-#ifndef CTMI_TILE_RULES_R3
-#define CTMI_TILE_RULES_R3 1   // 0 = the round-2 tile rules, for A/B runs (profiles/r03_gemm_tile_sweep.txt)
-#endif
-#ifndef CTMI_PP_STEADY
-#define CTMI_PP_STEADY 1
-#endif
-#ifndef CTMI_PP256_XLANE
-#define CTMI_PP256_XLANE 1
-#endif
-// Ping-pong load phase: issue the stage's LDS-DMA pieces BEFORE the fragment reads (the slot they overwrite was retired by the barrier
-// that opens the phase, so the order inside the phase is free).  Round-4 experiment (profiles/r04_gemm_load_phase.txt).
-#ifndef CTMI_PP_DMA_FIRST
-#define CTMI_PP_DMA_FIRST 0
-#endif
-// Ping-pong priorities: 0 = s_setprio 1 around every MFMA phase (rounds 1-3); 1 = static: the later-dispatched row group (waves 4-7) runs
-// at priority 1 for the whole kernel, no per-phase flips; 2 = no priorities at all.
-// (1 since round 4: three same-box A/B runs, each 0.1 - 0.15 ms per step in its favour — 39.49 / 39.71 vs 39.61 / 39.88 on the round-3 kernels,
-// 37.17 - 37.30 vs 37.28 - 37.47 on the final ones; the guide's "static priority for the younger half, no per-segment flips")
-#ifndef CTMI_PP_PRIO
-#define CTMI_PP_PRIO 1
-#endif
-// Side-input tile through LDS (round 4; r3 verdict item 2).  The epilogues that read a second [M,N] operand — the activation-
-// derivative input of the 4h->h data gradient (DGELU / MUL / DRELU) and the residual rows of the [T,H]-output forwards — fetched it with
-// global loads when the epilogue started: 64 KiB per 128x256 tile that every CU asks for at the same moment, queued behind the LDS-DMA
-// pieces of the next tile's first stages (vector memory returns in order) — ~12 000 cycles per tile, 119.8 us for a launch whose plain form
-// takes 68.  Here the side tile is a THIRD LDS-DMA operand: every wave issues one 1-KiB piece of it (two tile rows) every third K-step
-// (K-steps 1, 4, ..., 22 of the tile it belongs to — after both row groups have left the previous tile's epilogue, so one 64 KiB buffer
-// serves all tiles), and the epilogue reads it with ds_read_b128 (16-byte chunks XOR-swizzled with the row, conflict-free).  The fetch is
-// spread over ~20 000 cycles of K-loop instead of stalling the epilogue.  Costs the whole 160 KiB of LDS (96 ring + 64 side) for these
-// launches: no co-resident side-stream workgroup while they run.  Tiles with fewer than 32 K-steps or at a matrix edge keep the global loads.
-// MEASURED, NOT ADOPTED (profiles/r04_side_lds.txt, same box, interleaved, both arms with the K-loop wait fix): DGELU data gradient 112-114 us
-// against 96-97 with the register prefetch below (plain: 69), MUL 103-106 vs 94, residual forwards equal, training step 40.1-40.3 vs 39.3-39.4 ms —
-// also in the first version, whose pieces had one K-step instead of three to land (107 vs 92 us).  With the K-loop no longer drained every step
-// the epilogue's own loads are not what these kernels wait for any more; 64 KiB more LDS and 8 more DMA pieces per wave and tile cost more
-// than they hide.  Default 0; the code stays for the next attempt (a side tile in REGISTERS needs 32 VGPRs the 128-row tile has).
-#ifndef CTMI_PP_SIDE_LDS
-#define CTMI_PP_SIDE_LDS 0
-#endif
-constexpr bool glds_side_lds(bool pp, int wm, int epi, bool res) {
-    return CTMI_PP_SIDE_LDS && pp && wm == 4 && !CTMI_EPI_SHUFFLE && CTMI_PP128_RING == 4 &&
-           (epi == CTMI_EPI_DGELU || epi == CTMI_EPI_DRELU || epi == CTMI_EPI_MUL || res);
-}
+// LDS-DMA ring depth and epilogue re-layout of the bf16 fast path (gemm_glds_kernel below).
+//   free-running tiles (4 waves): 3 stages.
+//   256-row ping-pong tile (8 waves): 4 stages of 32 KiB; logits-sized outputs re-layout through 4 x 8 KiB per-wave LDS patches (128-byte row
+//     segments per store instruction), every other forward-layout output takes the XLANE instantiation: cross-lane re-layout, no patches.
+//   128-row ping-pong tile: cross-lane re-layout (v_permlane16_swap), no patches, and TWO 32-k ring stages per phase (K2): 16 fragment reads +
+//     6 DMA pieces | 32 MFMAs over a 6-stage ring of 24 KiB stages (144 KiB).  A phase costs ~730 cycles whatever it contains against 272
+//     cycles of MFMAs per stage: most of it is latency (LDS round trip, DMA issue, two barriers) that a phase pays once.
+// Everything that was measured and NOT adopted in rounds 1-4 (per-phase wave priorities, a fifth ring stage, DMA pieces before the fragment
+// reads or inside the MFMA phase, a 4-step unrolled trip, the side-input tile through LDS or requested early, the timing / ablation
+// instrumentation) lives as patches under tools/experiments/ (README.md there has the numbers), not as #if branches in this file.
+constexpr bool glds_k2(bool pp, int wm) { return pp && wm == 4; }
+constexpr int glds_ring(bool pp, int wm, bool xlane = false) { return !pp ? 3 : (glds_k2(pp, wm) ? 6 : 4); }
+constexpr int glds_patch_bytes(bool pp, int wm, bool xlane = false) { return (pp && !xlane && wm != 4) ? 4 * 8192 : 0; }
 
 
 template <typename T> struct Tile;
@@ -249,19 +153,6 @@ template <> __device__ __forceinline__ float OpTile<float, true, 128>::frag(cons
     return tile[kofs * PITCH + r16 + (lane & 15)];
 }
 
-// Timing-ablation switches (no steady-state DMA / no barrier / no LDS reads / ...), driven by the CTMI_GEMM_DBG environment
-// variable (0 = everything on).
-#ifndef CTMI_GEMM_DBG_BUILD
-#define CTMI_GEMM_DBG_BUILD 1
-#endif
-// (Compiling the switches out — GEMM_DBG(g) == 0 — was measured same-box against keeping them: LM-head dgrad +3.5 %, but the
-// training step 0.35 ms SLOWER (42.63 vs 42.26 ms, 3 interleaved runs each): the free-running layer kernels' schedule shifts.  So
-// they stay compiled in by default; -DCTMI_GEMM_DBG_BUILD=0 removes them.)
-#if CTMI_GEMM_DBG_BUILD
-#define GEMM_DBG(g) ((g).dbg)
-#else
-#define GEMM_DBG(g) 0
-#endif
 struct GemmArgs {
     const void* A; const void* B; void* C;
     int64_t lda, ldb, ldc, M, N, K;
@@ -271,7 +162,6 @@ struct GemmArgs {
     int nt_c;                                              // C is far larger than the 256 MiB Infinity Cache: write it non-temporally
     int splits; int64_t k_per_split; float* slabs;        // split-K: partial products go to slabs[s][M][N] (fp32)
     int splitk_ok; float* ws; int64_t ws_bytes;           // split-K permission + caller workspace (the launch path decides)
-    int dbg;                                               // -DCTMI_GEMM_DBG_BUILD=1 builds only (CTMI_GEMM_DBG): 1 = no steady-state DMA, 2 = no barrier, 4 = no LDS reads
 };
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -522,18 +412,6 @@ struct GTile {
     }
 };
 
-// -DCTMI_GEMM_TIMING=1 (tools/ variant builds only): wave 0 of every workgroup accumulates s_memtime deltas — prologue (entry ->
-// first K-step), K-loops, epilogues — into a __device__ array read back by ctmi_gemm_debug_ticks_<part>() (tools/gemm_anatomy.py)
-#ifndef CTMI_GEMM_TIMING
-#define CTMI_GEMM_TIMING 0
-#endif
-#if CTMI_GEMM_TIMING
-static __device__ unsigned long long g_gemm_ticks[2048 * 4];
-static __device__ unsigned long long g_gemm_phase[256 * 8];     // wave 0 and wave NW-1 of the first 128 workgroups: issue, waits, barrier 1, MFMAs, barrier 2
-#define GEMM_TICK(acc) do { const unsigned long long now__ = __builtin_amdgcn_s_memtime(); acc += now__ - tlast; tlast = now__; } while (0)
-#else
-#define GEMM_TICK(acc) do { } while (0)
-#endif
 template <typename TO, bool AK, bool BKM, int EPI, int WM, int WGN, bool PP = false, bool RES = false, bool XLANE = false>
 __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
     using T = bf16_t;
@@ -548,13 +426,9 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
     constexpr int PA = TA::NINSTR / NW, PB = TB::NINSTR / NW;               // DMA instructions per wave per stage
     constexpr int LOADS = PA + PB;
     static_assert(PP ? (LOADS == 3 || LOADS == 4) : (LOADS == 4 || LOADS == 6), "vmcnt immediates below assume these DMA piece counts");
-    constexpr bool K2 = glds_k2(PP, WM) && CTMI_PP_STEADY && !CTMI_PP_SPLIT_DMA && !CTMI_GEMM_TIMING;   // two ring stages per phase (see CTMI_PP_K2)
+    constexpr bool K2 = glds_k2(PP, WM);                                      // two ring stages per phase
     constexpr int FILL = K2 ? NST - 2 : NST - 1;                              // stages in flight between K-steps (K2: two slots stay free for the pair to issue)
-    constexpr bool SPLIT2 = CTMI_PP_SPLIT2 && PP && WM == 8 && PA == 2 && PB == 2 && CTMI_PP_STEADY && !CTMI_PP_SPLIT_DMA && !CTMI_GEMM_TIMING && !CTMI_PP_DMA_FIRST;
     constexpr int LAND = K2 ? 2 : 1;                                          // stages that have LANDED when a K-step starts (a pair reads two): every counted wait keeps that
-    constexpr bool SIDE_LDS = glds_side_lds(PP, WM, EPI, RES);               // side-input tile as a third LDS-DMA operand (see CTMI_PP_SIDE_LDS)
-    constexpr int SIDE_OFF = NST * STAGE;                                     // 64 KiB behind the ring: [128 rows][256 columns] bf16, 512-byte rows
-    static_assert(!SIDE_LDS || (BM == 128 && BN == 256 && NW == 8 && LOADS == 3), "the side-tile schedule is written for the 128x256 ping-pong tile");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
     const int tiles_m = (int)((g.M + BM - 1) / BM);
@@ -562,13 +436,10 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
     const int ntile = tiles_m * tiles_n;
     const int nwork = ntile * g.splits;                                       // work items: (split, output tile)
     const int bid = blockIdx.x, G = gridDim.x;                                // G == nwork, or a multiple of 8 (persistent)
-#ifndef CTMI_GEMM_GM256
-#define CTMI_GEMM_GM256 4
-#endif
     // (weight-gradient layout on the 256-row tile = the LM head's [V,H] gradient, four tile columns wide: groups of ONE tile row put the four
     // workgroups that share a dlogits panel next to each other in the order — 3.55 vs 3.61 ms, profiles/r03_gemm_tile_sweep.txt; the
     // forward wants 4: 3.85 vs 4.32 ms)
-    constexpr int GM = (WM == 8) ? ((AK && BKM) ? 1 : CTMI_GEMM_GM256) : 8;
+    constexpr int GM = (WM == 8) ? ((AK && BKM) ? 1 : 4) : 8;
     // work item w -> (split, tile origin).  Items w, w+8, w+16, ... run on one XCD (workgroup b lands on XCD b % 8), so
     // each XCD gets a CONTIGUOUS range of the grouped tile order and its private L2 sees the operand panels reused.
     auto decode = [&](int w, int64_t& m0, int64_t& n0, int& split) {
@@ -588,7 +459,7 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
     const int wr = wid / WGN, wc = wid % WGN;
     const T* A = reinterpret_cast<const T*>(g.A);
     const T* B = reinterpret_cast<const T*>(g.B);
-    const int64_t astep = (GEMM_DBG(g) & 8) ? 0 : (AK ? (int64_t)BK * g.lda : BK), bstep = (GEMM_DBG(g) & 8) ? 0 : (BKM ? (int64_t)BK * g.ldb : BK);
+    const int64_t astep = AK ? (int64_t)BK * g.lda : BK, bstep = BKM ? (int64_t)BK * g.ldb : BK;
     const unsigned lds0 = (unsigned)(size_t)smem_raw;
 
     // ---- issue side: the DMA stream runs ahead of the MFMA stream by two K-steps and crosses work-item boundaries,
@@ -636,61 +507,10 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < PB; ++j) pb[j] += bstep;
     };
-    // the same stage in two halves (CTMI_PP_SPLIT_DMA): the A pieces in the load phase, the B pieces one by one inside the MFMA phase
-    auto issue_A = [&](int stage_buf) {
-        const unsigned da = lds0 + AOFF + stage_buf * TA::BYTES + wid * PA * 1024;
-        unsigned keep;
-        if constexpr (!PP) { (void)da; (void)keep; }
-        else if constexpr (PA == 2) {
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-                         "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(pa[0]), "v"(pa[1]), "s"(da) : "memory", "scc");
-        } else {
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(pa[0]), "s"(da) : "memory");
-        }
-#pragma unroll
-        for (int j = 0; j < PA; ++j) pa[j] += astep;
-    };
-    auto issue_B = [&](int stage_buf, int jb) {
-        glds16(pb[jb], lds0 + BOFF + stage_buf * TB::BYTES + (wid * PB + jb) * 1024);
-        pb[jb] += bstep;
-    };
     auto stage_issued = [&]() {                                               // bookkeeping after a whole stage went out
         if (++ti == nti) { wi += G; if (wi < nwork) setup_issue(); }
     };
 
-    // side-input tile of the output tile being computed: on for interior tiles with >= 32 K-steps (the pieces go out at K-steps 1, 5, .., 29
-    // and have landed two steps after the last of them); wave w's piece i = rows 2*(8w+i), +1 of the tile, lane L -> row 2q + (L>>5),
-    // LDS chunk slot L&31 <- global chunk (L&31) ^ (row&15)
-    // Early side-input prefetch (round 4; r3 verdict item 2): the activation-derivative input / residual rows of BOTH epilogue passes are
-    // requested when the DMA stream crosses to the next output tile — three K-steps before this tile's epilogue — into the 32 registers the
-    // 128-row tile has to spare, instead of at the start of the epilogue (where they queued behind the next tile's first stages and then paid
-    // a full HBM latency per pass).  Ordinary loads: hipcc tracks them; the counted waits of the K-steps in between allow for them.
-    // MEASURED, NOT ADOPTED (profiles/r04_side_early.txt, same box, interleaved): DGELU data gradient 102-103 us against 97 with the prefetch at
-    // the start of the epilogue, MUL 97-100 vs 97-99, training step 39.54-39.77 vs 39.20-39.33 ms.  Neither WHEN the side tile is requested
-    // (this), nor through WHAT (the LDS variant above), nor its arithmetic (MUL = one multiply costs what dGELU costs) moves the ~27 us over the
-    // plain kernel: 64 MiB more from HBM in a 70 us launch whose 256 workgroups finish their tiles together.  Default 0.
-#ifndef CTMI_PP_SIDE_EARLY
-#define CTMI_PP_SIDE_EARLY 0
-#endif
-    constexpr bool SIDE_EARLY = CTMI_PP_SIDE_EARLY && CTMI_PP_STEADY && !CTMI_PP_SPLIT_DMA && !CTMI_GEMM_TIMING && !SIDE_LDS && PP && WM == 4 && !CTMI_EPI_SHUFFLE &&
-                                LOADS == 3 && ((EPI == CTMI_EPI_DGELU || EPI == CTMI_EPI_DRELU || EPI == CTMI_EPI_MUL) || RES);
-    static_assert(!(K2 && (SIDE_LDS || SIDE_EARLY)), "the side-input experiments spell their counted waits for one stage per phase: build them with -DCTMI_PP_K2=0");
-    uint4 sp00, sp01, sp02, sp03, sp10, sp11, sp12, sp13;                      // (eight named values, not an array: as an array captured by the epilogue lambda hipcc kept it in scratch memory)
-    sp00 = sp01 = sp02 = sp03 = sp10 = sp11 = sp12 = sp13 = make_uint4(0u, 0u, 0u, 0u);
-    bool spre_on = false;
-    bool side_on = false;
-    auto issue_side = [&](int i, const int64_t m0, const int64_t n0) {
-        if constexpr (SIDE_LDS) {
-            constexpr bool AUXS = (EPI == CTMI_EPI_DGELU || EPI == CTMI_EPI_DRELU || EPI == CTMI_EPI_MUL);
-            const T* sp = reinterpret_cast<const T*>(AUXS ? g.aux_in : g.residual);
-            const int q = wid * 8 + i;
-            const int row = 2 * q + (lane_ >> 5);
-            const int c = (lane_ & 31) ^ (row & 15);
-            glds16(sp + (m0 + row) * g.ldc + n0 + c * 8, lds0 + SIDE_OFF + q * 1024);
-        }
-    };
 
     f32x4 acc[WM][4];
 #pragma unroll
@@ -729,13 +549,6 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
     // Interior tiles with aligned pointers (the common case) take a straight-line epilogue: no per-lane bounds test, so
     // hipcc emits no exec-masked branches around the vector loads/stores; edge tiles take the guarded path.
     const bool interior = g.vec_c && (m0 + BM <= g.M) && (n0 + BN <= g.N);
-    if (GEMM_DBG(g) & 16) {                                                        // ablation: keep the accumulators live, store nothing
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[i][j]));
-        return;
-    }
     if constexpr (PP) {
         // LDS-shuffled epilogue: the MFMA accumulator layout (lane = one row, 4 columns) makes 8-byte stores that touch
         // 16 rows per instruction; measured on the LM-head forward those stores cost 26 % of the kernel.  Each wave
@@ -748,10 +561,7 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
         // ring, in every 128-row and every XLANE ping-pong kernel (~190 of the step's layer-GEMM launches; found in round 4, see
         // tools/kernel_isa_scan.py, which now checks every instantiation).  The combinations this excludes (a residual on a kernel that
         // was not instantiated for it, beta with a bf16 output) do not occur on the training path; they take the guarded epilogue below.
-#ifndef CTMI_PP_FAST_NONPLAIN
-#define CTMI_PP_FAST_NONPLAIN 0     // 1 = rounds 1-3 (non-plain variants of the cross-lane epilogue compiled in): A/B builds, profiles/r04_kloop_vmcnt0.txt
-#endif
-        constexpr bool USE_DIRECT = ((!CTMI_EPI_SHUFFLE && WM == 4) || XLANE) && !CTMI_PP_FAST_NONPLAIN;
+        constexpr bool USE_DIRECT = WM == 4 || XLANE;
         constexpr bool RES_IN_KERNEL = RES && WM == 4 && !(EPI == CTMI_EPI_DGELU || EPI == CTMI_EPI_DRELU || EPI == CTMI_EPI_MUL);   // == PRE_RES below
         const bool plain_tile = (RES_IN_KERNEL || R == nullptr) && !g.beta;
         if (interior && g.vec8 && (!USE_DIRECT || plain_tile)) {
@@ -783,10 +593,8 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
                     const uint4 tb = pack16<T>(v);
                     // the pre-activation is kept for the BACKWARD only (a whole forward and half a backward away): CTMI_GELU_AUX_NT writes it
                     // non-temporally, so that the activation next to it — the A operand of the very next GEMM — is what stays in the caches
-#ifndef CTMI_GELU_AUX_NT
-#define CTMI_GELU_AUX_NT 1      // (same box, interleaved: forward chain of 24 blocks 6.16 / 6.26 -> 6.07 / 6.05 ms, step 37.01-37.35 -> 36.83-37.08 ms)
-#endif
-                    if constexpr (CTMI_GELU_AUX_NT && sizeof(T) == 2) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, tb), reinterpret_cast<u32x4*>(AUXO + off));   // (the builtin, not asm: hipcc's hazard recognizer does not see into asm, and a first asm version — no wait state between the 16-byte store and the next write of its data registers — stored garbage in a few rows; tests/test_gpu_ops.py::test_gemm_at_the_step_shapes_sampled_vs_fp64 caught it)
+                    // (same box, interleaved: forward chain of 24 blocks 6.16 / 6.26 -> 6.07 / 6.05 ms, step 37.01-37.35 -> 36.83-37.08 ms)
+                    if constexpr (sizeof(T) == 2) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, tb), reinterpret_cast<u32x4*>(AUXO + off));   // (the builtin, not asm: hipcc's hazard recognizer does not see into asm, and a first asm version — no wait state between the 16-byte store and the next write of its data registers — stored garbage in a few rows; tests/test_gpu_ops.py::test_gemm_at_the_step_shapes_sampled_vs_fp64 caught it)
                     else *reinterpret_cast<uint4*>(AUXO + off) = tb;
                     unpack16<T>(tb, v);
 #pragma unroll
@@ -847,18 +655,8 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
                             for (int r = 0; r < 4; ++r) { v[r] += c0v[r]; v[4 + r] += c1v[r]; }
                         }
                     }
-                    // weight gradients (both operands K-major, fp32 out): written once, read by the optimizer a whole backward later —
-                    // CTMI_WGRAD_NT stores them non-temporally
-#ifndef CTMI_WGRAD_NT
-#define CTMI_WGRAD_NT 0
-#endif
-                    if constexpr (CTMI_WGRAD_NT && AK && BKM && PLAIN) {
-                        asm volatile("global_store_dwordx4 %0, %1, off nt\n\tglobal_store_dwordx4 %0, %2, off offset:16 nt\n\ts_nop 1"
-                                     :: "v"(Cf), "v"(f32x4{v[0], v[1], v[2], v[3]}), "v"(f32x4{v[4], v[5], v[6], v[7]}) : "memory");
-                    } else {
-                        *reinterpret_cast<f32x4*>(Cf) = f32x4{v[0], v[1], v[2], v[3]};
-                        *reinterpret_cast<f32x4*>(Cf + 4) = f32x4{v[4], v[5], v[6], v[7]};
-                    }
+                    *reinterpret_cast<f32x4*>(Cf) = f32x4{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(Cf + 4) = f32x4{v[4], v[5], v[6], v[7]};
                 } else {
                     if constexpr (!PLAIN) {
                         if (g.beta) {
@@ -937,42 +735,16 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
                 const int64_t offL = (mw + (lane & 15)) * g.ldc + nw + 16 * (q & 1) + 8 * (q >> 1);
                 const int64_t row16 = 16 * g.ldc;
                 uint4 pre[2][PRE ? 4 : 1];
-                // side tile in LDS (SIDE_LDS, this tile's side_on): row wr*64 + 16 i + (lane&15), chunk wc*8 + 4 jp + 2 (q&1) + (q>>1), stored at
-                // chunk ^ (row & 15): two lane-constant addresses (jp = 0 / 1) + an immediate per i
-                const unsigned char* sl0 = smem_raw + SIDE_OFF + (wr * 64 + (lane & 15)) * 512 + (((wc * 8 + 2 * (q & 1) + (q >> 1)) ^ (lane & 15)) << 4);
-                const unsigned char* sl1 = smem_raw + SIDE_OFF + (wr * 64 + (lane & 15)) * 512 + (((wc * 8 + 4 + 2 * (q & 1) + (q >> 1)) ^ (lane & 15)) << 4);
                 auto prefetch = [&](int p, int slot) {
                     if constexpr (PRE) {
-                        if (SIDE_LDS && side_on) {
 #pragma unroll
-                            for (int it = 0; it < 4; ++it) pre[slot][it] = *reinterpret_cast<const uint4*>(((it & 1) ? sl1 : sl0) + (p * 2 + (it >> 1)) * (16 * 512));
-                        } else {
-#pragma unroll
-                            for (int it = 0; it < 4; ++it) {
-                                const uint4* sp_ = reinterpret_cast<const uint4*>(side + offL + (p * 2 + (it >> 1)) * row16 + 32 * (it & 1));
-#ifndef CTMI_SIDE_NT
-#define CTMI_SIDE_NT 0
-#endif
-                                // the activation-derivative input is read here for the last time (CTMI_SIDE_NT: non-temporal load; not the residual rows)
-                                if constexpr (CTMI_SIDE_NT && PRE_AUX) pre[slot][it] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(sp_)));
-                                else pre[slot][it] = *sp_;
-                            }
-                        }
+                        for (int it = 0; it < 4; ++it) pre[slot][it] = *reinterpret_cast<const uint4*>(side + offL + (p * 2 + (it >> 1)) * row16 + 32 * (it & 1));
                     }
                 };
-                bool early = false;
-                if constexpr (SIDE_EARLY && PRE) {
-                    early = spre_on;
-                    if (early) {
-                        pre[0][0] = sp00; pre[0][1] = sp01; pre[0][2] = sp02; pre[0][3] = sp03;
-                        pre[1][0] = sp10; pre[1][1] = sp11; pre[1][2] = sp12; pre[1][3] = sp13;
-                        spre_on = false;
-                    }
-                }
-                if (!early) prefetch(0, 0);
+                prefetch(0, 0);
 #pragma unroll
                 for (int p = 0; p < WM / 2; ++p) {
-                    if (p + 1 < WM / 2 && !early) prefetch(p + 1, (p + 1) & 1);
+                    if (p + 1 < WM / 2) prefetch(p + 1, (p + 1) & 1);
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {
                         const int i = p * 2 + (it >> 1), jp = it & 1;
@@ -997,15 +769,7 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
             };
             const bool plain = (PRE_RES || R == nullptr) && !g.beta;
             constexpr bool CAN_NT = sizeof(TO) == 2 && EPI == CTMI_EPI_NONE && !RES;
-            if constexpr (CTMI_PP_FAST_NONPLAIN && ((!CTMI_EPI_SHUFFLE && WM == 4) || XLANE)) {
-                if (g.bias != nullptr) {
-                    if (plain) direct(std::true_type{}, std::integral_constant<bool, CAN_NT>{}, std::true_type{});
-                    else direct(std::false_type{}, std::false_type{}, std::true_type{});
-                } else {
-                    if (plain) direct(std::true_type{}, std::integral_constant<bool, CAN_NT>{}, std::false_type{});
-                    else direct(std::false_type{}, std::false_type{}, std::false_type{});
-                }
-            } else if constexpr (USE_DIRECT) {
+            if constexpr (USE_DIRECT) {
                 static_assert(RES_IN_KERNEL == PRE_RES, "the plain test in front of the fast path must match the variant compiled here");
                 if (g.bias != nullptr) direct(std::true_type{}, std::integral_constant<bool, CAN_NT>{}, std::true_type{});
                 else direct(std::true_type{}, std::integral_constant<bool, CAN_NT>{}, std::false_type{});
@@ -1108,10 +872,6 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
     }
     };
 
-#if CTMI_GEMM_TIMING
-    unsigned long long tlast = __builtin_amdgcn_s_memtime(), t_pro = 0, t_loop = 0, t_epi = 0;
-    const unsigned long long t_begin = tlast;
-#endif
     setup_issue();
     int inflight = 0;                                                         // stages issued and not yet consumed
     int rd = 0, wrb = 0;                                                      // ring positions: read stage, next write stage
@@ -1124,21 +884,13 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
         // RAW: a stage is read one full K-step after every wave's counted wait for it (the lagging group's wait
         // precedes the barrier the leading group passes before reading).  WAR: stage c+NST-1 reuses the slot of stage c-1,
         // whose last reads (lagging group, phase A of c-1) were retired by lgkmcnt(0) before the barrier in between.
+        // Wave priorities are static: the later-dispatched row group (waves 4-7) runs at priority 1 for the whole kernel, no per-phase flips.
         auto wait_stages = [&](int n) {                                       // allow n younger stages to stay in flight
             static_assert(LOADS == 3 || LOADS == 4, "counted waits are spelled out for 3 or 4 DMA instructions per stage");
             static_assert(NST <= 6, "wait_stages covers rings of up to 6 stages");
             if (n >= 4 && NST >= 6) { if (LOADS == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
             else if (n >= 3 && NST >= 5) { if (LOADS == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); }
             else if (n >= 2) { if (LOADS == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
-            else if (n == 1) { if (LOADS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        };
-        // split issue: `n` younger stages may stay in flight, the youngest of them (if `half`) with its A pieces only
-        auto wait_split = [&](int n, bool half) {
-            static_assert(NST == 4 || !CTMI_PP_SPLIT_DMA, "the split-issue waits are spelled out for the 4-stage ring");
-            if (n >= 2 && half) { if (LOADS == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-            else if (n >= 2) { if (LOADS == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
-            else if (n == 1 && half) { if (LOADS == 4) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); }
             else if (n == 1) { if (LOADS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         };
@@ -1150,296 +902,140 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
         wait_stages(inflight - LAND);
         __builtin_amdgcn_s_barrier();
         if (wr == 1) __builtin_amdgcn_s_barrier();                            // stagger the two row groups by one phase
-        if constexpr (CTMI_PP_PRIO == 1) { if (wr == 1) __builtin_amdgcn_s_setprio(1); }
-        GEMM_TICK(t_pro);
-#if CTMI_GEMM_TIMING
-        unsigned long long ph_issue = 0, ph_wait = 0, ph_bar1 = 0, ph_mfma = 0, ph_bar2 = 0;
-#endif
+        if (wr == 1) __builtin_amdgcn_s_setprio(1);
         int cw = bid, tc = 0, ntc;
         int64_t m0, n0; int split;
         decode(cw, m0, n0, split);
         ntc = (int)((min(g.K, (int64_t)(split + 1) * g.k_per_split) - (int64_t)split * g.k_per_split) / BK);
-        bool early_ok = false;                                                    // this tile's epilogue will take the fast cross-lane path with a side input
-        int snext = 1, sidx = 0, slast = -8;                                     // next K-step that issues a side piece, pieces issued for this tile, step of the newest
-        auto arm_side = [&]() {
-            if constexpr (SIDE_EARLY) {
-                constexpr bool AUXS = (EPI == CTMI_EPI_DGELU || EPI == CTMI_EPI_DRELU || EPI == CTMI_EPI_MUL);
-                early_ok = g.vec_c && g.vec8 && (m0 + BM <= g.M) && (n0 + BN <= g.N) && g.splits == 1 && !g.beta && (AUXS ? g.residual == nullptr : true) && ntc >= 4;
-                spre_on = false;
-            }
-            if constexpr (SIDE_LDS) {
-                side_on = g.vec_c && g.vec8 && (m0 + BM <= g.M) && (n0 + BN <= g.N) && ntc >= 32 && g.splits == 1 && !GEMM_DBG(g);
-                snext = 1; sidx = 0; slast = -8;
-            }
-        };
-        arm_side();
         for (;;) {
             bool tile_done = false;
-            if constexpr (CTMI_PP_UNROLL && NST == 4 && !CTMI_PP_SPLIT_DMA && !CTMI_GEMM_TIMING) {
-                // steady state: ring at position 0 with three stages in flight, >= 4 K-steps left in this tile and >= 4 stages left to issue
-                // (the issue side runs three stages ahead and may cross into the next work item inside the group)
-                // — and all four of THIS work item: the switch to the next item (setup_issue: 64-bit address arithmetic that needs scratch
-                // registers) stays out of the unrolled body; it happens at the end of the trip or in a generic step
-                while (rd == 0 && inflight == NST - 1 && ntc - tc >= 4 && !GEMM_DBG(g) && wi < nwork && nti - ti >= 4) {
+            // STEADY inner loops — as many K-steps as fit before either side (the MFMA side's tile, the DMA side's work item, FILL stages
+            // ahead) reaches a boundary — with one trip counter and none of the generic step's per-step checks (more work? item switch? ring
+            // fill?).  The generic step below stays for ring fill / drain.  (A loop around them since round 4: after the DMA stream's switch
+            // to the next work item the remaining K-steps of THIS tile run steady too.)
+            while (!tile_done && inflight == FILL && wi < nwork) {
+                if constexpr (K2) {
+                    // pairs of K-steps while both sides (this tile, the DMA stream's work item) have two left: stages rd, rd+1 are read, the pair
+                    // rd+4, rd+5 goes into the two free slots, the counted wait leaves exactly that pair in flight (rd+2, rd+3 have landed for
+                    // the next pair), 32 MFMAs: first all sixteen accumulators with stage rd, then again with rd+1 (no back-to-back dependency)
+                    const int npair = min(ntc - tc, nti - ti) >> 1;
+#pragma unroll 1
+                    for (int n = npair; n > 0; --n) {
+                        const int rd1 = rd == NST - 1 ? 0 : rd + 1;
+                        short8 af0[WM], bf0[4], af1[WM], bf1[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const unsigned char* as = smem_raw + AOFF + u * TA::BYTES;
-                        const unsigned char* bs = smem_raw + BOFF + u * TB::BYTES;
-                        short8 af[WM], bf[4];
+                        for (int j = 0; j < 4; ++j) bf0[j] = TB::frag(smem_raw + BOFF + rd * TB::BYTES, wc * 64 + j * 16, lane);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) bf[j] = TB::frag(bs, wc * 64 + j * 16, lane);
+                        for (int i = 0; i < WM; ++i) af0[i] = TA::frag(smem_raw + AOFF + rd * TA::BYTES, wr * (WM * 16) + i * 16, lane);
 #pragma unroll
-                        for (int i = 0; i < WM; ++i) af[i] = TA::frag(as, wr * (WM * 16) + i * 16, lane);
-                        issue_stage((u + 3) & 3);
-                        ++ti;
+                        for (int j = 0; j < 4; ++j) bf1[j] = TB::frag(smem_raw + BOFF + rd1 * TB::BYTES, wc * 64 + j * 16, lane);
+#pragma unroll
+                        for (int i = 0; i < WM; ++i) af1[i] = TA::frag(smem_raw + AOFF + rd1 * TA::BYTES, wr * (WM * 16) + i * 16, lane);
+                        issue_stage(wrb);
+                        wrb = wrb == NST - 1 ? 0 : wrb + 1;
+                        issue_stage(wrb);
+                        wrb = wrb == NST - 1 ? 0 : wrb + 1;
                         wait_stages(2);
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         __builtin_amdgcn_sched_barrier(0);
                         __builtin_amdgcn_s_barrier();
                         __builtin_amdgcn_sched_barrier(0);
-                        __builtin_amdgcn_s_setprio(1);
-                        // in-place accumulation spelled as asm ("+v": destination == C operand): with the builtin hipcc renames the 128
-                        // accumulator registers from step to step and restores them through scratch at the back edge of the trip
 #pragma unroll
                         for (int i = 0; i < WM; ++i)
 #pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(bf[j]), "v"(af[i]));
-                        __builtin_amdgcn_s_setprio(0);
+                            for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(bf0[j], af0[i], acc[i][j]);
+#pragma unroll
+                        for (int i = 0; i < WM; ++i)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(bf1[j], af1[i], acc[i][j]);
                         __builtin_amdgcn_sched_barrier(0);
                         __builtin_amdgcn_s_barrier();
                         __builtin_amdgcn_sched_barrier(0);
+                        rd = rd1 == NST - 1 ? 0 : rd1 + 1;
                     }
+                    ti += 2 * npair;
+                    tc += 2 * npair;
                     if (ti == nti) { wi += G; if (wi < nwork) setup_issue(); }
-                    tc += 4;
                     if (tc == ntc) { tile_done = true; break; }
+                    if (npair > 0) continue;                                  // re-evaluate: the next run may again hold pairs
                 }
-            }
-            if constexpr (CTMI_PP_STEADY && !CTMI_PP_SPLIT_DMA && !CTMI_GEMM_TIMING) {
-                // (a loop since round 4: after the DMA stream's switch to the next work item the remaining K-steps of THIS tile run steady too,
-                // in the same pass — the early side-input prefetch below is issued there and consumed by this tile's epilogue further down)
-                while (!tile_done && inflight == FILL && wi < nwork && !GEMM_DBG(g)) {
-                    if constexpr (K2) {
-                        // pairs of K-steps while both sides (this tile, the DMA stream's work item) have two left: stages rd, rd+1 are read, the pair
-                        // rd+4, rd+5 goes into the two free slots, the counted wait leaves exactly that pair in flight (rd+2, rd+3 have landed for
-                        // the next pair), 32 MFMAs: first all sixteen accumulators with stage rd, then again with rd+1 (no back-to-back dependency)
-                        const int npair = min(ntc - tc, nti - ti) >> 1;
+                const int nsteady = min(ntc - tc, nti - ti);                  // >= 1 on both sides here
 #pragma unroll 1
-                        for (int n = npair; n > 0; --n) {
-                            const int rd1 = rd == NST - 1 ? 0 : rd + 1;
-                            short8 af0[WM], bf0[4], af1[WM], bf1[4];
+                for (int n = nsteady; n > 0; --n) {
+                    const unsigned char* as = smem_raw + AOFF + rd * TA::BYTES;
+                    const unsigned char* bs = smem_raw + BOFF + rd * TB::BYTES;
+                    short8 af[WM], bf[4];
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) bf0[j] = TB::frag(smem_raw + BOFF + rd * TB::BYTES, wc * 64 + j * 16, lane);
+                    for (int j = 0; j < 4; ++j) bf[j] = TB::frag(bs, wc * 64 + j * 16, lane);
 #pragma unroll
-                            for (int i = 0; i < WM; ++i) af0[i] = TA::frag(smem_raw + AOFF + rd * TA::BYTES, wr * (WM * 16) + i * 16, lane);
+                    for (int i = 0; i < WM; ++i) af[i] = TA::frag(as, wr * (WM * 16) + i * 16, lane);
+                    issue_stage(wrb);
+                    wait_stages(FILL - LAND);                                 // (one stage consumed, one issued: FILL - LAND of the FILL younger ones may fly)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) bf1[j] = TB::frag(smem_raw + BOFF + rd1 * TB::BYTES, wc * 64 + j * 16, lane);
+                    for (int i = 0; i < WM; ++i)
 #pragma unroll
-                            for (int i = 0; i < WM; ++i) af1[i] = TA::frag(smem_raw + AOFF + rd1 * TA::BYTES, wr * (WM * 16) + i * 16, lane);
-                            issue_stage(wrb);
-                            wrb = wrb == NST - 1 ? 0 : wrb + 1;
-                            issue_stage(wrb);
-                            wrb = wrb == NST - 1 ? 0 : wrb + 1;
-                            wait_stages(2);
-                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                            __builtin_amdgcn_sched_barrier(0);
-                            __builtin_amdgcn_s_barrier();
-                            __builtin_amdgcn_sched_barrier(0);
-                            if constexpr (CTMI_PP_PRIO == 0) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(bf0[j], af0[i], acc[i][j]);
-#pragma unroll
-                            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(bf1[j], af1[i], acc[i][j]);
-                            if constexpr (CTMI_PP_PRIO == 0) __builtin_amdgcn_s_setprio(0);
-                            __builtin_amdgcn_sched_barrier(0);
-                            __builtin_amdgcn_s_barrier();
-                            __builtin_amdgcn_sched_barrier(0);
-                            rd = rd1 == NST - 1 ? 0 : rd1 + 1;
-                        }
-                        ti += 2 * npair;
-                        tc += 2 * npair;
-                        if (ti == nti) { wi += G; if (wi < nwork) setup_issue(); }
-                        if (tc == ntc) { tile_done = true; break; }
-                        if (npair > 0) continue;                                  // re-evaluate: the next run may again hold pairs
-                    }
-                    int spre_steps = 0;                                           // steady steps whose counted wait must allow the 8 prefetch loads
-                    if constexpr (SIDE_EARLY) {
-                        if (!spre_on && early_ok && ntc - tc <= 3) {
-                            constexpr bool AUXS = (EPI == CTMI_EPI_DGELU || EPI == CTMI_EPI_DRELU || EPI == CTMI_EPI_MUL);
-                            const T* sp = reinterpret_cast<const T*>(AUXS ? g.aux_in : g.residual);
-                            int ln = lane_;
-                            asm volatile("" : "+v"(ln));                          // (as in the epilogue: keep this address arithmetic out of the loops above)
-                            const int q = ln >> 4;
-                            const int64_t offL = (m0 + wr * (WM * 16) + (ln & 15)) * g.ldc + n0 + wc * 64 + 16 * (q & 1) + 8 * (q >> 1);
-                            const int64_t row16 = 16 * g.ldc;
-                            auto ld = [&](int pp, int it) { return *reinterpret_cast<const uint4*>(sp + offL + (pp * 2 + (it >> 1)) * row16 + 32 * (it & 1)); };
-                            sp00 = ld(0, 0); sp01 = ld(0, 1); sp02 = ld(0, 2); sp03 = ld(0, 3);
-                            sp10 = ld(1, 0); sp11 = ld(1, 1); sp12 = ld(1, 2); sp13 = ld(1, 3);
-                            spre_on = true;
-                            spre_steps = 2;                                       // the loads are younger than the stage a step waits for during two steps
-                        }
-                    }
-                    const int nsteady = min(ntc - tc, nti - ti);                  // >= 1 on both sides here
-                    int sc = tc;                                                  // K-step of the tile (side-tile schedule)
-#pragma unroll 1
-                    for (int n = nsteady; n > 0; --n) {
-                        const unsigned char* as = smem_raw + AOFF + rd * TA::BYTES;
-                        const unsigned char* bs = smem_raw + BOFF + rd * TB::BYTES;
-                        short8 af[WM], bf[4];
-                        if constexpr (CTMI_PP_DMA_FIRST) issue_stage(wrb);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) bf[j] = TB::frag(bs, wc * 64 + j * 16, lane);
-#pragma unroll
-                        for (int i = 0; i < WM; ++i) af[i] = TA::frag(as, wr * (WM * 16) + i * 16, lane);
-                        if constexpr (SPLIT2) issue_A(wrb);
-                        else if constexpr (!CTMI_PP_DMA_FIRST) issue_stage(wrb);
-                        bool swin = false;
-                        if constexpr (SIDE_LDS) {
-                            // AFTER the stage: the piece is then younger than the stage needed three steps from now, so (vector memory
-                            // returns in order) it has the same three K-steps to land as a ring stage.  One piece every third step, steps
-                            // 1, 4, .., 22: while the newest piece is at most two steps old it sits among the operations allowed to stay in
-                            // flight (two stages of three pieces + it = 7; pieces are >= 3 steps apart, so never two); the last one has landed
-                            // by step 25.  (Issued BEFORE the stage — the
-                            // first version — a piece had to land within ONE step: the kernel was 15 % slower than the register prefetch.)
-                            if (side_on && sc >= snext && sidx < 8) { issue_side(sidx, m0, n0); ++sidx; snext = sc + 3; slast = sc; }
-                            swin = sc - slast <= 2;                               // a side piece issued at this or one of the two previous steps
-                            ++sc;
-                        }
-                        if (SIDE_LDS && swin) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-                        else if (SIDE_EARLY && spre_steps > 0) { asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); --spre_steps; }   // 2 stages x 3 pieces + 8 loads
-                        else if constexpr (SPLIT2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // stage c+2 whole (4 pieces) + the two A pieces just issued may fly
-                        else wait_stages(FILL - LAND);                            // (one stage consumed, one issued: FILL - LAND of the FILL younger ones may fly)
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        __builtin_amdgcn_sched_barrier(0);
-                        __builtin_amdgcn_s_barrier();
-                        __builtin_amdgcn_sched_barrier(0);
-                        if constexpr (CTMI_PP_PRIO == 0) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                        for (int i = 0; i < WM; ++i)
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                acc[i][j] = Mma<T>::mma(bf[j], af[i], acc[i][j]);
-                                if constexpr (SPLIT2) {
-                                    if (i * 4 + j == 7 || i * 4 + j == 23) {
-                                        __builtin_amdgcn_sched_barrier(0);
-                                        issue_B(wrb, i * 4 + j == 7 ? 0 : 1);
-                                        __builtin_amdgcn_sched_barrier(0);
-                                    }
-                                }
-                            }
-                        if constexpr (CTMI_PP_PRIO == 0) __builtin_amdgcn_s_setprio(0);
-                        __builtin_amdgcn_sched_barrier(0);
-                        __builtin_amdgcn_s_barrier();
-                        __builtin_amdgcn_sched_barrier(0);
-                        if constexpr ((NST & (NST - 1)) == 0) { rd = (rd + 1) & (NST - 1); wrb = (wrb + 1) & (NST - 1); }
-                        else { rd = rd == NST - 1 ? 0 : rd + 1; wrb = wrb == NST - 1 ? 0 : wrb + 1; }
-                    }
-                    ti += nsteady;
-                    tc += nsteady;
-                    if (ti == nti) { wi += G; if (wi < nwork) setup_issue(); }
-                    if (tc == ntc) tile_done = true;
+                        for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(bf[j], af[i], acc[i][j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr ((NST & (NST - 1)) == 0) { rd = (rd + 1) & (NST - 1); wrb = (wrb + 1) & (NST - 1); }
+                    else { rd = rd == NST - 1 ? 0 : rd + 1; wrb = wrb == NST - 1 ? 0 : wrb + 1; }
                 }
+                ti += nsteady;
+                tc += nsteady;
+                if (ti == nti) { wi += G; if (wi < nwork) setup_issue(); }
+                if (tc == ntc) tile_done = true;
             }
             if (!tile_done) {
+            // generic step: ring fill / drain
             const unsigned char* as = smem_raw + AOFF + rd * TA::BYTES;
             const unsigned char* bs = smem_raw + BOFF + rd * TB::BYTES;
             short8 af[WM], bf[4];
-#if CTMI_GEMM_TIMING
-            unsigned long long pl = __builtin_amdgcn_s_memtime();
-#define PH_TICK(acc) do { const unsigned long long n__ = __builtin_amdgcn_s_memtime(); acc += n__ - pl; pl = n__; } while (0)
-#else
-#define PH_TICK(acc) do { } while (0)
-#endif
-            const bool more = wi < nwork && !(GEMM_DBG(g) & 1);
-            if constexpr (CTMI_PP_DMA_FIRST && !CTMI_PP_SPLIT_DMA) {
-                if (more) {
-                    issue_stage(wrb);
-                    stage_issued(); ++inflight; wrb = wrb == NST - 1 ? 0 : wrb + 1;
-                }
-            }
-            if (!(GEMM_DBG(g) & 4) || tc == 0) {
+            const bool more = wi < nwork;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) bf[j] = TB::frag(bs, wc * 64 + j * 16, lane);
+            for (int j = 0; j < 4; ++j) bf[j] = TB::frag(bs, wc * 64 + j * 16, lane);
 #pragma unroll
-                for (int i = 0; i < WM; ++i) af[i] = TA::frag(as, wr * (WM * 16) + i * 16, lane);
+            for (int i = 0; i < WM; ++i) af[i] = TA::frag(as, wr * (WM * 16) + i * 16, lane);
+            if (more) {
+                issue_stage(wrb);
+                stage_issued(); ++inflight; wrb = wrb == NST - 1 ? 0 : wrb + 1;
             }
-            if constexpr (CTMI_PP_SPLIT_DMA) {
-                if (more) { issue_A(wrb); ++inflight; }
-                wait_split(inflight - 2, more);
-            } else {
-                if (more && !CTMI_PP_DMA_FIRST) {
-                    issue_stage(wrb);
-                    stage_issued(); ++inflight; wrb = wrb == NST - 1 ? 0 : wrb + 1;
-                }
-                if constexpr (SIDE_LDS) {
-                    if (side_on && tc >= snext && sidx < 8) { issue_side(sidx, m0, n0); ++sidx; snext = tc + 3; slast = tc; }
-                }
-                PH_TICK(ph_issue);
-                // (generic steps ignore the side piece in their count: the plain wait is merely stricter by that one piece — loads return in order)
-                wait_stages(inflight - 1 - LAND);
-            }
+            wait_stages(inflight - 1 - LAND);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            PH_TICK(ph_wait);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            PH_TICK(ph_bar1);
-            if constexpr (CTMI_PP_PRIO == 0) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc[i][j] = Mma<T>::mma(bf[j], af[i], acc[i][j]);
-                    if constexpr (CTMI_PP_SPLIT_DMA) {
-                        constexpr int NM = WM * 4;
-                        const int idx = i * 4 + j;
-                        if (idx == NM / 4 - 1 || idx == (3 * NM) / 4 - 1) {
-                            if (more) issue_B(wrb, idx == NM / 4 - 1 ? 0 : 1);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
-                }
-            if constexpr (CTMI_PP_SPLIT_DMA) {
-                if (more) { stage_issued(); wrb = wrb == NST - 1 ? 0 : wrb + 1; }
-            }
-            if constexpr (CTMI_PP_PRIO == 0) __builtin_amdgcn_s_setprio(0);
-            PH_TICK(ph_mfma);
+                for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(bf[j], af[i], acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            PH_TICK(ph_bar2);
             rd = rd == NST - 1 ? 0 : rd + 1;
             --inflight;
             if (++tc < ntc) continue;
             }
-            GEMM_TICK(t_loop);
             epilogue(m0, n0, split);
-            GEMM_TICK(t_epi);
             cw += G;
             if (cw >= nwork) break;
             decode(cw, m0, n0, split);
             ntc = (int)((min(g.K, (int64_t)(split + 1) * g.k_per_split) - (int64_t)split * g.k_per_split) / BK);
             tc = 0;
-            arm_side();
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         if (wr == 0) __builtin_amdgcn_s_barrier();
-#if CTMI_GEMM_TIMING
-        if (tid == 0 && bid < 2048) { g_gemm_ticks[bid * 4] = t_pro; g_gemm_ticks[bid * 4 + 1] = t_loop; g_gemm_ticks[bid * 4 + 2] = t_epi; g_gemm_ticks[bid * 4 + 3] = __builtin_amdgcn_s_memtime() - t_begin; }
-        if (lane == 0 && (wid == 0 || wid == NW - 1) && bid < 128) {
-            unsigned long long* d = g_gemm_phase + (bid * 2 + (wid == 0 ? 0 : 1)) * 8;
-            d[0] = ph_issue; d[1] = ph_wait; d[2] = ph_bar1; d[3] = ph_mfma; d[4] = ph_bar2;
-        }
-#endif
         return;
     }
+    // ---- free-running schedule (4 waves, 2-3 workgroups per CU): one barrier per K-step, the DMA issues of the stage two K-steps ahead spread
+    // between the MFMAs
 #pragma unroll 1
     for (int s = 0; s < 2 && wi < nwork; ++s) {
 #pragma unroll
@@ -1447,7 +1043,6 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
         stage_issued(); ++inflight; wrb = wrb == NST - 1 ? 0 : wrb + 1;
     }
     // ---- compute side
-    GEMM_TICK(t_pro);
     int cw = bid, tc = 0, ntc;
     int64_t m0, n0; int split;
     decode(cw, m0, n0, split);
@@ -1459,17 +1054,15 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
         // they have to be, are covered by the same count).
         if (inflight >= 2) { if (LOADS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!(GEMM_DBG(g) & 2)) __builtin_amdgcn_s_barrier();                      // everyone's stage landed; the previous one is fully consumed
-        const bool more = (wi < nwork) && !(GEMM_DBG(g) & 1);
+        __builtin_amdgcn_s_barrier();                      // everyone's stage landed; the previous one is fully consumed
+        const bool more = wi < nwork;
         const unsigned char* as = smem_raw + AOFF + rd * TA::BYTES;
         const unsigned char* bs = smem_raw + BOFF + rd * TB::BYTES;
         short8 af[WM], bf[4];
-        if (!(GEMM_DBG(g) & 4) || tc == 0) {
 #pragma unroll
-            for (int i = 0; i < WM; ++i) af[i] = TA::frag(as, wr * (WM * 16) + i * 16, lane);
+        for (int i = 0; i < WM; ++i) af[i] = TA::frag(as, wr * (WM * 16) + i * 16, lane);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bf[j] = TB::frag(bs, wc * 64 + j * 16, lane);
-        }
+        for (int j = 0; j < 4; ++j) bf[j] = TB::frag(bs, wc * 64 + j * 16, lane);
         __builtin_amdgcn_s_setprio(1);                                        // MFMA phase outranks the partner wave's DMA / epilogue issue
         // the DMA issues of the stage two K-steps ahead are spread between the MFMAs (an LDS-DMA issue costs ~60-180
         // cycles of the wave's issue slot; back-to-back they would stall the matrix pipe for a whole K-step)
@@ -1489,9 +1082,7 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
         --inflight;
         if (more) { stage_issued(); ++inflight; wrb = wrb == NST - 1 ? 0 : wrb + 1; }
         if (++tc < ntc) continue;
-        GEMM_TICK(t_loop);
         epilogue(m0, n0, split);
-        GEMM_TICK(t_epi);
         cw += G;
         if (cw >= nwork) break;
         decode(cw, m0, n0, split);
@@ -1502,9 +1093,6 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-#if CTMI_GEMM_TIMING
-    if (tid == 0 && bid < 2048) { g_gemm_ticks[bid * 4] = t_pro; g_gemm_ticks[bid * 4 + 1] = t_loop; g_gemm_ticks[bid * 4 + 2] = t_epi; g_gemm_ticks[bid * 4 + 3] = __builtin_amdgcn_s_memtime() - t_begin; }
-#endif
 }
 
 // C[m,n] = alpha * sum_s slabs[s][m][n] (+ C_old)   — deterministic split-K reduction
@@ -1528,8 +1116,7 @@ static int reserved_cus();
 template <typename TO, bool AK, bool BKM, int EPI, int WM, int WGN, bool PP = false, bool RES = false, bool XLANE = false>
 static void glds_launch(GemmArgs& g, hipStream_t st) {
     constexpr int BM = WM * 32, BN = WGN * 64;
-    const size_t lds = glds_ring(PP, WM, XLANE) * (size_t)(GTile<AK, BM>::BYTES + GTile<BKM, BN>::BYTES) + glds_patch_bytes(PP, WM, XLANE) +
-                       (glds_side_lds(PP, WM, EPI, RES) ? 65536 : 0);
+    const size_t lds = glds_ring(PP, WM, XLANE) * (size_t)(GTile<AK, BM>::BYTES + GTile<BKM, BN>::BYTES) + glds_patch_bytes(PP, WM, XLANE);
     const int64_t nwork = cdiv64(g.M, BM) * cdiv64(g.N, BN) * g.splits;
     // persistent launch: one resident workgroup per occupancy slot (256 CUs x workgroups that fit a CU's 160 KiB LDS),
     // each walking work items bid, bid+G, ... with its DMA stream prefetching across item boundaries
@@ -1597,12 +1184,7 @@ extern "C" int ctmi_get_launch_policy(int* shared, int* reserve_cus) {
 }
 #endif
 
-#ifndef CTMI_WGRAD_ITEMS_TILE0
-#define CTMI_WGRAD_ITEMS_TILE0 256
-#endif
-#ifndef CTMI_WGRAD_ITEMS
-#define CTMI_WGRAD_ITEMS 256     // (same-box A/B vs 512: -0.15 ms per step — half the fp32 slab traffic) split-K target of the layer weight gradients: work items (tiles x splits) to aim for
-#endif
+constexpr int64_t WGRAD_ITEMS = 256;     // round-3 rule (CTMI_WGRAD_RULE=0): split-K target of the layer weight gradients, work items (tiles x splits) to aim for
 // layer weight-gradient rule (CTMI_WGRAD_RULE): 0 = round 3 (128x128 / 256x128 free-running tiles, co-resident with the data gradients),
 // 1 = 128x256 ping-pong unsplit, 2 (default since round 4) = the same with split-K up to CTMI_WGRAD_ITEMS4 (128) work items: at Bloom-560M the
 // QKV gradient (96 tiles) splits two ways, the dense one (32 tiles) four ways, the two [4H,H] ones (128 tiles) stay whole
@@ -1667,29 +1249,26 @@ static void pick_tile(int64_t M, int64_t N, int64_t K, bool wgrad, bool bkm, int
         }
         else {
             // round 3 (profiles/r03_gemm_tile_sweep.txt): a weight gradient with >= 256 tiles of 128x128 (h->4h and 4h->h) runs them
-            // UNSPLIT (CTMI_WGRAD_ITEMS_TILE0 = 256).  Alone on the GPU that is the slowest choice (602-621 TF/s, one workgroup per
+            // UNSPLIT (WGRAD_ITEMS = 256).  Alone on the GPU that is the slowest choice (602-621 TF/s, one workgroup per
             // CU; split two ways 778-805; the round-2 256x128 tiles split two ways 651-693) — in the training step it is the fastest:
             // 39.63 / 39.99 ms against 40.22 / 40.64 (split two ways) and 40.40 / 40.51 (round-2 rule), same box, interleaved.  The
             // weight gradients run on the side stream under the data-gradient chain: what counts there is how little they take from
             // the main stream (no fp32 slabs, no reduce launch, one co-resident workgroup per CU), not their own duration.
-            const bool t0_fills = CTMI_TILE_RULES_R3 && t0 >= 256;
+            const bool t0_fills = t0 >= 256;
             tile = t0_fills ? 0 : (t1 >= 128 ? 1 : 0);
             const int64_t tiles = tile ? t1 : t0;
-            const int64_t items = t0_fills ? CTMI_WGRAD_ITEMS_TILE0 : CTMI_WGRAD_ITEMS;
+            const int64_t items = WGRAD_ITEMS;
             while (splits < max_splits && tiles * splits < items && K / (splits * 2) >= 1024) splits *= 2;
         }
     } else if (K >= 32768 && max_splits >= 2 && t2 * 2 >= 192) { tile = 3; splits = 2; }
     else if (t2 >= tile3_min()) tile = 3;                                         // (also where 256x256 tiles fill their last round badly — QKV forward: 384
                                                                                   // tiles = 1.5 rounds; onto 768 tiles of 128x256 it is +4 % alone and 0.1 ms WORSE in the step, round 4)
-    else if (t4 >= 256 && (CTMI_TILE_RULES_R3 || !bkm || K <= 1024)) tile = 4;                                  // (round 3: also K-major B with long K — 919 vs 861 TF/s on the QKV data gradient)
+    else if (t4 >= 256) tile = 4;                                  // (round 3: also K-major B with long K — 919 vs 861 TF/s on the QKV data gradient)
     else if (t1 >= 700) tile = 1;
     else tile = 0;
     // epilogues that read a second [M,N] operand (activation-derivative input): only the 128-row ping-pong tile has the
     // registers to prefetch it a pass ahead (measured 112 vs 121 us on the [T,4H] DGELU dgrad)
-#ifndef CTMI_GEMM_MUL_TILE3
-#define CTMI_GEMM_MUL_TILE3 0
-#endif
-    if ((epi == CTMI_EPI_DGELU || epi == CTMI_EPI_DRELU || (epi == CTMI_EPI_MUL && !CTMI_GEMM_MUL_TILE3)) && tile == 3) tile = 4;
+    if ((epi == CTMI_EPI_DGELU || epi == CTMI_EPI_DRELU || epi == CTMI_EPI_MUL) && tile == 3) tile = 4;
     if (force >= 0) tile = force;
 }
 
@@ -1720,7 +1299,7 @@ static int gemm_launch(GemmArgs& g, bool fast, hipStream_t st) {
             constexpr bool CAN_RES = (EPI == CTMI_EPI_NONE) && !AK && sizeof(TO) == 2;      // residual-prefetching instantiations
             const bool res = CAN_RES && g.residual != nullptr;
             // forward-layout (row-major B) outputs that are not logits-sized: the 256-row tile with the cross-lane epilogue
-            constexpr bool CAN_XLANE = CTMI_PP256_XLANE && !AK && !BKM && sizeof(TO) == 2 && (EPI == CTMI_EPI_NONE || EPI == CTMI_EPI_GELU);
+            constexpr bool CAN_XLANE = !AK && !BKM && sizeof(TO) == 2 && (EPI == CTMI_EPI_NONE || EPI == CTMI_EPI_GELU);
             bool xl = false;
             if constexpr (CAN_XLANE) xl = tile == 3 && !g.nt_c && !res && g.vec8;
             if (xl) { if constexpr (CAN_XLANE) glds_launch<TO, AK, BKM, EPI, 8, 4, true, false, true>(g, st); }
@@ -1771,16 +1350,7 @@ static int gemm_unsupported(int ak, int bk, int epi, int out_f32) {
     return CTMI_ERR_UNSUPPORTED;
 }
 
-#if CTMI_GEMM_TIMING
-#define CTMI_TICKS_ACCESSOR(name) extern "C" int name(unsigned long long* host_out, int n) { \
-    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gemm_ticks), (size_t)n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; } \
-    extern "C" int name##_phase(unsigned long long* host_out, int n) { \
-    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gemm_phase), (size_t)n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
-#else
-#define CTMI_TICKS_ACCESSOR(name)
-#endif
 #if CTMI_GEMM_HAS(1)
-CTMI_TICKS_ACCESSOR(ctmi_gemm_debug_ticks_nt)
 int ctmi_gemm_bf16_nt(GemmArgs& g, int epi, bool fast, hipStream_t st) {
     if (epi == CTMI_EPI_NONE) return gemm_launch<bf16_t, bf16_t, false, false, CTMI_EPI_NONE>(g, fast, st);
     if (epi == CTMI_EPI_GELU) return gemm_launch<bf16_t, bf16_t, false, false, CTMI_EPI_GELU>(g, fast, st);
@@ -1791,7 +1361,6 @@ int ctmi_gemm_bf16_nt(GemmArgs& g, int epi, bool fast, hipStream_t st) {
 }
 #endif
 #if CTMI_GEMM_HAS(2)
-CTMI_TICKS_ACCESSOR(ctmi_gemm_debug_ticks_nn)
 int ctmi_gemm_bf16_nn(GemmArgs& g, int epi, bool fast, hipStream_t st) {
     if (epi == CTMI_EPI_NONE) return gemm_launch<bf16_t, bf16_t, false, true, CTMI_EPI_NONE>(g, fast, st);
     if (epi == CTMI_EPI_DGELU) return gemm_launch<bf16_t, bf16_t, false, true, CTMI_EPI_DGELU>(g, fast, st);
@@ -1802,7 +1371,6 @@ int ctmi_gemm_bf16_nn(GemmArgs& g, int epi, bool fast, hipStream_t st) {
 }
 #endif
 #if CTMI_GEMM_HAS(3)
-CTMI_TICKS_ACCESSOR(ctmi_gemm_debug_ticks_tn)
 int ctmi_gemm_bf16_tn(GemmArgs& g, int epi, bool fast, hipStream_t st) {
     if (epi == CTMI_EPI_NONE) return gemm_launch<bf16_t, float, true, true, CTMI_EPI_NONE>(g, fast, st);
     return gemm_unsupported(1, 1, epi, 1);
@@ -1875,7 +1443,6 @@ extern "C" int ctmi_gemm(const void* A, int64_t lda, int a_kmajor, const void* B
     g.splits = 1; g.k_per_split = K; g.slabs = nullptr;
     g.splitk_ok = (workspace != nullptr && epilogue == CTMI_EPI_NONE && bias == nullptr && residual == nullptr) ? 1 : 0;
     g.ws = reinterpret_cast<float*>(workspace); g.ws_bytes = workspace_bytes;
-    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("CTMI_GEMM_DBG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
     if (workspace != nullptr && epilogue == CTMI_EPI_NONE && bias == nullptr && residual == nullptr && ntile < 384 && K >= 8 * bkt) {
         int64_t want = std::min<int64_t>(8, cdiv64(512, ntile));
         want = std::min<int64_t>(want, K / (4 * bkt));

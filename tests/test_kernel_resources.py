@@ -58,20 +58,21 @@ def test_attention_head_dim_128_fast_kernels_do_not_spill(kernels):
 
 
 def test_gemm_kernels_fit_their_occupancy(kernels):
+    """Round 5: with the ablation / timing / experiment branches out of csrc/gemm.hip NO LDS-DMA GEMM kernel spills (round 4 shipped the
+    256-row ping-pong tiles at 256 VGPRs + up to 31 spilled), and every tile keeps headroom below its occupancy step."""
     gemms = pick(kernels, "void gemm_glds_kernel<")
     for name, k in gemms.items():
-        assert k["vgpr_count"] <= 256, (name, k["vgpr_count"])                 # two waves per SIMD (eight-wave tiles: one workgroup per CU)
+        assert k["vgpr_count"] <= 240, (name, k["vgpr_count"])                 # two waves per SIMD (eight-wave tiles: one workgroup per CU)
         assert k["agpr_count"] == 0, (name, k["agpr_count"])
-        assert k["vgpr_spill_count"] <= 40, (name, k["vgpr_spill_count"])     # (today: 0 in every K-loop; up to 36 in the 256-row tile's epilogues)
+        assert k["vgpr_spill_count"] == 0 and k.get("private_segment_fixed_size", 0) == 0, (name, k)
     # the 128 x 128 free-running tile: three workgroups per CU
     for name, k in gemms.items():
-        if ", 4, 2, false, false, false>" in name:
-            assert k["vgpr_count"] <= 168 and k["vgpr_spill_count"] == 0, (name, k)
-    # the roofline kernel of bench.py (LM-head forward) and the two epilogue choices of the 256-row tile
-    (name, k), = pick(kernels, "void gemm_glds_kernel<unsigned short, false, false, 0, 8, 4, true, false, false>").items()
-    assert k["vgpr_spill_count"] <= 4, (name, k)      # (since the steady inner loop: two 64-bit values stored once before the K-loops, reloaded in the edge-tile epilogue)
-    (name, k), = pick(kernels, "void gemm_glds_kernel<unsigned short, false, false, 0, 8, 4, true, false, true>").items()
-    assert k["vgpr_spill_count"] == 0, (name, k)
+        if ", 4, 2, false, false, false" in name:
+            assert k["vgpr_count"] <= 168, (name, k)
+    # the 128-row ping-pong tile (two ring stages per phase): the forward / data-gradient / weight-gradient instantiations
+    for name, k in gemms.items():
+        if ", 4, 4, true, " in name:
+            assert k["vgpr_count"] <= 200, (name, k)
 
 
 def test_streaming_kernels_do_not_spill(kernels):

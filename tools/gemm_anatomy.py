@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Per-workgroup cycle anatomy of the LDS-DMA GEMM kernels (variant build -DCTMI_GEMM_TIMING=1): prologue (kernel entry -> first
 K-step), K-loops, epilogues, whole lifetime — s_memtime deltas of wave 0 — next to the HIP-event duration of the launch.
-Build the variant in the build container first:
+Round 5: the instrumentation is no longer in csrc/gemm.hip — apply tools/experiments/gemm_experiment_branches_r04.patch (README.md there says
+to which commit) and build the variant in the build container first:
     python -c "from cleantransformer_amd import _build; _build.build_variant('gemmtiming', ['-DCTMI_GEMM_TIMING=1'])"
 Usage: python tools/gemm_anatomy.py"""
 import ctypes as C

@@ -15,6 +15,7 @@ multiple of the pieces the loop issues per trip (a miscounted immediate).  Exit 
 
     python tools/kernel_isa_scan.py            # all kernels
     python tools/kernel_isa_scan.py --one "bf16_t, false, true, 0, 4, 4, true, false, false" [-DFLAG=1 ...]   # one GEMM instantiation (seconds)
+    python tools/kernel_isa_scan.py --file some.s                                                              # an assembly file that already exists
 """
 import os
 import re
@@ -94,14 +95,18 @@ def scan(path):
 
 def main(argv):
     tmp = tempfile.mkdtemp(prefix="ctmi_isa_")
-    if argv and argv[0] == "--one":
+    if argv and argv[0] == "--file":
+        jobs = None
+        files = list(argv[1:])
+    elif argv and argv[0] == "--one":
         extra = ["-DCTMI_GEMM_PART=9", f"-DCTMI_ONE_KERNEL={argv[1]}", *argv[2:]]
         jobs = [("gemm.hip", os.path.join(tmp, "one.s"), extra)]
     else:
         jobs = [("gemm.hip", os.path.join(tmp, f"gemm_p{p}.s"), [f"-DCTMI_GEMM_PART={p}", *argv]) for p in (1, 2, 3)]
         jobs.append(("attention_w32.hip", os.path.join(tmp, "attention_w32.s"), ["-fno-slp-vectorize", *argv]))
-    with ThreadPoolExecutor(max_workers=4) as ex:
-        files = list(ex.map(lambda j: compile_s(*j), jobs))
+    if jobs is not None:
+        with ThreadPoolExecutor(max_workers=4) as ex:
+            files = list(ex.map(lambda j: compile_s(*j), jobs))
     # Loops of <= 200 lines are the steady K-loops proper (ping-pong: ~100-135 lines).  The free-running schedule keeps its work-item switch
     # (64-bit address set-up, run once per output tile) inside the K-loop's body (~380 lines): a wait there drains the ring once per tile, not
     # once per K-step — reported as a note, not an error.
