@@ -19,7 +19,7 @@ F32, BF16 = 0, 1
 EPI_NONE, EPI_GELU, EPI_DGELU, EPI_RELU, EPI_DRELU, EPI_GELUG, EPI_MUL = 0, 1, 2, 3, 4, 5, 6
 MT_MAX = 24
 PROF_CLASSES = ("gemm_fwd", "gemm_dgrad", "gemm_wgrad", "lm_head", "attn_fwd", "attn_bwd", "layernorm", "loss", "optimizer", "reduce", "other")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 
@@ -37,6 +37,11 @@ class AttnDesc(C.Structure):
 
 class ReduceJob(C.Structure):
     _fields_ = [("src", vp), ("dst", vp), ("n", i64), ("part_stride", i64), ("nparts", i32), ("accumulate", i32), ("alpha", f32), ("pad_", i32)]
+
+
+class WgradProblem(C.Structure):
+    """ctmi_wgrad_problem (include/ctmi355.h)."""
+    _fields_ = [("dy", vp), ("x", vp), ("dw", vp), ("db", vp), ("n_out", i64), ("n_in", i64), ("in_out", i32), ("pad_", i32)]
 
 
 BLK_SLOTS = ("ln1", "mean1", "rstd1", "qkv", "att", "stat_m", "stat_l", "h1", "mean2", "rstd2", "ln2", "u", "g", "out")
@@ -82,6 +87,7 @@ PROTOTYPES = {
     "ctmi_scale_if": (i32, [vp, i64, i64, i64, vp, f32, vp, i32, vp]),
     "ctmi_scale_if_passes": (i64, []),
     "ctmi_reduce_jobs": (i32, [C.POINTER(ReduceJob), i32, vp]),
+    "ctmi_wgrad_grouped": (i32, [C.POINTER(WgradProblem), i32, i64, i32, vp]),
     "ctmi_bloom_block_layout": (i64, [i64, i64, i64, i64, i32, C.POINTER(i64)]),
     "ctmi_bloom_block_fwd": (i32, [C.POINTER(BloomBlock), vp]),
     "ctmi_bloom_block_bwd_ws": (i64, [i64, i64, i64, i64, i32]),

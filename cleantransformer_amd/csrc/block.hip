@@ -3,6 +3,12 @@
 // calls (the round-1 profile had the host enqueue at 26-35 ms per 43 ms step — above the target step time).
 // Host-side orchestration only: every arithmetic step is one of the kernels in gemm.hip / attention.hip / elementwise.hip.
 //
+// Backward, round 5 (bf16, aligned geometry; CTMI_WGRAD_GROUP != 0): the data-gradient chain below runs on the main stream unchanged; the FOUR
+// weight gradients and the column sums of du / dqkv (db1, dbqkv) are ONE grouped launch on the side stream (ctmi_wgrad_grouped, csrc/gemm.hip),
+// forked after the attention backward — when the last of their operands, dqkv, exists — so it runs under the rest of this block's chain and
+// the next block's.  No split-K slabs, no reduce launch, no column-sum launches.  The per-product form below remains for fp32 (parity mode)
+// and shapes outside the grouped kernel's tiling.
+//
 // Backward (pre-LN form; the post-LN switch only moves the residual gradients):
 //   main stream                                         side stream (weight / bias gradients; optional)
 //   du   = (dout W2) * gelu'(u)                          dw2 = dout^T g
@@ -22,6 +28,7 @@ int ctmi_ln_bwd_parts_internal(const void* dy, const void* x, const float* w, co
                                const void* dres, void* dx, float* ws, int64_t rows, int64_t cols, int dtype, int want_sums,
                                int* nparts, int* ns, hipStream_t st);
 int ctmi_colsum_parts_internal(const void* x, int64_t ld, float* ws, int64_t M, int64_t N, int dtype, int* parts_out, hipStream_t st);
+bool ctmi_wgrad_grouped_ok(const ctmi_wgrad_problem* pr, int n, int64_t T, int dtype);      // csrc/gemm.hip
 
 #ifndef CTMI_BLOCK_GELUG
 #define CTMI_BLOCK_GELUG 0      // 1: forward saves gelu'(u) (GELUG) and the backward multiplies (MUL); 0: save u, DGELU epilogue.
@@ -239,9 +246,53 @@ extern "C" int ctmi_bloom_block_bwd(const ctmi_bloom_block* b, const ctmi_bloom_
     };
 
     const void* dout = gr->dout;
+    static int blk_dbg = -1;
+    if (blk_dbg < 0) { const char* e = getenv("CTMI_BLOCK_DBG"); blk_dbg = e ? atoi(e) : 0; }
+    // the four weight gradients as one grouped launch?  (list order = split order: the tiles of the last partial round — dwd, dwqkv at
+    // Bloom-560M — are the ones cut in two along T)
+    ctmi_wgrad_problem wp[4] = {
+        {dout, s.at(CTMI_BLK_G), gr->dw2, nullptr, H, 4 * H, wio ? 1 : 0, 0},
+        {W(W_DU), s.at(CTMI_BLK_LN2), gr->dw1, wio ? nullptr : gr->db1, 4 * H, H, wio ? 1 : 0, 0},
+        {W(W_DH1), s.at(CTMI_BLK_ATT), gr->dwd, nullptr, H, H, wio ? 1 : 0, 0},
+        {W(W_DQKV), s.at(CTMI_BLK_LN1), gr->dwqkv, wio ? nullptr : gr->dbqkv, 3 * H, H, wio ? 1 : 0, 0},
+    };
+    const bool grouped = !(blk_dbg & 1) && ctmi_wgrad_grouped_ok(wp, 4, T, dt);
     // The launches run inside a lambda so that a failure half-way still reaches the join below: the side stream may already hold
     // work that reads the caller's buffers, and the caller (who frees them on error) only orders against the main stream.
     const int rc_launch = [&]() -> int {
+    if (grouped) {
+        RC(linear_dgrad(dout, b->w2, W(W_DU), T, H, 4 * H, CTMI_BLOCK_GELUG ? CTMI_EPI_MUL : CTMI_EPI_DGELU, s.at(CTMI_BLK_U), nullptr, dt, nullptr, 0, main_st, w_io));
+        RC(linear_dgrad(W(W_DU), b->w1, W(W_DLN2), T, 4 * H, H, CTMI_EPI_NONE, nullptr, post ? dout : nullptr, dt, gr->splitk_ws, gr->splitk_ws_bytes, main_st, w_io));
+        int np2 = 0, ns2 = 2;
+        RC(ctmi_ln_bwd_parts_internal(W(W_DLN2), s.at(CTMI_BLK_H1), b->ln2_w, s.at<float>(CTMI_BLK_MEAN2), s.at<float>(CTMI_BLK_RSTD2),
+                                      post ? nullptr : dout, W(W_DH1), WF(W_LNP2), T, H, dt, 1, &np2, &ns2, main_st));
+        job(WF(W_LNP2), ns2 * H, np2, gr->dln2_w, H);
+        job(WF(W_LNP2) + H, ns2 * H, np2, gr->dln2_b, H);
+        RC(linear_dgrad(W(W_DH1), b->wd, W(W_DATT), T, H, H, CTMI_EPI_NONE, nullptr, nullptr, dt, gr->splitk_ws, gr->splitk_ws_bytes, main_st, w_io));
+        const ctmi_attn_desc d = fused_qkv_desc(b);
+        char* qkv = s.at<char>(CTMI_BLK_QKV);
+        char* dqkv = reinterpret_cast<char*>(W(W_DQKV));
+        RC(ctmi_attn_bwd(qkv, qkv + qkv_part(b, 1) * e, qkv + qkv_part(b, 2) * e, s.at(CTMI_BLK_ATT), W(W_DATT), s.at<float>(CTMI_BLK_STAT_M), s.at<float>(CTMI_BLK_STAT_L),
+                         dqkv, dqkv + qkv_part(b, 1) * e, dqkv + qkv_part(b, 2) * e, WF(W_DELTA), b->slopes, b->kpos, b->kvalid, b->first_valid, nullptr, &d, dt, main_st));
+        // every operand of the four weight gradients exists now
+        RC(fork());
+        if (ns2 == 4 && !post) job(WF(W_LNP2) + 2 * H, ns2 * H, np2, gr->db2, H);
+        else RC(colsum_job(dout, H, W_CS_DOUT, gr->db2));
+        if (ns2 == 4) job(WF(W_LNP2) + 3 * H, ns2 * H, np2, gr->dbd, H);
+        else RC(colsum_job(W(W_DH1), H, W_CS_DH1, gr->dbd));
+        if (wio) {                                                        // [in,out] weight gradients: dy is the B operand there, its column sums stay a pass of their own
+            RC(colsum_job(W(W_DU), 4 * H, W_CS_DU, gr->db1));
+            RC(colsum_job(dqkv, 3 * H, W_CS_DQKV, gr->dbqkv));
+        }
+        RC(ctmi_wgrad_grouped(wp, 4, T, dt, pst));
+        RC(linear_dgrad(dqkv, b->wqkv, W(W_DLN1), T, 3 * H, H, CTMI_EPI_NONE, nullptr, post ? W(W_DH1) : nullptr, dt, gr->splitk_ws, gr->splitk_ws_bytes, main_st, w_io));
+        int np1 = 0, ns1 = 2;
+        RC(ctmi_ln_bwd_parts_internal(W(W_DLN1), b->x, b->ln1_w, s.at<float>(CTMI_BLK_MEAN1), s.at<float>(CTMI_BLK_RSTD1),
+                                      post ? nullptr : W(W_DH1), gr->dx, WF(W_LNP1), T, H, dt, 0, &np1, &ns1, main_st));
+        job(WF(W_LNP1), ns1 * H, np1, gr->dln1_w, H);
+        job(WF(W_LNP1) + H, ns1 * H, np1, gr->dln1_b, H);
+        return CTMI_OK;
+    }
     // ---- MLP: out = res2 + W2 gelu(W1 ln2 + b1) + b2
     RC(fork());
     RC(linear_wgrad(dout, s.at(CTMI_BLK_G), gr->dw2, T, H, 4 * H, dt, pws, pws_bytes, pst, wio));
@@ -286,8 +337,9 @@ extern "C" int ctmi_bloom_block_bwd(const ctmi_bloom_block* b, const ctmi_bloom_
     // the end of the whole backward pass) and keeps this call's scratch alive until then; the partial-row reductions then run at the end of
     // the side stream's queue and the main stream goes straight on to the next block — the last weight gradient of a block no longer
     // holds up the first data gradient of the next (measured with the join simply dropped: -0.8 ms per step).
-    if (two && gr->defer_join) {
-        RC(rc_launch);
+    // (a launch that failed half-way takes the JOINED path below even in deferred mode: the side stream may already hold work that reads dout,
+    // the slab and ws, and the caller — who raises before its own record_stream / slot-event bookkeeping — only orders against the main stream)
+    if (two && gr->defer_join && rc_launch == CTMI_OK) {
         RC(fork());                                                             // the LayerNorm partial rows are written on the main stream
         RC(ctmi_reduce_jobs(jobs, nj, side));
         return CTMI_OK;

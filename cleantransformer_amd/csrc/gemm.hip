@@ -164,6 +164,20 @@ struct GemmArgs {
     int splitk_ok; float* ws; int64_t ws_bytes;           // split-K permission + caller workspace (the launch path decides)
 };
 
+// Grouped weight gradients (round 5): ONE persistent launch computes the weight gradients of several Linears — dW_p = dy_p^T x_p, every operand
+// K-major with K = T rows — from a host-built list of work items over 128x256 output tiles.  Whole tiles accumulate over all of K and are stored;
+// the tiles of the last, partial round of the 256 CUs are cut in two along K and their halves are ADDED into zeroed memory with fp32 hardware
+// atomics (exactly two commutative contributions on top of 0: bit-deterministic whatever the arrival order).  The column sums of dy (the bias
+// gradient) ride in the first tile column of a problem: one extra MFMA per A fragment against a fragment of ones.
+constexpr int WG_MAXP = 4;
+struct GroupProb { const void* A; const void* B; float* C; float* cs; int64_t lda, ldb, ldc, M, N; };   // C[M,N] = A^T B, A = [K][M], B = [K][N]; cs[M] = column sums of A (or null)
+struct GroupedArgs : GemmArgs { GroupProb p[WG_MAXP]; const int4* items; int nitems; };
+// work item (int4): x = problem | WG_ATOMIC | WG_COLSUM, y = first row, z = first column of the tile, w = first K-step | K-steps << 16
+constexpr int WG_ATOMIC = 16, WG_COLSUM = 32;
+template <bool GRP, int WM> struct GrpRegs { };
+template <int WM> struct GrpRegs<true, WM> { f32x4 accs[WM]; bool cs_on; };         // column-sum accumulators of the tile, and whether this wave keeps them
+#define WG_ONES8 (short8{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80})   /* eight bf16 1.0 */
+
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <typename TO> __device__ __forceinline__ void store4(TO* p, const float* v);
 template <> __device__ __forceinline__ void store4<float>(float* p, const float* v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
@@ -412,9 +426,10 @@ struct GTile {
     }
 };
 
-template <typename TO, bool AK, bool BKM, int EPI, int WM, int WGN, bool PP = false, bool RES = false, bool XLANE = false>
-__global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
+template <typename TO, bool AK, bool BKM, int EPI, int WM, int WGN, bool PP, bool RES, bool XLANE, bool GRP, typename GA>
+__device__ __forceinline__ void glds_body(const GA g) {   // (by value: through a reference hipcc kept a 16-byte piece of the kernel arguments in scratch memory, reloaded in every epilogue)
     using T = bf16_t;
+    static_assert(!GRP || (PP && WM == 4 && WGN == 4 && AK && BKM && EPI == CTMI_EPI_NONE && sizeof(TO) == 4), "grouped launches: weight gradients on the 128x256 ping-pong tile");
     constexpr int NW = 2 * WGN;                                             // waves: 2 along M x WGN along N
     constexpr int BM = WM * 32, BN = WGN * 64, BK = 32, NST = glds_ring(PP, WM, XLANE);
     using TA = GTile<AK, BM>;
@@ -434,7 +449,9 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
     const int tiles_m = (int)((g.M + BM - 1) / BM);
     const int tiles_n = (int)((g.N + BN - 1) / BN);
     const int ntile = tiles_m * tiles_n;
-    const int nwork = ntile * g.splits;                                       // work items: (split, output tile)
+    int nwork_;
+    if constexpr (GRP) nwork_ = g.nitems; else nwork_ = ntile * g.splits;
+    const int nwork = nwork_;                                                 // work items: (split, output tile) — or the grouped launch's list
     const int bid = blockIdx.x, G = gridDim.x;                                // G == nwork, or a multiple of 8 (persistent)
     // (weight-gradient layout on the 256-row tile = the LM head's [V,H] gradient, four tile columns wide: groups of ONE tile row put the four
     // workgroups that share a dlogits panel next to each other in the order — 3.55 vs 3.61 ms, profiles/r03_gemm_tile_sweep.txt; the
@@ -459,7 +476,8 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
     const int wr = wid / WGN, wc = wid % WGN;
     const T* A = reinterpret_cast<const T*>(g.A);
     const T* B = reinterpret_cast<const T*>(g.B);
-    const int64_t astep = AK ? (int64_t)BK * g.lda : BK, bstep = BKM ? (int64_t)BK * g.ldb : BK;
+    const int64_t astep_c = AK ? (int64_t)BK * g.lda : BK, bstep_c = BKM ? (int64_t)BK * g.ldb : BK;
+    int64_t astep_g = 0, bstep_g = 0;                                         // grouped launches: the K-step strides of the DMA stream's current problem
     const unsigned lds0 = (unsigned)(size_t)smem_raw;
 
     // ---- issue side: the DMA stream runs ahead of the MFMA stream by two K-steps and crosses work-item boundaries,
@@ -468,6 +486,18 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
     const T* pb[PB];
     int wi = bid, ti = 0, nti = 0;                                            // issue-side work item, K-step, K-steps
     auto setup_issue = [&]() {
+        if constexpr (GRP) {
+            const int4 it = g.items[wi];
+            const GroupProb& P = g.p[it.x & (WG_MAXP - 1)];
+            const int64_t kbeg = (int64_t)(it.w & 0xffff) * BK;
+            nti = it.w >> 16; ti = 0;
+            astep_g = (int64_t)BK * P.lda; bstep_g = (int64_t)BK * P.ldb;
+#pragma unroll
+            for (int j = 0; j < PA; ++j) pa[j] = TA::src(reinterpret_cast<const T*>(P.A), P.lda, it.y, P.M, (wid * PA + j) * 64 + lane) + kbeg * P.lda;
+#pragma unroll
+            for (int j = 0; j < PB; ++j) pb[j] = TB::src(reinterpret_cast<const T*>(P.B), P.ldb, it.z, P.N, (wid * PB + j) * 64 + lane) + kbeg * P.ldb;
+            return;
+        }
         int64_t m0, n0; int split;
         decode(wi, m0, n0, split);
         const int64_t kbeg = (int64_t)split * g.k_per_split;
@@ -480,8 +510,8 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
     };
     // one DMA piece (j-th of this wave's LOADS per stage) of the stage being issued; pointers advance
     auto issue_one = [&](int stage_buf, int j) {
-        if (j < PA) { glds16(pa[j], lds0 + AOFF + stage_buf * TA::BYTES + (wid * PA + j) * 1024); pa[j] += astep; }
-        else { const int jb = j - PA; glds16(pb[jb], lds0 + BOFF + stage_buf * TB::BYTES + (wid * PB + jb) * 1024); pb[jb] += bstep; }
+        if (j < PA) { glds16(pa[j], lds0 + AOFF + stage_buf * TA::BYTES + (wid * PA + j) * 1024); pa[j] += (GRP ? astep_g : astep_c); }
+        else { const int jb = j - PA; glds16(pb[jb], lds0 + BOFF + stage_buf * TB::BYTES + (wid * PB + jb) * 1024); pb[jb] += (GRP ? bstep_g : bstep_c); }
     };
     // all pieces of one stage in ONE statement: M0 saved/restored once, the second piece of each operand reached by
     // bumping M0 (the ping-pong schedule issues a stage back-to-back, so the SALU traffic around each DMA matters)
@@ -503,9 +533,9 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
                          : "=&s"(keep) : "v"(pa[0]), "v"(pb[0]), "v"(pb[1]), "s"(da), "s"(db) : "memory", "scc");
         }
 #pragma unroll
-        for (int j = 0; j < PA; ++j) pa[j] += astep;
+        for (int j = 0; j < PA; ++j) pa[j] += (GRP ? astep_g : astep_c);
 #pragma unroll
-        for (int j = 0; j < PB; ++j) pb[j] += bstep;
+        for (int j = 0; j < PB; ++j) pb[j] += (GRP ? bstep_g : bstep_c);
     };
     auto stage_issued = [&]() {                                               // bookkeeping after a whole stage went out
         if (++ti == nti) { wi += G; if (wi < nwork) setup_issue(); }
@@ -518,6 +548,15 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // grouped weight gradients: column sums of the A operand (the bias gradient) of this tile, accumulated by MFMAs against a fragment of ones
+    // (state of the grouped instantiation only: the other kernels do not even declare it)
+    GrpRegs<GRP, WM> gs;
+    if constexpr (GRP) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) gs.accs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gs.cs_on = false;
+    }
+
     auto epilogue = [&](const int64_t m0, const int64_t n0, const int split) {
         // the lane id is laundered through an empty asm so none of the address arithmetic below is loop-invariant for
         // hipcc: hoisted out of the persistent tile loop it stayed live across the MFMA loop, spilled, and every reload
@@ -525,6 +564,56 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
         int lane = lane_;
         asm volatile("" : "+v"(lane));
     // epilogue (same contract as v1): lane holds C[m][n..n+3], m = m0+wr*WM*16+i*16+(lane&15), n = n0+wc*64+j*16+(lane>>4)*4
+    if constexpr (GRP) {
+        // `split` carries the work item's x word: problem, WG_ATOMIC, WG_COLSUM.  Tiles of a grouped launch are interior by construction.
+        const GroupProb& P = g.p[split & (WG_MAXP - 1)];
+        float* Cg = P.C;
+        const int64_t ldc = P.ldc;
+        const int64_t mw = m0 + wr * (WM * 16), nw = n0 + wc * 64;
+        if (split & WG_ATOMIC) {
+            // one of the two K-halves of a tile: added into zeroed memory (two commutative contributions: deterministic)
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float* d = Cg + (mw + i * 16 + (lane & 15)) * ldc + nw + j * 16 + (lane >> 4) * 4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) (void)__hip_atomic_fetch_add(d + r, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+        } else {
+            // whole tile: the cross-lane re-layout of the 128-row tile (v_permlane16_swap of column tiles j, j+1: 8 consecutive columns per lane)
+            const int q = lane >> 4;
+            float* Cl = Cg + (mw + (lane & 15)) * ldc + nw + 16 * (q & 1) + 8 * (q >> 1);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    const f32x4 a = acc[i][2 * jp], b = acc[i][2 * jp + 1];
+                    float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
+                    asm volatile("s_nop 1\n\t"
+                                 "v_permlane16_swap_b32 %0, %4\n\t"
+                                 "v_permlane16_swap_b32 %1, %5\n\t"
+                                 "v_permlane16_swap_b32 %2, %6\n\t"
+                                 "v_permlane16_swap_b32 %3, %7"
+                                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+                    float* d = Cl + (int64_t)i * 16 * ldc + 32 * jp;
+                    *reinterpret_cast<f32x4*>(d) = f32x4{a0, a1, a2, a3};
+                    *reinterpret_cast<f32x4*>(d + 4) = f32x4{b0, b1, b2, b3};
+                }
+        }
+        if (gs.cs_on) {
+            // accs[i]: D'[n][m] = sum_k 1 * A[k][m] in every n: lanes 0-15 hold the 16 rows of fragment i in element 0
+            if ((lane >> 4) == 0) {
+#pragma unroll
+                for (int i = 0; i < WM; ++i) {
+                    float* d = P.cs + mw + i * 16 + lane;
+                    if (split & WG_ATOMIC) (void)__hip_atomic_fetch_add(d, gs.accs[i][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else *d = gs.accs[i][0];
+                }
+            }
+        }
+        return;
+    }
     if (g.splits > 1) {
         float* S = g.slabs + (int64_t)split * g.M * g.N;
 #pragma unroll
@@ -905,8 +994,17 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
         if (wr == 1) __builtin_amdgcn_s_setprio(1);
         int cw = bid, tc = 0, ntc;
         int64_t m0, n0; int split;
-        decode(cw, m0, n0, split);
-        ntc = (int)((min(g.K, (int64_t)(split + 1) * g.k_per_split) - (int64_t)split * g.k_per_split) / BK);
+        auto next_tile = [&]() {
+            if constexpr (GRP) {
+                const int4 it = g.items[cw];
+                m0 = it.y; n0 = it.z; split = it.x; ntc = it.w >> 16;
+                gs.cs_on = (it.x & WG_COLSUM) && wc == 0;
+            } else {
+                decode(cw, m0, n0, split);
+                ntc = (int)((min(g.K, (int64_t)(split + 1) * g.k_per_split) - (int64_t)split * g.k_per_split) / BK);
+            }
+        };
+        next_tile();
         for (;;) {
             bool tile_done = false;
             // STEADY inner loops — as many K-steps as fit before either side (the MFMA side's tile, the DMA side's work item, FILL stages
@@ -948,6 +1046,14 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
                         for (int i = 0; i < WM; ++i)
 #pragma unroll
                             for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(bf1[j], af1[i], acc[i][j]);
+                        if constexpr (GRP) {
+                            if (gs.cs_on) {
+#pragma unroll
+                                for (int i = 0; i < WM; ++i) gs.accs[i] = Mma<T>::mma(WG_ONES8, af0[i], gs.accs[i]);
+#pragma unroll
+                                for (int i = 0; i < WM; ++i) gs.accs[i] = Mma<T>::mma(WG_ONES8, af1[i], gs.accs[i]);
+                            }
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                         __builtin_amdgcn_s_barrier();
                         __builtin_amdgcn_sched_barrier(0);
@@ -979,6 +1085,12 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
                     for (int i = 0; i < WM; ++i)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(bf[j], af[i], acc[i][j]);
+                    if constexpr (GRP) {
+                        if (gs.cs_on) {
+#pragma unroll
+                            for (int i = 0; i < WM; ++i) gs.accs[i] = Mma<T>::mma(WG_ONES8, af[i], gs.accs[i]);
+                        }
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
@@ -1013,6 +1125,12 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(bf[j], af[i], acc[i][j]);
+            if constexpr (GRP) {
+                if (gs.cs_on) {
+#pragma unroll
+                    for (int i = 0; i < WM; ++i) gs.accs[i] = Mma<T>::mma(WG_ONES8, af[i], gs.accs[i]);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -1023,13 +1141,16 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
             epilogue(m0, n0, split);
             cw += G;
             if (cw >= nwork) break;
-            decode(cw, m0, n0, split);
-            ntc = (int)((min(g.K, (int64_t)(split + 1) * g.k_per_split) - (int64_t)split * g.k_per_split) / BK);
+            next_tile();
             tc = 0;
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (GRP) {
+#pragma unroll
+                for (int i = 0; i < WM; ++i) gs.accs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
         if (wr == 0) __builtin_amdgcn_s_barrier();
         return;
@@ -1094,6 +1215,28 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 }
+
+template <typename TO, bool AK, bool BKM, int EPI, int WM, int WGN, bool PP = false, bool RES = false, bool XLANE = false>
+__global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
+    glds_body<TO, AK, BKM, EPI, WM, WGN, PP, RES, XLANE, false, GemmArgs>(g);
+}
+// the grouped weight-gradient launch (see GroupedArgs): the 128x256 ping-pong tile of gemm_glds_kernel<float, true, true, 0, 4, 4, true> walking a
+// host-built work list over several problems
+#if CTMI_GEMM_HAS(3) || CTMI_GEMM_PART == 8
+__global__ __launch_bounds__(512, 2) void gemm_wgrad_grouped_kernel(GroupedArgs g) {
+    glds_body<float, true, true, CTMI_EPI_NONE, 4, 4, true, false, false, true, GroupedArgs>(g);
+}
+// zero up to 8 regions in one launch (the outputs the K-halves of a grouped launch are added into)
+struct ZeroRegions { float* p[8]; int64_t n[8]; int count; };
+__global__ __launch_bounds__(256) void zero_regions_k(ZeroRegions z) {
+    for (int r = 0; r < z.count; ++r) {
+        float4* p4 = reinterpret_cast<float4*>(z.p[r]);
+        const int64_t n4 = ((reinterpret_cast<uintptr_t>(z.p[r]) & 15) == 0) ? (z.n[r] >> 2) : 0;     // (an unaligned region: element by element)
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) p4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < z.n[r]; i += (int64_t)gridDim.x * 256) z.p[r][i] = 0.f;
+    }
+}
+#endif
 
 // C[m,n] = alpha * sum_s slabs[s][m][n] (+ C_old)   — deterministic split-K reduction
 template <typename TO>
@@ -1375,6 +1518,158 @@ int ctmi_gemm_bf16_tn(GemmArgs& g, int epi, bool fast, hipStream_t st) {
     if (epi == CTMI_EPI_NONE) return gemm_launch<bf16_t, float, true, true, CTMI_EPI_NONE>(g, fast, st);
     return gemm_unsupported(1, 1, epi, 1);
 }
+
+// ---- grouped weight gradients: host side -----------------------------------------------------------------------------------------------------
+#include <map>
+#include <mutex>
+#include <vector>
+namespace {
+struct WgShape { int64_t M[WG_MAXP], N[WG_MAXP]; int cs[WG_MAXP]; int n; int64_t ksteps; int slots; int split;
+    bool operator<(const WgShape& o) const {
+        if (n != o.n) return n < o.n;
+        if (ksteps != o.ksteps) return ksteps < o.ksteps;
+        if (slots != o.slots) return slots < o.slots;
+        if (split != o.split) return split < o.split;
+        for (int i = 0; i < n; ++i) { if (M[i] != o.M[i]) return M[i] < o.M[i]; if (N[i] != o.N[i]) return N[i] < o.N[i]; if (cs[i] != o.cs[i]) return cs[i] < o.cs[i]; }
+        return false;
+    }
+};
+struct WgTable { int4* dev = nullptr; int nitems = 0; unsigned atomic_mask = 0; };       // atomic_mask: problems with tiles whose K-halves are added
+std::mutex g_wg_mu;
+std::map<std::pair<int, WgShape>, WgTable> g_wg_tables;                                   // per (device, shape)
+
+// XCD-aware position of workgroup b among L items of one round: workgroups b, b+8, ... run on one XCD and get a contiguous run of the list
+inline int xcd_pos(int b, int L) {
+    const int xcd = b & 7, q = L >> 3, r8 = L & 7;
+    return (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (b >> 3);
+}
+
+// Work list.  Tiles of all problems in the grouped order of the single-problem kernel (groups of 8 tile rows x all tile columns, rows fastest:
+// 32 consecutive tiles are a compact block that shares 8 A panels and 4 B panels in an XCD's L2).  Whole rounds of `slots` tiles run over all of K;
+// the R tiles of the last, partial round are cut in two along K when both halves fit the round (2R <= slots) — `split` = 0 turns that off,
+// 2 cuts EVERY tile (finer-grained sharing of the CUs with the data-gradient chain of the other stream).
+void build_items(const WgShape& sh, std::vector<int4>& out, unsigned& atomic_mask) {
+    struct Tile { int p, m0, n0; };
+    std::vector<Tile> tiles;
+    for (int p = 0; p < sh.n; ++p) {
+        const int tm = (int)(sh.M[p] / 128), tn = (int)(sh.N[p] / 256);
+        for (int g0 = 0; g0 < tm; g0 += 8) {
+            const int gm = std::min(8, tm - g0);
+            for (int j = 0; j < tn; ++j)
+                for (int i = 0; i < gm; ++i) tiles.push_back({p, (g0 + i) * 128, j * 256});
+        }
+    }
+    const int nt = (int)tiles.size(), slots = sh.slots;
+    const int ks = (int)sh.ksteps, h0 = ks / 2, h1 = ks - h0;
+    int whole = nt;                                                                        // tiles [0, whole) run over all of K
+    if (sh.split == 2 && ks >= 2) whole = 0;
+    else if (sh.split == 1 && ks >= 2) { const int R = nt % slots; if (R > 0 && 2 * R <= slots) whole = nt - R; }
+    atomic_mask = 0;
+    auto item = [&](const Tile& t, int kb, int n, bool atomic) {
+        const int cs = (sh.cs[t.p] && t.n0 == 0) ? WG_COLSUM : 0;
+        if (atomic) atomic_mask |= 1u << t.p;
+        return make_int4(t.p | (atomic ? WG_ATOMIC : 0) | cs, t.m0, t.n0, kb | (n << 16));
+    };
+    std::vector<int4> lin;                                                                 // items in list order, before the XCD-aware placement
+    for (int t = 0; t < whole; ++t) lin.push_back(item(tiles[t], 0, ks, false));
+    // the halves: chunks of 16 tiles, first halves then second halves, so that the 32 items one XCD takes are 16 tiles x 2
+    for (int t0 = whole; t0 < nt; t0 += 16) {
+        const int t1 = std::min(nt, t0 + 16);
+        for (int t = t0; t < t1; ++t) lin.push_back(item(tiles[t], 0, h0, true));
+        for (int t = t0; t < t1; ++t) lin.push_back(item(tiles[t], h0, h1, true));
+    }
+    // placement: round r holds list entries [r*slots, ...); inside a round workgroup b takes the entry at its XCD-aware position
+    const int total = (int)lin.size();
+    out.assign(total, make_int4(0, 0, 0, 0));
+    for (int r0 = 0; r0 < total; r0 += slots) {
+        const int L = std::min(slots, total - r0);
+        for (int b = 0; b < L; ++b) out[r0 + b] = lin[r0 + xcd_pos(b, L)];
+    }
+}
+}  // namespace
+
+// CTMI_WGRAD_GROUP: 0 = off (four launches per block, split-K slabs: round 4), 1 (default) = grouped, the last partial round cut in two along K,
+// 2 = every tile cut in two, 3 = grouped, nothing cut
+int ctmi_wgrad_group_mode() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("CTMI_WGRAD_GROUP"); v = e ? std::max(0, atoi(e)) : 1; }
+    return v;
+}
+
+bool ctmi_wgrad_grouped_ok(const ctmi_wgrad_problem* pr, int n, int64_t T, int dtype) {
+    if (ctmi_wgrad_group_mode() == 0 || !glds_enabled() || dtype != CTMI_BF16 || n < 1 || n > WG_MAXP || T < 64 || T % 32 != 0 || T / 32 > 0x7fff) return false;
+    for (int i = 0; i < n; ++i) {
+        const int64_t M = pr[i].in_out ? pr[i].n_in : pr[i].n_out, N = pr[i].in_out ? pr[i].n_out : pr[i].n_in;
+        if (M <= 0 || N <= 0 || M % 128 != 0 || N % 256 != 0 || M * N > (1LL << 31)) return false;
+        if (!pr[i].dy || !pr[i].x || !pr[i].dw) return false;
+        if ((((uintptr_t)pr[i].dy) | ((uintptr_t)pr[i].x) | ((uintptr_t)pr[i].dw)) & 15) return false;
+        if (pr[i].db && (pr[i].in_out || (((uintptr_t)pr[i].db) & 3))) return false;       // the column sums ride on the A operand: dy must be it
+    }
+    return true;
+}
+
+extern "C" int ctmi_wgrad_grouped(const ctmi_wgrad_problem* pr, int n, int64_t T, int dtype, void* stream) {
+    CTMI_REQUIRE(pr != nullptr, "wgrad_grouped: null problem list");
+    if (!ctmi_wgrad_grouped_ok(pr, n, T, dtype)) {
+        ctmi_set_error("wgrad_grouped: unsupported problem set (bf16, <= %d problems, rows a multiple of 128 and columns of 256 of every gradient, T %% 32 == 0, "
+                       "16-byte aligned operands, no bias gradient with an [in,out] weight; CTMI_WGRAD_GROUP != 0)", WG_MAXP);
+        return CTMI_ERR_UNSUPPORTED;
+    }
+    hipStream_t st = as_stream(stream);
+    ProfScope prof__(CTMI_PROF_GEMM_WGRAD, st);
+    const int persist = shared_mode() ? 0 : 1;
+    const int slots = (256 - reserved_cus()) / 8 * 8;
+    WgShape sh = {};
+    sh.n = n; sh.ksteps = T / 32; sh.slots = slots;
+    const int mode = ctmi_wgrad_group_mode();
+    sh.split = mode == 3 ? 0 : (mode == 2 ? 2 : 1);
+    GroupedArgs g = {};
+    g.M = 128; g.N = 256; g.K = T; g.k_per_split = T; g.splits = 1; g.alpha = 1.0f;       // (the single-problem fields are not read by a grouped launch)
+    for (int i = 0; i < n; ++i) {
+        const bool io = pr[i].in_out != 0;
+        GroupProb& P = g.p[i];
+        P.A = io ? pr[i].x : pr[i].dy; P.B = io ? pr[i].dy : pr[i].x; P.C = pr[i].dw; P.cs = pr[i].db;
+        P.M = io ? pr[i].n_in : pr[i].n_out; P.N = io ? pr[i].n_out : pr[i].n_in;
+        P.lda = P.M; P.ldb = P.N; P.ldc = P.N;
+        sh.M[i] = P.M; sh.N[i] = P.N; sh.cs[i] = P.cs != nullptr;
+    }
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    WgTable tab;
+    {
+        std::lock_guard<std::mutex> lk(g_wg_mu);
+        auto key = std::make_pair(dev, sh);
+        auto it = g_wg_tables.find(key);
+        if (it == g_wg_tables.end()) {
+            std::vector<int4> items;
+            WgTable t;
+            build_items(sh, items, t.atomic_mask);
+            t.nitems = (int)items.size();
+            if (hipMalloc(&t.dev, items.size() * sizeof(int4)) != hipSuccess) { ctmi_set_error("wgrad_grouped: cannot allocate the work list"); return CTMI_ERR_LAUNCH; }
+            // synchronous copy, once per geometry and device: the list is read by every later launch on any stream
+            if (hipMemcpy(t.dev, items.data(), items.size() * sizeof(int4), hipMemcpyHostToDevice) != hipSuccess) { ctmi_set_error("wgrad_grouped: cannot upload the work list"); return CTMI_ERR_LAUNCH; }
+            it = g_wg_tables.emplace(key, t).first;
+        }
+        tab = it->second;
+    }
+    g.items = tab.dev; g.nitems = tab.nitems;
+    if (tab.atomic_mask) {
+        ZeroRegions z = {};
+        for (int i = 0; i < n; ++i)
+            if (tab.atomic_mask & (1u << i)) {
+                z.p[z.count] = g.p[i].C; z.n[z.count] = g.p[i].M * g.p[i].N; ++z.count;
+                if (g.p[i].cs) { z.p[z.count] = g.p[i].cs; z.n[z.count] = g.p[i].M; ++z.count; }
+            }
+        hipLaunchKernelGGL(zero_regions_k, dim3(1024), dim3(256), 0, st, z);
+        CTMI_CHECK_LAUNCH("wgrad_grouped_zero");
+    }
+    constexpr size_t lds = 6 * (size_t)(GTile<true, 128>::BYTES + GTile<true, 256>::BYTES);
+    const unsigned grid = (unsigned)((persist && tab.nitems > slots) ? slots : tab.nitems);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wgrad_grouped_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(gemm_wgrad_grouped_kernel, dim3(grid), dim3(512), lds, st, g);
+    CTMI_CHECK_LAUNCH("wgrad_grouped");
+    return CTMI_OK;
+}
 #endif
 
 #if CTMI_GEMM_HAS(0)
@@ -1460,6 +1755,7 @@ extern "C" int ctmi_gemm(const void* A, int64_t lda, int a_kmajor, const void* B
 
 // -DCTMI_GEMM_PART=9 (tools only): nothing but ONE explicit instantiation, chosen with -DCTMI_ONE_KERNEL="...": a seconds-long compile for
 // reading the ISA of a single kernel (tools/kernel_isa_scan.py)
+// -DCTMI_GEMM_PART=8 (tools only): the grouped weight-gradient kernel alone
 #if CTMI_GEMM_PART == 9
 #ifndef CTMI_ONE_KERNEL
 #define CTMI_ONE_KERNEL bf16_t, false, true, 0, 4, 4, true, false, false

@@ -182,6 +182,27 @@ def linear_wgrad(dy: Tensor, x2d: Tensor, out: Optional[Tensor] = None, accumula
     return gemm(dy, Nout, True, x2d, Kin, True, Nout, Kin, T, out=out, out_f32=True, beta=int(accumulate), alpha=alpha)
 
 
+def wgrad_grouped(problems, in_out: bool = False):
+    """The weight (and bias) gradients of several Linears in ONE launch (include/ctmi355.h ctmi_wgrad_grouped; autograd of modeling_bloom.py:79,121,
+    256,267): problems = [(dy [T,n_out], x [T,n_in], want_bias_grad)], bf16 -> [(dw fp32 [n_out,n_in] (or [n_in,n_out] if in_out), db fp32 [n_out] or None)].
+    Raises CtmiError (unsupported) for shapes outside the kernel's tiling; callers fall back to linear_wgrad / colsum per product."""
+    lib = _lib.load()
+    arr = (_lib.WgradProblem * len(problems))()
+    outs = []
+    T = problems[0][0].shape[0]
+    for i, (dy, x, want_db) in enumerate(problems):
+        _need_cuda(dy, x)
+        assert dy.is_contiguous() and x.is_contiguous() and dy.shape[0] == T and x.shape[0] == T
+        n_out, n_in = dy.shape[1], x.shape[1]
+        dw = torch.empty((n_in, n_out) if in_out else (n_out, n_in), dtype=torch.float32, device=dy.device)
+        db = torch.empty(n_out, dtype=torch.float32, device=dy.device) if want_db else None
+        arr[i].dy, arr[i].x, arr[i].dw, arr[i].db = dy.data_ptr(), x.data_ptr(), dw.data_ptr(), (None if db is None else db.data_ptr())
+        arr[i].n_out, arr[i].n_in, arr[i].in_out = n_out, n_in, int(in_out)
+        outs.append((dw, db))
+    check(lib.ctmi_wgrad_grouped(arr, len(problems), T, dt_code(problems[0][0].dtype), _stream()), "wgrad_grouped")
+    return outs
+
+
 def colsum(x2d: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
     M, N = x2d.shape
     lib = _lib.load()

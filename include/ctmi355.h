@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CTMI_ABI_VERSION 12
+#define CTMI_ABI_VERSION 13
 
 enum ctmi_dtype { CTMI_F32 = 0, CTMI_BF16 = 1 };
 enum ctmi_status { CTMI_OK = 0, CTMI_ERR_ARG = -1, CTMI_ERR_LAUNCH = -2, CTMI_ERR_UNSUPPORTED = -3 };
@@ -73,6 +73,24 @@ int ctmi_gemm(const void* A, int64_t lda, int a_kmajor, const void* B, int64_t l
               float alpha, int beta, const float* bias, const void* residual, int epilogue,
               const void* aux_in, void* aux_out, int out_f32, int dtype,
               void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- grouped weight gradients (ABI v13).  The four parameter-gradient products of one block's backward — autograd of the Linears at
+ * modeling_bloom.py:79 (query_key_value), :121 (dense), :256 (dense_h_to_4h), :267 (dense_4h_to_h) — in ONE persistent launch:
+ *   dw[n_out, n_in] (fp32, overwritten) = dy[T, n_out]^T x[T, n_in]        dy, x: row-major, dense, bf16
+ *   db[n_out]       (fp32, overwritten, optional) = column sums of dy      (the bias gradient; computed by the matrix cores against a vector of ones)
+ *   in_out = 1: dw is written [n_in, n_out] (a Conv1D weight's own layout, modeling_gpt.py:32-46); db must be NULL then.
+ * Output tiles are 128 x 256; whole rounds of the 256 CUs accumulate over all T rows, the tiles of the last partial round are cut in two along T
+ * and their halves added into zeroed memory with fp32 atomics (two commutative contributions: bit-deterministic).  No split-K slabs, no reduce
+ * launch, no separate column-sum pass.  Needs dtype = CTMI_BF16, n <= 4, T % 32 == 0, every gradient's rows a multiple of 128 and columns of 256,
+ * 16-byte aligned pointers: anything else returns CTMI_ERR_UNSUPPORTED (callers then use ctmi_gemm(a_kmajor = b_kmajor = 1) per product).
+ * CTMI_WGRAD_GROUP = 0 in the environment disables it (ctmi_bloom_block_bwd then launches the four products separately, as in ABI <= 12). */
+typedef struct ctmi_wgrad_problem {
+    const void* dy; const void* x;      /* device, [T, n_out] and [T, n_in] */
+    float* dw; float* db;               /* device; db may be NULL */
+    int64_t n_out, n_in;
+    int in_out; int pad_;
+} ctmi_wgrad_problem;
+int ctmi_wgrad_grouped(const ctmi_wgrad_problem* problems /* host */, int count, int64_t T, int dtype, void* stream);
 
 /* GEMM launch policy (process-wide).  shared = 0: the GPU is ours — persistent launches sized to the 256 CUs, one-workgroup-
  * per-CU ping-pong tiles.  shared = 1: another long-running kernel holds CUs under our GEMMs (the RCCL all-reduce of a

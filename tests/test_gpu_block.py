@@ -7,6 +7,7 @@ dx, weight gradients, LayerNorm affine gradients) must be bit-identical between 
 gradients that moved into the LayerNorm backward are summed in a different order and are compared with a summation-sized
 tolerance."""
 import math
+import os
 
 import pytest
 import torch
@@ -239,13 +240,17 @@ def test_block_one_call_equals_per_op_sequence(dtype, post, B, S, H, nh):
     # LayerNorm's backward goes through a different instantiation of that kernel in the one-call form (the one that also emits
     # the bias column sums): same formula, but hipcc's fp contraction may differ by an ulp, so those are compared to rounding.
     rt = 2e-5 if dtype == torch.float32 else 2e-2
+    # round 5: bf16 blocks whose geometry fits the grouped weight-gradient launch (csrc/gemm.hip ctmi_wgrad_grouped) take it in the one-call form
+    grouped = dtype == torch.bfloat16 and H % 256 == 0 and T % 32 == 0 and T >= 64 and os.environ.get("CTMI_WGRAD_GROUP", "1") != "0"
     for side in (False, True):
         dx, grads = results[side]
         assert relerr(dx, dx_ref) < rt, f"dx side={side}"
         for n, g, gr in zip(names, grads, g_ref):
-            if n in ("w2", "w1", "b1"):
+            if n in ("w2", "w1", "b1") and not grouped:
                 assert torch.equal(g, gr), (n, side)
-            elif n in ("bd", "b2", "bqkv"):
+            elif n in ("w2", "w1"):
+                assert relerr(g, gr) < 5e-6, (n, side)                          # grouped launch: same products, other fp32 summation order
+            elif n in ("bd", "b2", "bqkv", "b1"):
                 # column sums: bd / b2 come out of the LayerNorm backward (other summation order)
                 scale = float(gr.abs().max()) + 1e-30
                 assert float((g - gr).abs().max()) <= (2e-5 if dtype == torch.float32 else 2e-2) * scale * math.sqrt(T), (n, side)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel microbenchmarks at the Bloom-560M C2 shapes (T = 8192 tokens): HIP-event timing, TFLOP/s or GB/s.
-Usage: python tools/microbench.py [gemm] [attn] [ln] [ce] [adamw] [embed]"""
+Usage: python tools/microbench.py [gemm] [wgroup] [attn] [ln] [ce] [adamw] [embed]"""
 import os
 import sys
 
@@ -52,6 +52,27 @@ def bench_gemm(T=8192):
         t = timeit(lambda: ops.linear_wgrad(dy, x), it)
         print(f"{name:8s} wgrad M={N} N={K} K={T}: {t:8.3f} ms  {fl / t / 1e9:8.1f} TF/s")
         del x, w, dy
+
+
+def bench_wgroup(T=8192, H=1024):
+    """the four weight gradients + two bias column sums of one Bloom block: grouped launch vs the per-product kernels (single stream, warm)"""
+    print(f"--- layer weight gradients of one block, T={T} H={H}")
+    shapes = [(H, 4 * H, False), (4 * H, H, True), (H, H, False), (3 * H, H, True)]
+    probs = [(rnd(T, no), rnd(T, ni), db) for (no, ni, db) in shapes]
+    fl = sum(2.0 * T * no * ni for no, ni, _ in shapes)
+
+    def separate():
+        for dy, x, db in probs:
+            ops.linear_wgrad(dy, x)
+            if db:
+                ops.colsum(dy)
+    t = timeit(separate, 20)
+    print(f"per-product (4 GEMMs + split-K reduces + 2 column sums): {t * 1e3:8.1f} us  {fl / t / 1e9:8.1f} TF/s")
+    try:
+        t = timeit(lambda: ops.wgrad_grouped(probs), 20)
+        print(f"grouped (one launch, CTMI_WGRAD_GROUP={os.environ.get('CTMI_WGRAD_GROUP', '1')}):            {t * 1e3:8.1f} us  {fl / t / 1e9:8.1f} TF/s")
+    except Exception as ex:                                            # noqa: BLE001
+        print("grouped: not available in this library:", str(ex)[:80])
 
 
 def bench_attn(B=8, S=1024, nh=16, hd=64):
@@ -141,6 +162,8 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["gemm", "attn", "ln", "ce", "adamw"]
     if "gemm" in which:
         bench_gemm()
+    if "wgroup" in which:
+        bench_wgroup()
     if "attn" in which:
         bench_attn()
     if "ln" in which:
