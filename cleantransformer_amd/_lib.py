@@ -87,10 +87,11 @@ PROTOTYPES = {
     "ctmi_scale_if": (i32, [vp, i64, i64, i64, vp, f32, vp, i32, vp]),
     "ctmi_scale_if_passes": (i64, []),
     "ctmi_reduce_jobs": (i32, [C.POINTER(ReduceJob), i32, vp]),
-    "ctmi_wgrad_grouped": (i32, [C.POINTER(WgradProblem), i32, i64, i32, vp]),
+    "ctmi_wgrad_grouped": (i32, [C.POINTER(WgradProblem), i32, i64, i32, vp, i64, vp]),
     "ctmi_bloom_block_layout": (i64, [i64, i64, i64, i64, i32, C.POINTER(i64)]),
     "ctmi_bloom_block_fwd": (i32, [C.POINTER(BloomBlock), vp]),
     "ctmi_bloom_block_bwd_ws": (i64, [i64, i64, i64, i64, i32]),
+    "ctmi_bloom_block_wgrad_grouped": (i32, [i64, i64, i64, i32, i32]),
     "ctmi_bloom_block_bwd": (i32, [C.POINTER(BloomBlock), C.POINTER(BloomBlockGrads), vp]),
     "ctmi_ce_soft_fwd": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, i64, i64, i32, i64, i32, vp]),
     "ctmi_ce_soft_bwd": (i32, [vp, i64, vp, i64, vp, vp, vp, vp, vp, i64, i64, i64, i32, vp]),

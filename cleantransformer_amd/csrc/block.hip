@@ -6,7 +6,8 @@
 // Backward, round 5 (bf16, aligned geometry; CTMI_WGRAD_GROUP != 0): the data-gradient chain below runs on the main stream unchanged; the FOUR
 // weight gradients and the column sums of du / dqkv (db1, dbqkv) are ONE grouped launch on the side stream (ctmi_wgrad_grouped, csrc/gemm.hip),
 // forked after the attention backward — when the last of their operands, dqkv, exists — so it runs under the rest of this block's chain and
-// the next block's.  No split-K slabs, no reduce launch, no column-sum launches.  The per-product form below remains for fp32 (parity mode)
+// the next block's.  No split-K slabs of whole gradients, no column-sum launches; one small second launch adds the K-halves of the 128 tiles
+// of the last partial round.  The per-product form below remains for fp32 (parity mode)
 // and shapes outside the grouped kernel's tiling.
 //
 // Backward (pre-LN form; the post-LN switch only moves the residual gradients):
@@ -195,6 +196,19 @@ int64_t bwd_layout(int64_t B, int64_t S, int64_t H, int64_t nh, int dtype, int64
 }
 }  // namespace
 
+// does ctmi_bloom_block_bwd take the grouped weight-gradient launch at this geometry?  (Then the whole backward of a block is best issued on ONE
+// stream: the grouped launch fills the 256 CUs by itself — profiles/r05_wgrad_grouped.txt — and callers keep side_stream NULL.)
+extern "C" int ctmi_bloom_block_wgrad_grouped(int64_t B, int64_t S, int64_t H, int dtype, int flags) {
+    if (B <= 0 || S <= 0 || H <= 0) return 0;
+    { const char* e = getenv("CTMI_BLOCK_DBG"); if (e && (atoi(e) & 1)) return 0; }
+    const int io = (flags & CTMI_BLK_WGRAD_IN_OUT) ? 1 : 0;
+    void* const al = reinterpret_cast<void*>(uintptr_t(256));                          // stands for any 16-byte aligned pointer
+    float* const fa = reinterpret_cast<float*>(al);
+    const ctmi_wgrad_problem wp[4] = {{al, al, fa, nullptr, H, 4 * H, io, 0}, {al, al, fa, io ? nullptr : fa, 4 * H, H, io, 0},
+                                      {al, al, fa, nullptr, H, H, io, 0}, {al, al, fa, io ? nullptr : fa, 3 * H, H, io, 0}};
+    return ctmi_wgrad_grouped_ok(wp, 4, B * S, dtype) ? 1 : 0;
+}
+
 extern "C" int64_t ctmi_bloom_block_bwd_ws(int64_t B, int64_t S, int64_t H, int64_t nh, int dtype) {
     return bwd_layout(B, S, H, nh, dtype, nullptr);
 }
@@ -284,7 +298,7 @@ extern "C" int ctmi_bloom_block_bwd(const ctmi_bloom_block* b, const ctmi_bloom_
             RC(colsum_job(W(W_DU), 4 * H, W_CS_DU, gr->db1));
             RC(colsum_job(dqkv, 3 * H, W_CS_DQKV, gr->dbqkv));
         }
-        RC(ctmi_wgrad_grouped(wp, 4, T, dt, pst));
+        RC(ctmi_wgrad_grouped(wp, 4, T, dt, pws, pws_bytes, pst));
         RC(linear_dgrad(dqkv, b->wqkv, W(W_DLN1), T, 3 * H, H, CTMI_EPI_NONE, nullptr, post ? W(W_DH1) : nullptr, dt, gr->splitk_ws, gr->splitk_ws_bytes, main_st, w_io));
         int np1 = 0, ns1 = 2;
         RC(ctmi_ln_bwd_parts_internal(W(W_DLN1), b->x, b->ln1_w, s.at<float>(CTMI_BLK_MEAN1), s.at<float>(CTMI_BLK_RSTD1),

@@ -166,16 +166,20 @@ struct GemmArgs {
 
 // Grouped weight gradients (round 5): ONE persistent launch computes the weight gradients of several Linears — dW_p = dy_p^T x_p, every operand
 // K-major with K = T rows — from a host-built list of work items over 128x256 output tiles.  Whole tiles accumulate over all of K and are stored;
-// the tiles of the last, partial round of the 256 CUs are cut in two along K and their halves are ADDED into zeroed memory with fp32 hardware
-// atomics (exactly two commutative contributions on top of 0: bit-deterministic whatever the arrival order).  The column sums of dy (the bias
-// gradient) ride in the first tile column of a problem: one extra MFMA per A fragment against a fragment of ones.
+// the tiles of the last, partial round of the 256 CUs are cut in two along K: each half stores its partial tile (and partial column sums) into a
+// slab of the caller's workspace and a small second launch adds the two halves in a fixed order (deterministic).  (The first version ADDED the
+// halves into zeroed memory with fp32 hardware atomics — two commutative contributions, also deterministic: 32 768 scattered 4-byte atomics per
+// half tile cost 70 us per block, profiles/r05_wgrad_grouped.txt.)  The column sums of dy (the bias gradient) ride in the first tile column of
+// a problem: ONE extra MFMA per wave and ring stage against a fragment of ones — each of the four waves of a row group starts its A fragments at
+// a different 16-row block (i -> (i + wc) & 3), so wave wc's fragment 0 is block wc and the four waves cover the 64 rows between them.
 constexpr int WG_MAXP = 4;
-struct GroupProb { const void* A; const void* B; float* C; float* cs; int64_t lda, ldb, ldc, M, N; };   // C[M,N] = A^T B, A = [K][M], B = [K][N]; cs[M] = column sums of A (or null)
+struct GroupProb { const void* A; const void* B; float* C; float* cs; float* part; float* cspart; int64_t lda, ldb, ldc, M, N; };
+    // C[M,N] = A^T B, A = [K][M], B = [K][N]; cs[M] = column sums of A (or null); part = [2][M][N] / cspart = [2][M] partial results of the K-halves
 struct GroupedArgs : GemmArgs { GroupProb p[WG_MAXP]; const int4* items; int nitems; };
-// work item (int4): x = problem | WG_ATOMIC | WG_COLSUM, y = first row, z = first column of the tile, w = first K-step | K-steps << 16
-constexpr int WG_ATOMIC = 16, WG_COLSUM = 32;
+// work item (int4): x = problem | WG_PART | WG_HALF1 | WG_COLSUM, y = first row, z = first column of the tile, w = first K-step | K-steps << 16
+constexpr int WG_PART = 16, WG_COLSUM = 32, WG_HALF1 = 64;
 template <bool GRP, int WM> struct GrpRegs { };
-template <int WM> struct GrpRegs<true, WM> { f32x4 accs[WM]; bool cs_on; };         // column-sum accumulators of the tile, and whether this wave keeps them
+template <int WM> struct GrpRegs<true, WM> { f32x4 accs; bool cs_on; };             // column-sum accumulator of this wave's 16-row block, and whether the tile has one
 #define WG_ONES8 (short8{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80})   /* eight bf16 1.0 */
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -551,11 +555,9 @@ __device__ __forceinline__ void glds_body(const GA g) {   // (by value: through 
     // grouped weight gradients: column sums of the A operand (the bias gradient) of this tile, accumulated by MFMAs against a fragment of ones
     // (state of the grouped instantiation only: the other kernels do not even declare it)
     GrpRegs<GRP, WM> gs;
-    if constexpr (GRP) {
-#pragma unroll
-        for (int i = 0; i < WM; ++i) gs.accs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        gs.cs_on = false;
-    }
+    if constexpr (GRP) { gs.accs = f32x4{0.f, 0.f, 0.f, 0.f}; gs.cs_on = false; }
+    // first row (inside the wave's WM*16 rows) of A fragment i: grouped launches rotate the blocks by the wave's column index
+    auto arow = [&](int i) { return GRP ? ((i + wc) & (WM - 1)) * 16 : i * 16; };
 
     auto epilogue = [&](const int64_t m0, const int64_t n0, const int split) {
         // the lane id is laundered through an empty asm so none of the address arithmetic below is loop-invariant for
@@ -565,51 +567,37 @@ __device__ __forceinline__ void glds_body(const GA g) {   // (by value: through 
         asm volatile("" : "+v"(lane));
     // epilogue (same contract as v1): lane holds C[m][n..n+3], m = m0+wr*WM*16+i*16+(lane&15), n = n0+wc*64+j*16+(lane>>4)*4
     if constexpr (GRP) {
-        // `split` carries the work item's x word: problem, WG_ATOMIC, WG_COLSUM.  Tiles of a grouped launch are interior by construction.
+        // `split` carries the work item's x word: problem, WG_PART (a K-half: the result goes to the partial slabs), WG_HALF1, WG_COLSUM.
+        // Tiles of a grouped launch are interior by construction.  The cross-lane re-layout of the 128-row tile (v_permlane16_swap of column
+        // tiles j, j+1: 8 consecutive columns per lane); accumulator row i holds block (i + wc) & 3 of the wave's rows (see arow).
         const GroupProb& P = g.p[split & (WG_MAXP - 1)];
-        float* Cg = P.C;
+        const bool part = (split & WG_PART) != 0, half1 = (split & WG_HALF1) != 0;
+        float* Cg = part ? P.part + (half1 ? P.M * P.N : 0) : P.C;
         const int64_t ldc = P.ldc;
         const int64_t mw = m0 + wr * (WM * 16), nw = n0 + wc * 64;
-        if (split & WG_ATOMIC) {
-            // one of the two K-halves of a tile: added into zeroed memory (two commutative contributions: deterministic)
+        const int q = lane >> 4;
+        float* Cl = Cg + (mw + (lane & 15)) * ldc + nw + 16 * (q & 1) + 8 * (q >> 1);
 #pragma unroll
-            for (int i = 0; i < WM; ++i)
+        for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float* d = Cg + (mw + i * 16 + (lane & 15)) * ldc + nw + j * 16 + (lane >> 4) * 4;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) (void)__hip_atomic_fetch_add(d + r, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-        } else {
-            // whole tile: the cross-lane re-layout of the 128-row tile (v_permlane16_swap of column tiles j, j+1: 8 consecutive columns per lane)
-            const int q = lane >> 4;
-            float* Cl = Cg + (mw + (lane & 15)) * ldc + nw + 16 * (q & 1) + 8 * (q >> 1);
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int jp = 0; jp < 2; ++jp) {
-                    const f32x4 a = acc[i][2 * jp], b = acc[i][2 * jp + 1];
-                    float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
-                    asm volatile("s_nop 1\n\t"
-                                 "v_permlane16_swap_b32 %0, %4\n\t"
-                                 "v_permlane16_swap_b32 %1, %5\n\t"
-                                 "v_permlane16_swap_b32 %2, %6\n\t"
-                                 "v_permlane16_swap_b32 %3, %7"
-                                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
-                    float* d = Cl + (int64_t)i * 16 * ldc + 32 * jp;
-                    *reinterpret_cast<f32x4*>(d) = f32x4{a0, a1, a2, a3};
-                    *reinterpret_cast<f32x4*>(d + 4) = f32x4{b0, b1, b2, b3};
-                }
-        }
+            for (int jp = 0; jp < 2; ++jp) {
+                const f32x4 a = acc[i][2 * jp], b = acc[i][2 * jp + 1];
+                float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
+                asm volatile("s_nop 1\n\t"
+                             "v_permlane16_swap_b32 %0, %4\n\t"
+                             "v_permlane16_swap_b32 %1, %5\n\t"
+                             "v_permlane16_swap_b32 %2, %6\n\t"
+                             "v_permlane16_swap_b32 %3, %7"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+                float* d = Cl + (int64_t)arow(i) * ldc + 32 * jp;
+                *reinterpret_cast<f32x4*>(d) = f32x4{a0, a1, a2, a3};
+                *reinterpret_cast<f32x4*>(d + 4) = f32x4{b0, b1, b2, b3};
+            }
         if (gs.cs_on) {
-            // accs[i]: D'[n][m] = sum_k 1 * A[k][m] in every n: lanes 0-15 hold the 16 rows of fragment i in element 0
+            // gs.accs: D'[n][m] = sum_k 1 * A[k][m] in every n for the wave's block arow(0): lanes 0-15 hold its 16 rows in element 0
             if ((lane >> 4) == 0) {
-#pragma unroll
-                for (int i = 0; i < WM; ++i) {
-                    float* d = P.cs + mw + i * 16 + lane;
-                    if (split & WG_ATOMIC) (void)__hip_atomic_fetch_add(d, gs.accs[i][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    else *d = gs.accs[i][0];
-                }
+                float* d = (part ? P.cspart + (half1 ? P.M : 0) : P.cs) + mw + arow(0) + lane;
+                *d = gs.accs[0];
             }
         }
         return;
@@ -998,7 +986,7 @@ __device__ __forceinline__ void glds_body(const GA g) {   // (by value: through 
             if constexpr (GRP) {
                 const int4 it = g.items[cw];
                 m0 = it.y; n0 = it.z; split = it.x; ntc = it.w >> 16;
-                gs.cs_on = (it.x & WG_COLSUM) && wc == 0;
+                gs.cs_on = (it.x & WG_COLSUM) != 0;
             } else {
                 decode(cw, m0, n0, split);
                 ntc = (int)((min(g.K, (int64_t)(split + 1) * g.k_per_split) - (int64_t)split * g.k_per_split) / BK);
@@ -1024,11 +1012,11 @@ __device__ __forceinline__ void glds_body(const GA g) {   // (by value: through 
 #pragma unroll
                         for (int j = 0; j < 4; ++j) bf0[j] = TB::frag(smem_raw + BOFF + rd * TB::BYTES, wc * 64 + j * 16, lane);
 #pragma unroll
-                        for (int i = 0; i < WM; ++i) af0[i] = TA::frag(smem_raw + AOFF + rd * TA::BYTES, wr * (WM * 16) + i * 16, lane);
+                        for (int i = 0; i < WM; ++i) af0[i] = TA::frag(smem_raw + AOFF + rd * TA::BYTES, wr * (WM * 16) + arow(i), lane);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) bf1[j] = TB::frag(smem_raw + BOFF + rd1 * TB::BYTES, wc * 64 + j * 16, lane);
 #pragma unroll
-                        for (int i = 0; i < WM; ++i) af1[i] = TA::frag(smem_raw + AOFF + rd1 * TA::BYTES, wr * (WM * 16) + i * 16, lane);
+                        for (int i = 0; i < WM; ++i) af1[i] = TA::frag(smem_raw + AOFF + rd1 * TA::BYTES, wr * (WM * 16) + arow(i), lane);
                         issue_stage(wrb);
                         wrb = wrb == NST - 1 ? 0 : wrb + 1;
                         issue_stage(wrb);
@@ -1048,10 +1036,8 @@ __device__ __forceinline__ void glds_body(const GA g) {   // (by value: through 
                             for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(bf1[j], af1[i], acc[i][j]);
                         if constexpr (GRP) {
                             if (gs.cs_on) {
-#pragma unroll
-                                for (int i = 0; i < WM; ++i) gs.accs[i] = Mma<T>::mma(WG_ONES8, af0[i], gs.accs[i]);
-#pragma unroll
-                                for (int i = 0; i < WM; ++i) gs.accs[i] = Mma<T>::mma(WG_ONES8, af1[i], gs.accs[i]);
+                                gs.accs = Mma<T>::mma(WG_ONES8, af0[0], gs.accs);
+                                gs.accs = Mma<T>::mma(WG_ONES8, af1[0], gs.accs);
                             }
                         }
                         __builtin_amdgcn_sched_barrier(0);
@@ -1074,7 +1060,7 @@ __device__ __forceinline__ void glds_body(const GA g) {   // (by value: through 
 #pragma unroll
                     for (int j = 0; j < 4; ++j) bf[j] = TB::frag(bs, wc * 64 + j * 16, lane);
 #pragma unroll
-                    for (int i = 0; i < WM; ++i) af[i] = TA::frag(as, wr * (WM * 16) + i * 16, lane);
+                    for (int i = 0; i < WM; ++i) af[i] = TA::frag(as, wr * (WM * 16) + arow(i), lane);
                     issue_stage(wrb);
                     wait_stages(FILL - LAND);                                 // (one stage consumed, one issued: FILL - LAND of the FILL younger ones may fly)
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1086,10 +1072,7 @@ __device__ __forceinline__ void glds_body(const GA g) {   // (by value: through 
 #pragma unroll
                         for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(bf[j], af[i], acc[i][j]);
                     if constexpr (GRP) {
-                        if (gs.cs_on) {
-#pragma unroll
-                            for (int i = 0; i < WM; ++i) gs.accs[i] = Mma<T>::mma(WG_ONES8, af[i], gs.accs[i]);
-                        }
+                        if (gs.cs_on) gs.accs = Mma<T>::mma(WG_ONES8, af[0], gs.accs);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_barrier();
@@ -1111,7 +1094,7 @@ __device__ __forceinline__ void glds_body(const GA g) {   // (by value: through 
 #pragma unroll
             for (int j = 0; j < 4; ++j) bf[j] = TB::frag(bs, wc * 64 + j * 16, lane);
 #pragma unroll
-            for (int i = 0; i < WM; ++i) af[i] = TA::frag(as, wr * (WM * 16) + i * 16, lane);
+            for (int i = 0; i < WM; ++i) af[i] = TA::frag(as, wr * (WM * 16) + arow(i), lane);
             if (more) {
                 issue_stage(wrb);
                 stage_issued(); ++inflight; wrb = wrb == NST - 1 ? 0 : wrb + 1;
@@ -1126,10 +1109,7 @@ __device__ __forceinline__ void glds_body(const GA g) {   // (by value: through 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(bf[j], af[i], acc[i][j]);
             if constexpr (GRP) {
-                if (gs.cs_on) {
-#pragma unroll
-                    for (int i = 0; i < WM; ++i) gs.accs[i] = Mma<T>::mma(WG_ONES8, af[i], gs.accs[i]);
-                }
+                if (gs.cs_on) gs.accs = Mma<T>::mma(WG_ONES8, af[0], gs.accs);
             }
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -1147,10 +1127,7 @@ __device__ __forceinline__ void glds_body(const GA g) {   // (by value: through 
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (GRP) {
-#pragma unroll
-                for (int i = 0; i < WM; ++i) gs.accs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            if constexpr (GRP) gs.accs = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         if (wr == 0) __builtin_amdgcn_s_barrier();
         return;
@@ -1181,7 +1158,7 @@ __device__ __forceinline__ void glds_body(const GA g) {   // (by value: through 
         const unsigned char* bs = smem_raw + BOFF + rd * TB::BYTES;
         short8 af[WM], bf[4];
 #pragma unroll
-        for (int i = 0; i < WM; ++i) af[i] = TA::frag(as, wr * (WM * 16) + i * 16, lane);
+        for (int i = 0; i < WM; ++i) af[i] = TA::frag(as, wr * (WM * 16) + arow(i), lane);
 #pragma unroll
         for (int j = 0; j < 4; ++j) bf[j] = TB::frag(bs, wc * 64 + j * 16, lane);
         __builtin_amdgcn_s_setprio(1);                                        // MFMA phase outranks the partner wave's DMA / epilogue issue
@@ -1226,15 +1203,21 @@ __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
 __global__ __launch_bounds__(512, 2) void gemm_wgrad_grouped_kernel(GroupedArgs g) {
     glds_body<float, true, true, CTMI_EPI_NONE, 4, 4, true, false, false, true, GroupedArgs>(g);
 }
-// zero up to 8 regions in one launch (the outputs the K-halves of a grouped launch are added into)
-struct ZeroRegions { float* p[8]; int64_t n[8]; int count; };
-__global__ __launch_bounds__(256) void zero_regions_k(ZeroRegions z) {
-    for (int r = 0; r < z.count; ++r) {
-        float4* p4 = reinterpret_cast<float4*>(z.p[r]);
-        const int64_t n4 = ((reinterpret_cast<uintptr_t>(z.p[r]) & 15) == 0) ? (z.n[r] >> 2) : 0;     // (an unaligned region: element by element)
-        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) p4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < z.n[r]; i += (int64_t)gridDim.x * 256) z.p[r][i] = 0.f;
+// second launch of a grouped call that cut tiles in two along K: C = partial 0 + partial 1 (and the column sums), one 32-row slice of a tile per workgroup
+struct WgReduceArgs { GroupProb p[WG_MAXP]; const int4* tiles; int ntiles; };           // tiles: x = problem | WG_COLSUM, y = first row, z = first column
+__global__ __launch_bounds__(256) void wgrad_partials_reduce_k(WgReduceArgs z) {
+    const int4 it = z.tiles[blockIdx.x >> 2];
+    const GroupProb& P = z.p[it.x & (WG_MAXP - 1)];
+    const int qr = blockIdx.x & 3, tid = threadIdx.x;
+    const int64_t half = P.M * P.N;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int id = r * 256 + tid;                                                   // 32 rows x 64 float4
+        const int64_t off = (int64_t)(it.y + qr * 32 + (id >> 6)) * P.ldc + it.z + (id & 63) * 4;
+        const float4 a = *reinterpret_cast<const float4*>(P.part + off), b = *reinterpret_cast<const float4*>(P.part + half + off);
+        *reinterpret_cast<float4*>(P.C + off) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
     }
+    if ((it.x & WG_COLSUM) && qr == 0 && tid < 128) P.cs[it.y + tid] = P.cspart[it.y + tid] + P.cspart[P.M + it.y + tid];
 }
 #endif
 
@@ -1534,7 +1517,7 @@ struct WgShape { int64_t M[WG_MAXP], N[WG_MAXP]; int cs[WG_MAXP]; int n; int64_t
         return false;
     }
 };
-struct WgTable { int4* dev = nullptr; int nitems = 0; unsigned atomic_mask = 0; };       // atomic_mask: problems with tiles whose K-halves are added
+struct WgTable { int4* dev = nullptr; int nitems = 0, nsplit = 0; unsigned split_mask = 0; };   // nsplit tiles (listed behind the items) are cut in two; split_mask: their problems
 std::mutex g_wg_mu;
 std::map<std::pair<int, WgShape>, WgTable> g_wg_tables;                                   // per (device, shape)
 
@@ -1547,8 +1530,8 @@ inline int xcd_pos(int b, int L) {
 // Work list.  Tiles of all problems in the grouped order of the single-problem kernel (groups of 8 tile rows x all tile columns, rows fastest:
 // 32 consecutive tiles are a compact block that shares 8 A panels and 4 B panels in an XCD's L2).  Whole rounds of `slots` tiles run over all of K;
 // the R tiles of the last, partial round are cut in two along K when both halves fit the round (2R <= slots) — `split` = 0 turns that off,
-// 2 cuts EVERY tile (finer-grained sharing of the CUs with the data-gradient chain of the other stream).
-void build_items(const WgShape& sh, std::vector<int4>& out, unsigned& atomic_mask) {
+// 2 cuts EVERY tile (experiments).  `out` = the work items, then the list of cut tiles for the second launch.
+void build_items(const WgShape& sh, std::vector<int4>& out, int& nitems, int& nsplit, unsigned& split_mask) {
     struct Tile { int p, m0, n0; };
     std::vector<Tile> tiles;
     for (int p = 0; p < sh.n; ++p) {
@@ -1564,11 +1547,11 @@ void build_items(const WgShape& sh, std::vector<int4>& out, unsigned& atomic_mas
     int whole = nt;                                                                        // tiles [0, whole) run over all of K
     if (sh.split == 2 && ks >= 2) whole = 0;
     else if (sh.split == 1 && ks >= 2) { const int R = nt % slots; if (R > 0 && 2 * R <= slots) whole = nt - R; }
-    atomic_mask = 0;
-    auto item = [&](const Tile& t, int kb, int n, bool atomic) {
+    split_mask = 0;
+    auto item = [&](const Tile& t, int kb, int n, bool part) {
         const int cs = (sh.cs[t.p] && t.n0 == 0) ? WG_COLSUM : 0;
-        if (atomic) atomic_mask |= 1u << t.p;
-        return make_int4(t.p | (atomic ? WG_ATOMIC : 0) | cs, t.m0, t.n0, kb | (n << 16));
+        if (part) split_mask |= 1u << t.p;
+        return make_int4(t.p | (part ? WG_PART : 0) | ((part && kb) ? WG_HALF1 : 0) | cs, t.m0, t.n0, kb | (n << 16));
     };
     std::vector<int4> lin;                                                                 // items in list order, before the XCD-aware placement
     for (int t = 0; t < whole; ++t) lin.push_back(item(tiles[t], 0, ks, false));
@@ -1585,11 +1568,13 @@ void build_items(const WgShape& sh, std::vector<int4>& out, unsigned& atomic_mas
         const int L = std::min(slots, total - r0);
         for (int b = 0; b < L; ++b) out[r0 + b] = lin[r0 + xcd_pos(b, L)];
     }
+    nitems = total; nsplit = nt - whole;
+    for (int t = whole; t < nt; ++t) out.push_back(make_int4(tiles[t].p | ((sh.cs[tiles[t].p] && tiles[t].n0 == 0) ? WG_COLSUM : 0), tiles[t].m0, tiles[t].n0, 0));
 }
 }  // namespace
 
-// CTMI_WGRAD_GROUP: 0 = off (four launches per block, split-K slabs: round 4), 1 (default) = grouped, the last partial round cut in two along K,
-// 2 = every tile cut in two, 3 = grouped, nothing cut
+// CTMI_WGRAD_GROUP: 0 = off (four launches per block, split-K slabs: round 4), 1 (default) = grouped, the tiles of the last partial round cut in two
+// along K (partials in the workspace + a small second launch), 2 = every tile cut in two (experiments), 3 = grouped, nothing cut
 int ctmi_wgrad_group_mode() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("CTMI_WGRAD_GROUP"); v = e ? std::max(0, atoi(e)) : 1; }
@@ -1608,7 +1593,7 @@ bool ctmi_wgrad_grouped_ok(const ctmi_wgrad_problem* pr, int n, int64_t T, int d
     return true;
 }
 
-extern "C" int ctmi_wgrad_grouped(const ctmi_wgrad_problem* pr, int n, int64_t T, int dtype, void* stream) {
+extern "C" int ctmi_wgrad_grouped(const ctmi_wgrad_problem* pr, int n, int64_t T, int dtype, void* workspace, int64_t workspace_bytes, void* stream) {
     CTMI_REQUIRE(pr != nullptr, "wgrad_grouped: null problem list");
     if (!ctmi_wgrad_grouped_ok(pr, n, T, dtype)) {
         ctmi_set_error("wgrad_grouped: unsupported problem set (bf16, <= %d problems, rows a multiple of 128 and columns of 256 of every gradient, T %% 32 == 0, "
@@ -1623,6 +1608,12 @@ extern "C" int ctmi_wgrad_grouped(const ctmi_wgrad_problem* pr, int n, int64_t T
     sh.n = n; sh.ksteps = T / 32; sh.slots = slots;
     const int mode = ctmi_wgrad_group_mode();
     sh.split = mode == 3 ? 0 : (mode == 2 ? 2 : 1);
+    // the K-halves need 2 x (M N + M) floats per cut problem: without that much workspace nothing is cut
+    {
+        int64_t need = 0;
+        for (int i = 0; i < n; ++i) { const int64_t M = pr[i].in_out ? pr[i].n_in : pr[i].n_out, N = pr[i].in_out ? pr[i].n_out : pr[i].n_in; need += 2 * (M * N + M) * 4 + 512; }
+        if (workspace == nullptr || workspace_bytes < need || (((uintptr_t)workspace) & 15)) sh.split = 0;
+    }
     GroupedArgs g = {};
     g.M = 128; g.N = 256; g.K = T; g.k_per_split = T; g.splits = 1; g.alpha = 1.0f;       // (the single-problem fields are not read by a grouped launch)
     for (int i = 0; i < n; ++i) {
@@ -1643,8 +1634,7 @@ extern "C" int ctmi_wgrad_grouped(const ctmi_wgrad_problem* pr, int n, int64_t T
         if (it == g_wg_tables.end()) {
             std::vector<int4> items;
             WgTable t;
-            build_items(sh, items, t.atomic_mask);
-            t.nitems = (int)items.size();
+            build_items(sh, items, t.nitems, t.nsplit, t.split_mask);
             if (hipMalloc(&t.dev, items.size() * sizeof(int4)) != hipSuccess) { ctmi_set_error("wgrad_grouped: cannot allocate the work list"); return CTMI_ERR_LAUNCH; }
             // synchronous copy, once per geometry and device: the list is read by every later launch on any stream
             if (hipMemcpy(t.dev, items.data(), items.size() * sizeof(int4), hipMemcpyHostToDevice) != hipSuccess) { ctmi_set_error("wgrad_grouped: cannot upload the work list"); return CTMI_ERR_LAUNCH; }
@@ -1653,21 +1643,25 @@ extern "C" int ctmi_wgrad_grouped(const ctmi_wgrad_problem* pr, int n, int64_t T
         tab = it->second;
     }
     g.items = tab.dev; g.nitems = tab.nitems;
-    if (tab.atomic_mask) {
-        ZeroRegions z = {};
-        for (int i = 0; i < n; ++i)
-            if (tab.atomic_mask & (1u << i)) {
-                z.p[z.count] = g.p[i].C; z.n[z.count] = g.p[i].M * g.p[i].N; ++z.count;
-                if (g.p[i].cs) { z.p[z.count] = g.p[i].cs; z.n[z.count] = g.p[i].M; ++z.count; }
-            }
-        hipLaunchKernelGGL(zero_regions_k, dim3(1024), dim3(256), 0, st, z);
-        CTMI_CHECK_LAUNCH("wgrad_grouped_zero");
+    if (tab.nsplit) {                                                                     // partial slabs of the cut problems, carved out of the workspace
+        char* w = reinterpret_cast<char*>(workspace);
+        for (int i = 0; i < n; ++i) {
+            g.p[i].part = reinterpret_cast<float*>(w); w += 2 * g.p[i].M * g.p[i].N * 4;
+            g.p[i].cspart = reinterpret_cast<float*>(w); w += (2 * g.p[i].M * 4 + 255) / 256 * 256;
+        }
     }
     constexpr size_t lds = 6 * (size_t)(GTile<true, 128>::BYTES + GTile<true, 256>::BYTES);
     const unsigned grid = (unsigned)((persist && tab.nitems > slots) ? slots : tab.nitems);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wgrad_grouped_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(gemm_wgrad_grouped_kernel, dim3(grid), dim3(512), lds, st, g);
     CTMI_CHECK_LAUNCH("wgrad_grouped");
+    if (tab.nsplit) {
+        WgReduceArgs z = {};
+        for (int i = 0; i < n; ++i) z.p[i] = g.p[i];
+        z.tiles = tab.dev + tab.nitems; z.ntiles = tab.nsplit;
+        hipLaunchKernelGGL(wgrad_partials_reduce_k, dim3(4 * tab.nsplit), dim3(256), 0, st, z);
+        CTMI_CHECK_LAUNCH("wgrad_grouped_reduce");
+    }
     return CTMI_OK;
 }
 #endif

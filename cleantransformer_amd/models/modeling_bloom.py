@@ -88,7 +88,7 @@ def alibi_slopes(num_heads: int) -> Tensor:
 
 import os as _os
 
-_WGRAD_SIDE_STREAM = _os.environ.get("CTMI_WGRAD_STREAM", "1") != "0"
+_WGRAD_SIDE_STREAM = None       # None = ops.bloom_block_bwd decides (side stream unless the grouped weight-gradient launch applies); True / False force it (bench.py's breakdown pass)
 _CHECK_IDS = _os.environ.get("CTMI_CHECK_IDS", "0") == "1"
 
 
@@ -116,6 +116,7 @@ class BloomBlockFn(torch.autograd.Function):
         params = (ln1_w.detach(), ln1_b.detach(), ops.compute_weight(wqkv, cd), bqkv.detach(), ops.compute_weight(wd, cd), bd.detach(),
                   ln2_w.detach(), ln2_b.detach(), ops.compute_weight(w1, cd), b1.detach(), ops.compute_weight(w2, cd), b2.detach())
         acts = ops.bloom_block_fwd(x2, params, actx.mask, actx.slopes, eps, post_ln_res, B, S, actx.nh)
+        ops.note_block_params(actx.mask, (ln1_w, ln1_b, wqkv, bqkv, wd, bd, ln2_w, ln2_b, w1, b1, w2, b2))
         # The slab is a tensor: it goes through save_for_backward (released right after this node's backward — as a Python attribute of
         # ctx it lived as long as anything referenced the graph, i.e. through the NEXT step's forward in the reference loop); only
         # geometry stays on ctx.  Without a graph nothing is saved and the K/V presents are copied out (ops.LazyKV).
@@ -145,9 +146,9 @@ class BloomBlockFn(torch.autograd.Function):
         # back into the current stream before the call returns, so everything downstream (autograd accumulation, DDP hooks,
         # optimizer) is ordered.
         ctx.kv.release()
-        side = _WGRAD_SIDE_STREAM and x2.is_cuda
-        # single process, no accumulation pending, no gradient hooks: the side stream is joined once, at the end of the backward pass
-        defer = side and ops.params_allow_deferred_grads((ln1_w, ln1_b, wqkv, bqkv, wd, bd, ln2_w, ln2_b, w1, b1, w2, b2))
+        side = _WGRAD_SIDE_STREAM
+        # single process, no accumulation pending, no gradient hooks: a side stream (if one is used at all) is joined once, at the end of the backward pass
+        defer = side is not False and x2.is_cuda and ops.params_allow_deferred_grads((ln1_w, ln1_b, wqkv, bqkv, wd, bd, ln2_w, ln2_b, w1, b1, w2, b2), ctx.actx.mask)
         dx, g = ops.bloom_block_bwd(ops.BlockActs.rebuild(slab, ctx.geo), x2, params, ctx.actx.mask, ctx.actx.slopes, ctx.eps, ctx.post_ln_res, dout2,
                                     use_side_stream=side, defer_join=defer)
         return (dx.view(B, S, H), *g, None, None, None, None)

@@ -165,6 +165,7 @@ class GPT2BlockFn(torch.autograd.Function):
                   n2w.detach(), n2b.detach(), ops.compute_weight(wf, cd), bf.detach(), ops.compute_weight(wo, cd), bo.detach())
         acts = ops.bloom_block_fwd(x2, params, mask, None, eps, False, B, S, nh, flags=_lib.BLK_QKV_BLOCKED | _lib.BLK_WGRAD_IN_OUT | _lib.BLK_W_IN_OUT,
                                    attn_scale=scale, future_fill=-1e4)
+        ops.note_block_params(mask, (n1w, n1b, wa, ba, wp, bp, n2w, n2b, wf, bf, wo, bo))
         grad = getattr(kv_out, "grad", True) and any(ctx.needs_input_grad)                                # see BloomBlockFn: slab through save_for_backward, presents lazily
         if grad:
             ctx.save_for_backward(x2, n1w, n1b, wa, ba, wp, bp, n2w, n2b, wf, bf, wo, bo, acts.slab)
@@ -187,7 +188,7 @@ class GPT2BlockFn(torch.autograd.Function):
         params = (n1w.detach(), n1b.detach(), ops.compute_weight(wa, cd), ba.detach(), ops.compute_weight(wp, cd), bp.detach(),
                   n2w.detach(), n2b.detach(), ops.compute_weight(wf, cd), bf.detach(), ops.compute_weight(wo, cd), bo.detach())
         ctx.kv.release()
-        defer = x2.is_cuda and ops.params_allow_deferred_grads((n1w, n1b, wa, ba, wp, bp, n2w, n2b, wf, bf, wo, bo))
+        defer = x2.is_cuda and ops.params_allow_deferred_grads((n1w, n1b, wa, ba, wp, bp, n2w, n2b, wf, bf, wo, bo), ctx.mask)
         dx, g = ops.bloom_block_bwd(ops.BlockActs.rebuild(slab, ctx.geo), x2, params, ctx.mask, None, ctx.eps, False, dout2, defer_join=defer)
         return (dx.view(B, S, H), *g, None, None, None, None, None)
 

@@ -199,7 +199,8 @@ def wgrad_grouped(problems, in_out: bool = False):
         arr[i].dy, arr[i].x, arr[i].dw, arr[i].db = dy.data_ptr(), x.data_ptr(), dw.data_ptr(), (None if db is None else db.data_ptr())
         arr[i].n_out, arr[i].n_in, arr[i].in_out = n_out, n_in, int(in_out)
         outs.append((dw, db))
-    check(lib.ctmi_wgrad_grouped(arr, len(problems), T, dt_code(problems[0][0].dtype), _stream()), "wgrad_grouped")
+    ws = _splitk_ws(problems[0][0].device)
+    check(lib.ctmi_wgrad_grouped(arr, len(problems), T, dt_code(problems[0][0].dtype), ws.data_ptr(), ws.numel() * 4, _stream()), "wgrad_grouped")
     return outs
 
 
@@ -216,10 +217,11 @@ def colsum(x2d: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) 
 # ------------------------------------------------------------------------------------------------ attention
 class MaskInfo:
     """Device-side digest of attention_mask [B,S]: ALiBi key positions, key validity, first valid key."""
-    __slots__ = ("kpos", "kvalid", "first_valid", "B", "S")
+    __slots__ = ("kpos", "kvalid", "first_valid", "B", "S", "seen_params", "shared_params")
 
     def __init__(self, attention_mask: Tensor):
         _need_cuda(attention_mask)
+        self.seen_params, self.shared_params = set(), False             # per-forward record of the block parameters (see note_block_params)
         am = _c(attention_mask.to(torch.int64))
         B, S = am.shape
         self.B, self.S = B, S
@@ -463,11 +465,51 @@ _LAST_DEFERRED_GRAD_PTRS = []
 _DEFER_JOIN = os.environ.get("CTMI_WGRAD_DEFER_JOIN", "1") != "0"
 
 
-def params_allow_deferred_grads(params) -> bool:
+_DEFER_HOLDS = 0
+
+
+def hold_deferred_wgrad_join() -> None:
+    """THE CONTRACT for anything that touches parameter gradients DURING a backward pass — gradient hooks of any kind (tensor hooks,
+    post-accumulate hooks, hooks on the AccumulateGrad node as torch DDP / FSDP / apex register them), bucket copies, in-backward optimizers:
+    call this once (and release_deferred_wgrad_join() when detached).  While any hold is active the block backward joins its weight-gradient
+    side stream before it returns, so a gradient handed to autograd is complete on the compute stream.  cleantransformer_amd's
+    DistributedDataParallel holds it for its lifetime; CTMI_WGRAD_DEFER_JOIN=0 in the environment is the process-wide form."""
+    global _DEFER_HOLDS
+    _DEFER_HOLDS += 1
+
+
+def release_deferred_wgrad_join() -> None:
+    global _DEFER_HOLDS
+    _DEFER_HOLDS = max(0, _DEFER_HOLDS - 1)
+
+
+def note_block_params(mask: Optional["MaskInfo"], params) -> None:
+    """Called by a block node's forward with its parameters and the per-forward MaskInfo: a parameter that feeds TWO block nodes of one forward
+    (weights shared across layers) gets its two gradients summed by the autograd engine on the compute stream — the deferred join must stay off
+    for that forward."""
+    if mask is None:
+        return
+    seen = getattr(mask, "seen_params", None)
+    if seen is None:                                                    # (a per-forward context object other than ops.MaskInfo)
+        seen = set()
+        mask.seen_params, mask.shared_params = seen, False
+    for q in params:
+        k = id(q)
+        if k in seen:
+            mask.shared_params = True
+        seen.add(k)
+
+
+def params_allow_deferred_grads(params, mask: Optional["MaskInfo"] = None) -> bool:
     """The parameter gradients of a block may complete on the side stream AFTER the autograd node has returned only if nothing touches them
-    before the end of the backward pass: no accumulation into an existing .grad (AccumulateGrad would read them on the compute stream), no
-    gradient hooks (the data-parallel wrapper's bucket copy runs in one)."""
-    if not _DEFER_JOIN:
+    before the end of the backward pass.  Refused when: a hold is active (hold_deferred_wgrad_join: the explicit contract of wrappers that
+    install gradient hooks — the data-parallel wrapper's bucket copy runs in one), the environment says so, grad mode is on inside this
+    backward (backward(create_graph=True): AccumulateGrad then clones the gradient on the compute stream), a parameter of this forward feeds
+    two block nodes (the engine sums the two gradients on the compute stream), a gradient is already accumulated in .grad (AccumulateGrad adds
+    on the compute stream) — and, as a second line behind the contract, when torch's own hook lists on the parameter are non-empty."""
+    if not _DEFER_JOIN or _DEFER_HOLDS > 0 or torch.is_grad_enabled():
+        return False
+    if mask is not None and getattr(mask, "shared_params", False):
         return False
     for p in params:
         if p.grad is not None or getattr(p, "_post_accumulate_grad_hooks", None) or getattr(p, "_backward_hooks", None):
@@ -595,14 +637,33 @@ def bloom_block_fwd(x2: Tensor, params, mask: Optional[MaskInfo], slopes: Option
     return acts
 
 
+_GROUPED = {}
+_WGRAD_STREAM_ENV = os.environ.get("CTMI_WGRAD_STREAM", "auto")           # "1" / "0" force the weight-gradient side stream on / off
+
+
+def block_wgrad_grouped(B: int, S: int, H: int, dtype: torch.dtype, flags: int = 0) -> bool:
+    """Does the block backward take the grouped weight-gradient launch at this geometry (include/ctmi355.h ctmi_bloom_block_wgrad_grouped)?"""
+    key = (B, S, H, dtype, flags)
+    v = _GROUPED.get(key)
+    if v is None:
+        v = bool(_lib.load().ctmi_bloom_block_wgrad_grouped(B, S, H, dt_code(dtype), int(flags)))
+        _GROUPED[key] = v
+    return v
+
+
 def bloom_block_bwd(acts: BlockActs, x2: Tensor, params, mask: Optional[MaskInfo], slopes: Optional[Tensor], eps: float,
-                    post_ln_res: bool, dout2: Tensor, use_side_stream: bool = True, defer_join: bool = False):
+                    post_ln_res: bool, dout2: Tensor, use_side_stream: Optional[bool] = None, defer_join: bool = False):
     """Backward of bloom_block_fwd -> (dx [T,H] in the compute dtype, the 12 fp32 parameter gradients in BLK_PARAMS order).
+    use_side_stream None (default): the library's four weight-gradient products run on a side stream — unless the geometry takes the GROUPED
+    weight-gradient launch (round 5: bf16, aligned shapes), which fills the GPU by itself: the whole backward then runs on the compute stream
+    (same-box A/B, profiles/r05_wgrad_grouped.txt: 36.67 vs 36.98 ms per step; CTMI_WGRAD_STREAM=1 / 0 forces either).
     defer_join (only from inside a backward pass, with the side stream): the parameter gradients complete on the side stream; the compute
     stream waits for it ONCE, in a callback at the end of the backward pass (see params_allow_deferred_grads for when that is sound)."""
     _need_cuda(x2, dout2)
     B, S, H, nh = acts.B, acts.S, acts.H, acts.nh
     dev = x2.device
+    if use_side_stream is None:
+        use_side_stream = (_WGRAD_STREAM_ENV != "0") if _WGRAD_STREAM_ENV in ("0", "1") else not block_wgrad_grouped(B, S, H, x2.dtype, acts.flags)
     d = _lib.BloomBlock()
     _fill_block_desc(d, x2, params, mask, slopes, eps, post_ln_res, B, S, H, nh, acts.slab, acts.flags, acts.attn_scale, acts.future_fill)
     g = _lib.BloomBlockGrads()

@@ -79,19 +79,23 @@ class _TiedGradSync:
         self.owner = owner
         self.works = []
         self.active = False
-        self._pad_rows_for_test = 0                                  # tests only: extra row capacity, so that the padded exchange runs on one rank
         self.steps = 0                                               # how many backward passes took the early path
         self._tmax = None                                            # agreed row capacity of this step's exchange (announce)
         self._announced = False
         self._tbuf = self._thost = self._tstream = self._tevent = self._tall = None
+
+    def _single_rank(self) -> bool:
+        """One rank has nothing to exchange: the tied gradient takes the generic path.  (A method so that the one-rank GPU tests can run the
+        early path and the padded row exchange on the real backend by overriding it and _row_capacity — tests/test_gpu_bloom.py; the product
+        carries no test switches.)"""
+        return self.owner.world_size == 1
 
     def prescale(self, weight: torch.nn.Parameter):
         """1/world if this backward pass reduces the dense part early (the LM-head weight-gradient GEMM then applies it as
         its alpha: torch-DDP's pre-division at no cost), None for the generic bucket path (no sync, a single rank, or
         gradient accumulation pending in ``weight.grad``)."""
         o = self.owner
-        single = o.world_size == 1 and os.environ.get("CTMI_DDP_TIED_EARLY_AT_WORLD1") != "1"     # (test hook: exercise the path on 1 rank)
-        if not o.require_backward_grad_sync or single or weight.grad is not None:
+        if not o.require_backward_grad_sync or self._single_rank() or weight.grad is not None:
             return None
         return 1.0 / o.world_size
 
@@ -107,7 +111,7 @@ class _TiedGradSync:
         o = self.owner
         self._tmax = None
         self._announced = True
-        if o.world_size == 1 and self._pad_rows_for_test == 0 and os.environ.get("CTMI_DDP_TIED_EARLY_AT_WORLD1") != "1":
+        if self._single_rank():
             self._tmax = int(n_tokens)                               # single rank: nothing to agree on, no collective
             return
         on_rccl = dist.get_backend(o.process_group) == "nccl" and torch.device(device).type == "cuda"
@@ -153,7 +157,7 @@ class _TiedGradSync:
             self._tmax = int(self._thost[0])
         if self._tmax < n_local:
             raise RuntimeError(f"tied-gradient row exchange: announced capacity {self._tmax} < local rows {n_local}")
-        return self._tmax + self._pad_rows_for_test
+        return self._tmax
 
     CHUNK_ROWS_BYTES = 64 * _MiB                                   # one piece of the dense [V,H] reduction (fp32 bytes)
 
@@ -320,6 +324,11 @@ class DistributedDataParallel(torch.nn.Module):
         self._callback_queued = False
         self._launch_events = None                                    # record_launch_events(): [(kind, event)] of this step's collectives
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad_ready) for p in self._params]
+        # the bucket copies run in these hooks, on the compute stream: every gradient handed to autograd must be complete there (explicit
+        # contract, ops.hold_deferred_wgrad_join — not something for the block backward to guess from torch's private hook lists)
+        from .. import ops as _ops
+        _ops.hold_deferred_wgrad_join()
+        self._holds_join = True
 
     def _make_direct_comm(self):
         """CTMI_DDP_BACKEND=rccl: an RCCL communicator of libctmi355 for the step's gradient collectives (module docstring).  Its
@@ -490,12 +499,25 @@ class DistributedDataParallel(torch.nn.Module):
             self._arm_launch_policy()
         return self.module(*inputs, **kwargs)
 
+    def __del__(self):
+        try:
+            if getattr(self, "_holds_join", False):
+                from .. import ops as _ops
+                _ops.release_deferred_wgrad_join()
+                self._holds_join = False
+        except Exception:                                              # noqa: BLE001  (interpreter shutdown)
+            pass
+
     def close(self) -> None:
         """Detach from the module: remove the gradient hooks, drop the bucket memory and the library communicator.  bench.py's
         configuration probe wraps the same model several times (backend x launch policy) and keeps one."""
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        if getattr(self, "_holds_join", False):
+            from .. import ops as _ops
+            _ops.release_deferred_wgrad_join()
+            self._holds_join = False
         for b in self._buckets:
             b.flat = b.comm = b.work = None
         if self._tied_param is not None and getattr(self._tied_param, "_ct_tied_sync", None) is self._tied_sync:

@@ -79,10 +79,11 @@ int ctmi_gemm(const void* A, int64_t lda, int a_kmajor, const void* B, int64_t l
  *   dw[n_out, n_in] (fp32, overwritten) = dy[T, n_out]^T x[T, n_in]        dy, x: row-major, dense, bf16
  *   db[n_out]       (fp32, overwritten, optional) = column sums of dy      (the bias gradient; computed by the matrix cores against a vector of ones)
  *   in_out = 1: dw is written [n_in, n_out] (a Conv1D weight's own layout, modeling_gpt.py:32-46); db must be NULL then.
- * Output tiles are 128 x 256; whole rounds of the 256 CUs accumulate over all T rows, the tiles of the last partial round are cut in two along T
- * and their halves added into zeroed memory with fp32 atomics (two commutative contributions: bit-deterministic).  No split-K slabs, no reduce
- * launch, no separate column-sum pass.  Needs dtype = CTMI_BF16, n <= 4, T % 32 == 0, every gradient's rows a multiple of 128 and columns of 256,
- * 16-byte aligned pointers: anything else returns CTMI_ERR_UNSUPPORTED (callers then use ctmi_gemm(a_kmajor = b_kmajor = 1) per product).
+ * Output tiles are 128 x 256; whole rounds of the 256 CUs accumulate over all T rows, the tiles of the last partial round are cut in two along T:
+ * each half stores its partial tile into `workspace` and a small second launch adds the two in a fixed order (deterministic; without enough
+ * workspace — 2 x (rows x columns + rows) floats per gradient — nothing is cut).  No split-K slabs of whole gradients, no separate column-sum pass.
+ * Needs dtype = CTMI_BF16, n <= 4, T % 32 == 0, every gradient's rows a multiple of 128 and columns of 256, 16-byte aligned pointers: anything
+ * else returns CTMI_ERR_UNSUPPORTED (callers then use ctmi_gemm(a_kmajor = b_kmajor = 1) per product).
  * CTMI_WGRAD_GROUP = 0 in the environment disables it (ctmi_bloom_block_bwd then launches the four products separately, as in ABI <= 12). */
 typedef struct ctmi_wgrad_problem {
     const void* dy; const void* x;      /* device, [T, n_out] and [T, n_in] */
@@ -90,7 +91,8 @@ typedef struct ctmi_wgrad_problem {
     int64_t n_out, n_in;
     int in_out; int pad_;
 } ctmi_wgrad_problem;
-int ctmi_wgrad_grouped(const ctmi_wgrad_problem* problems /* host */, int count, int64_t T, int dtype, void* stream);
+int ctmi_wgrad_grouped(const ctmi_wgrad_problem* problems /* host */, int count, int64_t T, int dtype,
+                       void* workspace /* device, may be NULL */, int64_t workspace_bytes, void* stream);
 
 /* GEMM launch policy (process-wide).  shared = 0: the GPU is ours — persistent launches sized to the 256 CUs, one-workgroup-
  * per-CU ping-pong tiles.  shared = 1: another long-running kernel holds CUs under our GEMMs (the RCCL all-reduce of a
@@ -362,6 +364,10 @@ typedef struct ctmi_bloom_block_grads {
                                            this call's work (alternate two workspaces) */
 } ctmi_bloom_block_grads;
 int64_t ctmi_bloom_block_bwd_ws(int64_t B, int64_t S, int64_t H, int64_t nh, int dtype);
+/* (ABI v13) 1 if ctmi_bloom_block_bwd takes the grouped weight-gradient launch (ctmi_wgrad_grouped) at this geometry / dtype / flags: the caller then
+ * issues the whole backward on one stream (side_stream = NULL) — the grouped launch fills the GPU on its own; 0: the four products are separate
+ * launches that gain from a side stream. */
+int ctmi_bloom_block_wgrad_grouped(int64_t B, int64_t S, int64_t H, int dtype, int flags);
 int ctmi_bloom_block_bwd(const ctmi_bloom_block* blk /* host */, const ctmi_bloom_block_grads* gr /* host */, void* stream);
 
 /* ---- hardware probe (diagnostics: dumps MFMA / LDS-transpose lane layouts into out[]; used by tests only) */

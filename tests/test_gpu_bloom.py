@@ -400,7 +400,7 @@ def test_ddp_wrapper_on_rccl_single_rank(backend):
     code = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, os.getcwd())
-os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", CTMI_DDP_TIED_EARLY_AT_WORLD1="1", CTMI_DDP_TIED_CHUNK_ROWS="256")
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", CTMI_DDP_TIED_CHUNK_ROWS="256")
 os.environ["CTMI_DDP_BACKEND"] = "@BACKEND@"
 os.environ["CTMI_DDP_MAX_CHANNELS"] = "8"
 dist.init_process_group("nccl", rank=0, world_size=1)
@@ -434,7 +434,12 @@ ref = make()
 (l0, _, _), _ = ref(input_ids=ids, attention_mask=am, labels=ids.clone()); l0.backward()
 m = make(); ddp = DDP(m, device_ids=[0], bucket_cap_mb=0.25)
 assert (ddp._direct is not None) == ("@BACKEND@" == "rccl")
-ddp._tied_sync._pad_rows_for_test = 37          # capacity != local rows: the padded id / row exchange (all_gather_into_tensor) on the real backend
+# the test, not the product, makes one rank behave like one of many: the early path is taken, and the agreed capacity exceeds the local rows by 37
+# (capacity != local rows: the padded id / row exchange — all_gather_into_tensor — on the real backend)
+ts = ddp._tied_sync
+ts._single_rank = lambda: False
+_cap = ts._row_capacity
+ts._row_capacity = lambda n_local: _cap(n_local) + 37
 evs = ddp.record_launch_events()
 for it in range(2):
     for p in m.parameters(): p.grad = None
