@@ -1585,7 +1585,10 @@ bool ctmi_wgrad_grouped_ok(const ctmi_wgrad_problem* pr, int n, int64_t T, int d
     if (ctmi_wgrad_group_mode() == 0 || !glds_enabled() || dtype != CTMI_BF16 || n < 1 || n > WG_MAXP || T < 64 || T % 32 != 0 || T / 32 > 0x7fff) return false;
     for (int i = 0; i < n; ++i) {
         const int64_t M = pr[i].in_out ? pr[i].n_in : pr[i].n_out, N = pr[i].in_out ? pr[i].n_out : pr[i].n_in;
-        if (M <= 0 || N <= 0 || M % 128 != 0 || N % 256 != 0 || M * N > (1LL << 31)) return false;
+        if (M <= 0 || N <= 0 || M % 128 != 0 || N % 256 != 0) return false;
+        // gradients of >= 32 Mi elements fill the GPU with 256x256 tiles on their own (>= 512 of them), at a higher rate than this launch's
+        // 128x256 tiles reach (Bloom-7B1 geometry, one GPU: 213.8 ms per step per-product vs 216.9 grouped, profiles/r05_wgrad_grouped.txt)
+        if (M * N >= (32LL << 20)) return false;
         if (!pr[i].dy || !pr[i].x || !pr[i].dw) return false;
         if ((((uintptr_t)pr[i].dy) | ((uintptr_t)pr[i].x) | ((uintptr_t)pr[i].dw)) & 15) return false;
         if (pr[i].db && (pr[i].in_out || (((uintptr_t)pr[i].db) & 3))) return false;       // the column sums ride on the A operand: dy must be it

@@ -110,14 +110,19 @@ def test_presents_after_backward_and_inplace_on_a_block_output_fail_loudly():
     assert pres[L - 1][1].is_contiguous()
 
 
-def test_deferred_side_stream_join_equals_joined_backward_bit_for_bit():
-    """Round 4: with no accumulation pending and no gradient hooks the weight-gradient side stream is joined ONCE, at the end of the backward
+@pytest.mark.parametrize("S,force_side", [(256, True), (250, None)], ids=["grouped-launch-on-the-side-stream", "per-product-launches"])
+def test_deferred_side_stream_join_equals_joined_backward_bit_for_bit(S, force_side):
+    """(Round 5: geometries that take the grouped weight-gradient launch run their whole backward on ONE stream by default — T = 1024 here; the
+    first case forces the side stream for them, the second uses T = 1000, which the grouped launch refuses: four products, side stream by default.)
+    Round 4: with no accumulation pending and no gradient hooks the weight-gradient side stream is joined ONCE, at the end of the backward
     pass (ops.bloom_block_bwd(defer_join=True); two alternating scratch buffers, record_stream on what the side stream still touches).  Same
     kernels, same order per stream: every gradient must be bit-identical to the per-block join (CTMI_WGRAD_DEFER_JOIN=0 semantics), autograd
     must ADOPT the gradient tensors (a copy on the compute stream would read them before the side stream has written them), and with an
     existing .grad (accumulation) the node must fall back to the joined form."""
     from cleantransformer_amd import ops as o
-    V, H, L, nh, B, S = 512, 256, 6, 4, 4, 256                                     # large enough for the side stream to lag the main stream
+    from cleantransformer_amd.models import modeling_bloom as MB
+    V, H, L, nh, B = 512, 256, 6, 4, 4                                            # large enough for the side stream to lag the main stream
+    assert o.block_wgrad_grouped(B, S, H, torch.bfloat16) == (force_side is True)
     torch.manual_seed(3)
     params = {n: (torch.randn(s) * 0.05 if len(s) > 1 else (torch.ones(s) if "layernorm.weight" in n or "ln_f.weight" in n else torch.zeros(s)))
               for n, s in ((n, R.param_shape(R.BloomShape(V, H, L, nh), n)) for n in R.param_names(R.BloomShape(V, H, L, nh)))}
@@ -125,8 +130,9 @@ def test_deferred_side_stream_join_equals_joined_backward_bit_for_bit():
     am = torch.ones(B, S, dtype=torch.long, device=DEV)
 
     def run(defer, steps=1, zero=True):
-        old = o._DEFER_JOIN
+        old, old_side = o._DEFER_JOIN, MB._WGRAD_SIDE_STREAM
         o._DEFER_JOIN = defer
+        MB._WGRAD_SIDE_STREAM = force_side
         try:
             m = build(V, H, L, nh, compute_dtype="bf16", params=params)
             for _ in range(steps):
@@ -138,7 +144,7 @@ def test_deferred_side_stream_join_equals_joined_backward_bit_for_bit():
             torch.cuda.synchronize()
             return m, {n: p.grad.clone() for n, p in m.named_parameters()}
         finally:
-            o._DEFER_JOIN = old
+            o._DEFER_JOIN, MB._WGRAD_SIDE_STREAM = old, old_side
     m1, g_join = run(False)
     assert o._LAST_DEFERRED_GRAD_PTRS == []
     m2, g_def = run(True)

@@ -64,7 +64,7 @@ BLOOM = [(1024, 4096, False), (4096, 1024, True), (1024, 1024, False), (3072, 10
     (512, [(256, 256, True)]),                                        # one problem, two tiles: both cut
     (256, [(128, 256, True), (256, 512, False), (384, 256, True)]),   # three problems, 1 + 4 + 3 tiles
     (1024, [(2048, 4096, True), (4096, 2048, False)]),                # 256 + 256 tiles: two whole rounds, nothing cut, column sums in a whole tile
-    (2048, [(4096, 4096, True)]),                                     # 512 tiles of one problem
+    (2048, [(4096, 2048, True), (2048, 4096, True)]),                 # 512 tiles
 ], ids=lambda v: str(v) if isinstance(v, int) else f"{len(v)}p")
 def test_grouped_weight_gradients_vs_fp64_and_per_product(T, shapes):
     o = ops()
@@ -102,7 +102,7 @@ def test_grouped_weight_gradients_in_out_layout():
 def test_grouped_weight_gradients_refuse_what_the_tiling_cannot_take():
     o = ops()
     for T, shapes in ((32, [(256, 256, False)]), (100, [(256, 256, False)]), (256, [(192, 256, False)]), (256, [(256, 128, False)]),
-                      (256, [(256, 256, False)] * 5)):
+                      (256, [(256, 256, False)] * 5), (64, [(8192, 4096, False)])):            # (the last: >= 32 Mi elements — left to the 256x256 tiles)
         with pytest.raises(lib().CtmiError):
             o.wgrad_grouped(_problems(T, shapes, seed=1))
     with pytest.raises(lib().CtmiError):                             # fp32 operands: parity mode keeps the per-product kernels
