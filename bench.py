@@ -225,6 +225,8 @@ def main(argv=None):
                     help="N > 1: gradient collectives through torch.distributed (default) or the library's own RCCL communicator (ctmi_ddp_*)")
     ap.add_argument("--no-comm-probe", action="store_true",
                     help="N > 1: do not time the backend x launch-policy candidates during warm-up; run --ddp-backend / CTMI_DDP_LAUNCH_POLICY as given")
+    ap.add_argument("--probe-rccl", action="store_true", help="--gpus N > 1: also time the library's own RCCL communicator (csrc/comm.hip) among the candidates")
+    ap.add_argument("--no-power-sampler", action="store_true", help="do not sample rocm-smi power / clocks beside the timed steps")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the per-class HIP-event pass after the timed region")
     ap.add_argument("--no-padded-sample", action="store_true", help="skip the secondary sample with 25 %% of every row right-padded")
     args = ap.parse_args(argv)
@@ -283,11 +285,31 @@ def main(argv=None):
         chosen = (args.ddp_backend, os.environ.get("CTMI_DDP_LAUNCH_POLICY", "shared"))
         if not args.no_comm_probe:
             comm_candidates = []
-            for backend in ("torch", "rccl"):
+            # (round 5) the library's own RCCL communicator is only probed on request (--probe-rccl): it has never run at world > 1, and a
+            # candidate that HANGS takes the whole measurement with it; torch.distributed's RCCL backend x the two launch policies is the default
+            for backend in (("torch", "rccl") if args.probe_rccl else ("torch",)):
                 for policy in ("shared", "reserve"):
                     rec = {"ddp_backend": backend, "launch_policy": policy}
+                    # phase 1: wrap.  Every rank reports whether ITS wrapper exists before any rank enters the wrapper's collectives — a
+                    # candidate that cannot be built on one rank (no librccl there, a communicator error) is skipped by all (round-4 advisor)
                     try:
-                        holder["net"] = wrap(backend, policy)
+                        net = wrap(backend, policy)
+                        werr = None
+                    except Exception as e:                                   # noqa: BLE001
+                        net, werr = None, f"{type(e).__name__}: {e}"[:200]
+                    wt = torch.tensor([0.0 if net is not None else 1.0], dtype=torch.float64, device=device)
+                    dist.all_reduce(wt, op=dist.ReduceOp.MAX)
+                    if float(wt[0]) > 0.5:
+                        if net is not None:
+                            net.close()
+                        rec["error"] = werr or "the wrapper could not be built on another rank"
+                        rec["ms_per_step"] = None
+                        comm_candidates.append(rec)
+                        if rank == 0:
+                            print(f"[bench] comm candidate {rec}", file=sys.stderr, flush=True)
+                        continue
+                    try:
+                        holder["net"] = net
                         step()
                         torch.cuda.synchronize()
                         dist.barrier()
@@ -353,7 +375,7 @@ def main(argv=None):
     clock_before = ops.clock_probe(device)                                 # shader clock under MFMA load, chip warm from the warm-up steps
     timer = ops.KernelTimer(["lm_head_fwd"])
     ops.set_timer(timer)
-    sampler = _PowerSampler().start() if rank == 0 else None
+    sampler = _PowerSampler().start() if (rank == 0 and not args.no_power_sampler) else None
     dt, per_step_ms, host_loop_s, loss = timed_steps(args.steps)
     ops.set_timer(None)
     if sampler is not None:
@@ -361,7 +383,12 @@ def main(argv=None):
     clock_after = ops.clock_probe(device)                                  # ... and right after the timed steps
     smi_after = _smi_snapshot() if rank == 0 else None
     final_loss = float(loss.detach())
-    if not (math.isfinite(final_loss) and 0.0 < final_loss < 2.0 * math.log(V)):
+    bad_loss = not (math.isfinite(final_loss) and 0.0 < final_loss < 2.0 * math.log(V))
+    if world > 1:                                                         # every rank leaves together (a lone exit would hang the others in the next all-reduce)
+        bl = torch.tensor([1.0 if bad_loss else 0.0], dtype=torch.float64, device=device)
+        dist.all_reduce(bl, op=dist.ReduceOp.MAX)
+        bad_loss = bool(float(bl[0]) > 0.5) or bad_loss
+    if bad_loss:
         # A timing of garbage is not a measurement — and it is not even conservative: MFMAs on NaN operands draw less power, the chip clocks
         # higher and EVERY kernel of the step runs ~8 % faster (measured in round 4 on a build with a data race: profiles/r04_k2_pairs.txt).
         raise SystemExit(f"bench.py: the loss after the timed steps is {final_loss} (random-init start: ~{math.log(V):.1f}) — "

@@ -71,7 +71,7 @@ class GradScaler():
                 # from the next forward on, the fused loss folds this scale into dlogits (ops.set_expected_loss_grad): the backward of
                 # scaler.scale(loss) then finds its upstream gradient already applied and skips the rescale pass over [T,V]
                 from . import ops
-                ops.set_expected_loss_grad(scale=self._state[0:1])
+                ops.set_expected_loss_grad(scale=self._state[0:1], owner=self)
         return self._state
 
     def is_enabled(self):

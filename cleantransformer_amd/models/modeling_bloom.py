@@ -406,6 +406,10 @@ class ShiftedCrossEntropyFn(torch.autograd.Function):
             fac, fdev = ops.current_expected_loss_grad()
             if fdev is not None and fdev.device != l2.device:
                 fdev = None
+            if fdev is not None:
+                # a private snapshot: the node compares the gradient that arrives in backward with what THIS forward folded, also when the
+                # scaler's live scale has moved in between (update() / load_state_dict() between forward and backward; round-4 advisor)
+                fdev = fdev.clone()
             loss_out, _, dl = ops.ce_fwd_bwd(l2, lab, seq=S, shift=1, ignore_index=-100, denom_mode=0, grad_factor=fac, grad_factor_dev=fdev)
             ctx.dl, ctx.used, ctx.applied = dl, False, (fac, fdev)
             return loss_out[0].clone()

@@ -357,21 +357,26 @@ def ce_soft_bwd(logits2d: Tensor, target: Tensor, row_lse: Tensor, row_tsum: Ten
 # (trainer.py:468-504 backpropagates `loss / ga`), the loss scale of a GradScaler (ft_bloom_DDP.py:123-127: a device scalar), or both.
 # The fused loss folds it into dlogits in its one pass (fp32, one rounding); its backward then rescales only if the gradient that actually
 # arrives is a different number.  Process-wide (the training loop is single-threaded on the forward side).
-_EXPECTED_LOSS_GRAD = {"factor": 1.0, "dev": None}
+_EXPECTED_LOSS_GRAD = {"factor": 1.0, "dev": None, "owner": None}
 
 
-def set_expected_loss_grad(factor: Optional[float] = None, scale: Optional[Tensor] = None) -> None:
-    """Persistent form (amp.GradScaler registers its device scale here); `None` leaves a field as it is, `scale=False` clears it."""
+def set_expected_loss_grad(factor: Optional[float] = None, scale: Optional[Tensor] = None, owner=None) -> None:
+    """Persistent form (amp.GradScaler registers its device scale here); `None` leaves a field as it is, `scale=False` clears it.
+    `owner` (the scaler) is held by weak reference: the registration ends with the scaler — deleted or disabled — instead of folding a
+    stale scale into every later loss of the process (round-4 advisor).  One registration at a time: a second scaler replaces the first;
+    that costs the first its saved rescale pass, never correctness (the loss node compares what it folded with what arrives)."""
     if factor is not None:
         if not factor > 0.0:
             raise ValueError("expected loss gradient factor must be > 0")
         _EXPECTED_LOSS_GRAD["factor"] = float(factor)
     if scale is False:
-        _EXPECTED_LOSS_GRAD["dev"] = None
+        _EXPECTED_LOSS_GRAD["dev"] = _EXPECTED_LOSS_GRAD["owner"] = None
     elif scale is not None:
         if scale.numel() != 1 or scale.dtype != torch.float32:
             raise ValueError("expected loss gradient scale: one fp32 element on the device")
+        import weakref
         _EXPECTED_LOSS_GRAD["dev"] = scale
+        _EXPECTED_LOSS_GRAD["owner"] = weakref.ref(owner) if owner is not None else None
 
 
 @contextlib.contextmanager
@@ -386,6 +391,11 @@ def expected_loss_grad(factor: float = 1.0):
 
 
 def current_expected_loss_grad():
+    own = _EXPECTED_LOSS_GRAD["owner"]
+    if _EXPECTED_LOSS_GRAD["dev"] is not None and own is not None:
+        o = own()
+        if o is None or not o.is_enabled():                             # the scaler that registered this scale is gone
+            _EXPECTED_LOSS_GRAD["dev"] = _EXPECTED_LOSS_GRAD["owner"] = None
     return _EXPECTED_LOSS_GRAD["factor"], _EXPECTED_LOSS_GRAD["dev"]
 
 

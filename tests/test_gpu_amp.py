@@ -120,3 +120,48 @@ def test_overflow_skips_and_torch_scaler_interop():
         ts.update()
         assert abs(float(loss) - TINY["traj"][t, 0]) <= 1e-5 * TINY["traj"][t, 0]
     assert opt.steps[0] == 3
+
+
+def test_scaler_registration_ends_with_the_scaler_and_a_moved_scale_is_noticed():
+    """Round-4 advisor: (a) the loss scale a GradScaler registers for the fused loss (ops.set_expected_loss_grad) is held by weak reference:
+    after the scaler is deleted or disabled no later loss folds it; (b) the loss node snapshots the scale it folded — when the scaler's live
+    scale moves between forward and backward the rescale is NOT skipped: dlogits equal the unscaled gradient x the scale that backward sends."""
+    import gc
+    from cleantransformer_amd import ops
+    from cleantransformer_amd.amp import GradScaler
+    from cleantransformer_amd.models.modeling_bloom import ShiftedCrossEntropyFn
+    ops.set_expected_loss_grad(factor=1.0, scale=False)
+    g = torch.Generator().manual_seed(5)
+    B, S, V = 2, 8, 4096
+    logits0 = torch.randn(B, S, V, generator=g).to(DEV).to(torch.bfloat16)
+    labels = torch.randint(0, V, (B, S), generator=g).to(DEV)
+
+    def dlogits(upstream):
+        lg = logits0.clone().requires_grad_(True)
+        loss = ShiftedCrossEntropyFn.apply(lg, labels)
+        return lg, loss
+
+    lg, loss = dlogits(None)
+    loss.backward()
+    plain = lg.grad.float().clone()
+
+    sc = GradScaler(init_scale=256.0)
+    lg, loss = dlogits(None)
+    scaled = sc.scale(loss)                                                  # first use: registers the device scale (for the NEXT forward)
+    scaled.backward()
+    assert torch.equal(lg.grad.float(), plain * 256.0)
+    assert ops.current_expected_loss_grad()[1] is not None
+    # the next forward folds 256; then the scale moves to 64 BEFORE backward: the node must rescale by 64 / 256, not skip
+    lg, loss = dlogits(None)
+    sc.update(new_scale=64.0)
+    sc.scale(loss).backward()
+    assert torch.allclose(lg.grad.float(), plain * 64.0, rtol=2.0 ** -7, atol=0.0)      # (one extra bf16 rounding from the rescale pass)
+    # the scaler goes away: no later loss folds its scale
+    del sc, scaled
+    gc.collect()
+    assert ops.current_expected_loss_grad()[1] is None
+    lg, loss = dlogits(None)
+    loss.backward()
+    assert torch.equal(lg.grad.float(), plain)
+    off = GradScaler(init_scale=8.0, enabled=False)
+    assert off.scale(loss.detach()) is not None and ops.current_expected_loss_grad()[1] is None

@@ -581,7 +581,21 @@ def test_config1_full_size_bf16_and_fp32_vs_oracle():
         loss_o, logits_o, _, grads_o = R.loss_and_grads(p, sh, ids, am)
         gn_o, am_o = R.grad_norm(grads_o.values()), logits_o.argmax(-1)
     loss_o = float(loss_o)
-    del logits_o, grads_o
+    del logits_o
+    grads_o["lm_head.weight"] = grads_o["bloom.word_embeddings.weight"]           # tied: one tensor, one gradient
+
+    def per_parameter(m, rel_bar, what):
+        """Round-4 verdict: a wrong gradient in ONE matrix of one layer is ~1e-3 of the global norm and passes a global bar.  Every parameter's
+        gradient, norm-wise: ||g - g_oracle|| <= rel_bar * ||g_oracle|| + 1e-7 * (global norm) — the absolute term for parameters whose
+        gradient is ~0.  Returns the worst (relative error, name)."""
+        worst = (0.0, "")
+        for n, q in m.named_parameters():
+            ref = grads_o[n].double()
+            d = float((q.grad.double().cpu() - ref).norm())
+            rn = float(ref.norm())
+            worst = max(worst, (d / (rn + 1e-30), n))
+            assert d <= rel_bar * rn + 1e-7 * gn_o, (what, n, d / (rn + 1e-30), rn)
+        return worst
 
     def gpu(cd):
         m = build(V, H, L, nh, compute_dtype=cd, params=p)
@@ -592,13 +606,17 @@ def test_config1_full_size_bf16_and_fp32_vs_oracle():
         return m, out
 
     m32, (l32, g32, a32) = gpu("fp32")
-    del m32
     assert abs(l32 - loss_o) <= 1e-4 * loss_o, (l32, loss_o)
     assert abs(g32 - gn_o) <= 1e-4 * gn_o, (g32, gn_o)
+    w32 = per_parameter(m32, 1e-4, "fp32")                             # the north star's 1e-4, per parameter (294 tensors)
+    del m32
     assert float((a32 == am_o).float().mean()) > 0.999                # fp32 near-ties at V = 250880 may flip an argmax
     m, (loss0, gn, a16) = gpu("bf16")
     assert abs(loss0 - loss_o) <= 3e-3 * loss_o, (loss0, loss_o)
     assert abs(gn - gn_o) <= 3e-2 * gn_o, (gn, gn_o)
+    w16 = per_parameter(m, 4e-2, "bf16")                               # bf16 operands through 24 layers: norm-wise per parameter (measured worst 1.7e-2, printed below)
+    print(f"\nconfigs[1] per-parameter gradient error vs the oracle: fp32 worst {w32[0]:.2e} ({w32[1]}), bf16 worst {w16[0]:.2e} ({w16[1]})")
+    del grads_o
     assert float((a16 == am_o).float().mean()) > 0.97                 # bf16 rounding may flip near-ties only
     # properties at this size
     with torch.no_grad():
@@ -626,6 +644,49 @@ def test_config1_full_size_bf16_and_fp32_vs_oracle():
         losses.append(float(loss.detach()))
     assert abs(losses[0] - loss0) <= 1e-6 * loss0                      # same parameters: same loss
     assert all(math.isfinite(x) for x in losses) and losses[0] > losses[1] > losses[2], losses
+
+
+def test_config1_full_size_greedy_decode_bit_exact_vs_oracle():
+    """north_star: "bit-exact for token indexing / argmax decode" — at the FULL vocabulary and depth (V = 250 880, 24 layers, fp32 parity mode):
+    GenerationMixin._greedy_search (generation_util.py:57-119: KV-cached forward, argmax, append) against oracle.bloom_ref.greedy_decode, 8 new
+    tokens (+ the two of the loop-exit quirk) for a ragged LEFT-padded batch.  The oracle is re-run step by step beside it to know every
+    step's top-1 / top-2 margin: wherever that margin exceeds fp32 round-off (1e-4 of the logit scale) the ids must be identical; a narrower
+    margin — an fp32 near-tie among 250 880 candidates, not seen with this seed — would be reported, not silently accepted."""
+    V, H, L, nh = 250880, 1024, 24, 16
+    sh = R.BloomShape(V, H, L, nh)
+    p = R.det_init(sh)
+    g = torch.Generator().manual_seed(77)
+    B, S0, NEW = 2, 12, 8
+    ids = torch.randint(0, V, (B, S0), generator=g)
+    am = torch.ones(B, S0, dtype=torch.long)
+    am[1, :5] = 0                                                       # left padding, as a batched generation call pads its prompts
+    with _cpu_threads(32):
+        want = R.greedy_decode(p, sh, ids, am, max_gen_len=NEW, end_ids=None, pad_id=3)
+        # margins of the oracle's own decisions
+        margins, cur, mask, pasts, step = [], ids.clone(), am.clone(), None, 0
+        while cur.shape[1] < want.shape[-1]:
+            with torch.no_grad():
+                _, logits, _, pasts = R.bloom_forward(p, sh, cur[:, step:], mask, None, pasts)
+            top2 = logits[:, -1, :].double().topk(2, dim=-1).values
+            margins.append((top2[:, 0] - top2[:, 1]) / (logits[:, -1, :].double().abs().max(dim=-1).values + 1e-30))
+            nxt = logits[:, -1, :].argmax(-1)
+            cur = torch.cat([cur, nxt[:, None]], dim=-1)
+            mask = torch.cat([mask, mask[:, -1:]], dim=-1)
+            step = cur.shape[1] - 1
+        assert torch.equal(cur, want.view(B, -1))
+    m = build(V, H, L, nh, compute_dtype="fp32", params=p).eval()
+    out = m.generate(ids.to(DEV), attention_mask=am.to(DEV),
+                     generation_configs=dict(beam_size=1, max_gen_len=NEW, do_sample=False, end_ids=None, pad_id=3))
+    got = out.cpu().view(B, -1)
+    assert got.shape == cur.shape, (got.shape, cur.shape)
+    tight = min(float(x.min()) for x in margins)
+    for b in range(B):
+        for t in range(S0, cur.shape[1]):
+            if int(got[b, t]) != int(cur[b, t]):
+                mg = float(margins[t - S0][b])
+                raise AssertionError(f"greedy decode differs at batch {b}, position {t}: got {int(got[b, t])}, oracle {int(cur[b, t])}, the oracle's "
+                                     f"top-2 margin there is {mg:.2e} of the logit scale ({'a near-tie' if mg < 1e-4 else 'NOT a tie'})")
+    assert tight > 1e-4, f"bit-exact, but the narrowest top-2 margin of this seed ({tight:.2e}) is inside fp32 round-off: pick another seed"
 
 
 def test_config4_bloom7b1_geometry_at_stated_sequence_length():

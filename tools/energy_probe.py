@@ -8,7 +8,7 @@ alone and draws 5 % more gives the step nothing.  This tool puts a number on tha
 loop x time per launch; "dynamic" subtracts the idle draw measured first.  Operand values matter (switching activity): operands are
 N(0, 0.5) in bf16 like the microbenchmarks'; `--zeros` repeats every workload on all-zero operands as the floor.
 
-    python tools/energy_probe.py [gemm] [vendor] [wgrad] [attn] [hbm] [--seconds 1.5] [--zeros]
+    python tools/energy_probe.py [gemm] [vendor] [wgrad] [wgroup] [attn] [hbm] [--seconds 1.5] [--zeros]
 
 gemm: the step's GEMM shapes through the library (tile choice as in the step)      vendor: the same products through torch.matmul (hipBLASLt)
 attn: attention forward / backward at B=8 S=1024 nh=16 hd=64                        hbm: AdamW, fused cross entropy, LayerNorm backward
@@ -138,6 +138,19 @@ def main(argv):
                     measure(f"{name} dgrad hipBLASLt{tag}", lambda: torch.matmul(dy, w, out=dx), seconds, fl, idle_w=idle_w)
                     del out, dx
                 del x, w, dy
+        if "wgroup" in which:                                           # the four weight gradients + two bias column sums of one block (round 5)
+            shapes = [(H, 4 * H, False), (4 * H, H, True), (H, H, False), (3 * H, H, True)]
+            probs = [(rnd(T, no, zeros=zeros), rnd(T, ni, zeros=zeros), db) for (no, ni, db) in shapes]
+            fl = sum(2.0 * T * no * ni for no, ni, _ in shapes)
+
+            def separate():
+                for dy, x, db in probs:
+                    ops.linear_wgrad(dy, x)
+                    if db:
+                        ops.colsum(dy)
+            measure(f"block wgrads, per product{tag}", separate, seconds, fl, idle_w=idle_w)
+            measure(f"block wgrads, grouped launch{tag}", lambda: ops.wgrad_grouped(probs), seconds, fl, idle_w=idle_w)
+            del probs
         if "attn" in which:
             from cleantransformer_amd.models.modeling_bloom import alibi_slopes
             B, S, nh, hd = 8, 1024, 16, 64

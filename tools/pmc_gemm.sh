@@ -25,7 +25,9 @@ for k in sorted(a):
 ms = sum(dur) / len(dur) / 1e6
 print(f"average duration under counters: {ms:.3f} ms")
 if "GRBM_GUI_ACTIVE" in a and "SQ_VALU_MFMA_BUSY_CYCLES" in a:
-    print(f"MfmaUtil (gfx94x formula) = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 256 CUs * 4 SIMDs) = {100 * a['SQ_VALU_MFMA_BUSY_CYCLES'] / (a['GRBM_GUI_ACTIVE'] * 256 * 4):.1f} %")
+    # GRBM_GUI_ACTIVE is summed over the 8 XCDs (round-4 verdict: r04's line divided by the raw sum and reported 7.1 % for a 57 % busy pipe)
+    print(f"MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 256 CUs * 4 SIMDs) = {100 * a['SQ_VALU_MFMA_BUSY_CYCLES'] / (a['GRBM_GUI_ACTIVE'] / 8 * 256 * 4):.1f} % of SIMD cycles "
+          f"(shader clock of the counted run: {a['GRBM_GUI_ACTIVE'] / 8 / (ms * 1e-3) / 1e9:.2f} GHz)")
 if "SQ_INSTS_VALU_MFMA_MOPS_BF16" in a:
     print(f"MFMA bf16 MOPS x 512 FLOP = {a['SQ_INSTS_VALU_MFMA_MOPS_BF16'] * 512 / 1e12:.3f} TFLOP per launch (algorithmic 2*T*H*V = {2 * 8192 * 1024 * 250880 / 1e12:.3f})")
 PY

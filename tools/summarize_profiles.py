@@ -41,10 +41,12 @@ def pmc(counter):
 
 
 steps = 15                                                                # bench.py default: 3 warm-up + 2 (idle-queue host timing) + 10 timed
-a = kernel_table("prof_bench", steps, f"{rnd}: python bench.py --no-cpu-baseline (default: weight-gradient GEMMs on a side stream, kernels overlap)",
+a = kernel_table("prof_bench", steps, f"{rnd}: python bench.py --no-cpu-baseline (default since round 5: grouped weight gradients, the whole step on ONE stream: clean per-kernel durations)",
                  f"{rnd}_bench_kernel_summary.txt")
-b = kernel_table("prof_bench_1stream", steps, f"{rnd}: CTMI_WGRAD_STREAM=0 python bench.py --no-cpu-baseline (single stream: clean per-kernel durations)",
-                 f"{rnd}_bench_1stream_kernel_summary.txt")
+import shutil as _sh
+_sh.copy(os.path.join(dst, f"{rnd}_bench_kernel_summary.txt"), os.path.join(dst, f"{rnd}_bench_1stream_kernel_summary.txt"))   # (the name rounds 1-4 used for the single-stream trace)
+b = kernel_table("prof_bench_1stream", steps, f"{rnd}: CTMI_WGRAD_GROUP=0 python bench.py --no-cpu-baseline (the round-4 form: four weight-gradient products per block on a side stream, kernels overlap)",
+                 f"{rnd}_bench_per_product_kernel_summary.txt")
 fetch, write = pmc("FETCH_SIZE"), pmc("WRITE_SIZE")
 fk, wk = sum(fetch) / len(fetch), sum(write) / len(write)
 traffic = {
@@ -86,10 +88,10 @@ except Exception as e:                                                   # (olde
 
 # the plain result files of the collection travel as they are
 import shutil
-for name in (f"{rnd}_bench_default.json", f"{rnd}_bench_under_rocprof.json", f"{rnd}_bench_1stream_under_rocprof.json",
+for name in (f"{rnd}_bench_default.json", f"{rnd}_bench_under_rocprof.json", f"{rnd}_bench_per_product_under_rocprof.json", f"{rnd}_energy_probe.txt", f"{rnd}_chain_probe.txt", f"{rnd}_pmc_lmhead_mfma.txt",
              f"{rnd}_microbench.txt", f"{rnd}_vendor_gemm_reference.txt", f"{rnd}_microbench_epilogues.txt", f"{rnd}_attention_paths.txt",
              f"{rnd}_gpt2_medium_bench.txt", f"{rnd}_bloom7b1_1gpu_bench.txt"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, name))
 shutil.copy(one("prof_bench/*/*_kernel_stats.csv"), os.path.join(dst, f"{rnd}_bench_kernel_stats.csv"))
-print("LM-head fwd avg ms: side-stream run %.4f, single-stream run %.4f; traffic %.2f GB/launch" % (a, b, traffic["traffic_bytes_per_launch"] / 1e9))
+print("LM-head fwd avg ms: default run %.4f, per-product two-stream run %.4f; traffic %.2f GB/launch" % (a, b, traffic["traffic_bytes_per_launch"] / 1e9))
