@@ -125,7 +125,7 @@ class _PowerSampler:
         med = lambda v: sorted(v)[len(v) // 2]                                # noqa: E731
         return {"samples": len(busy), "package_power_w_median": med(busy), "package_power_w_max": max(busy),
                 "sclk_mhz_median": med(self.sclk) if self.sclk else None,
-                "note": "rocm-smi sampled ~10 x per second during the timed steps (its figure is a moving average: the first samples still see the idle gap before them; cap: smi_before)"}
+                "note": "rocm-smi sampled ~10 x per second during the extra steps that follow the timed region (its figure is a moving average: the first samples still see the idle gap before them; cap: smi_before)"}
 
 
 def build_model(device, compute_dtype):
@@ -288,7 +288,7 @@ def main(argv=None):
             # (round 5) the library's own RCCL communicator is only probed on request (--probe-rccl): it has never run at world > 1, and a
             # candidate that HANGS takes the whole measurement with it; torch.distributed's RCCL backend x the two launch policies is the default
             for backend in (("torch", "rccl") if args.probe_rccl else ("torch",)):
-                for policy in ("shared", "reserve"):
+                for policy in ("shared", "reserve", "persistent"):
                     rec = {"ddp_backend": backend, "launch_policy": policy}
                     # phase 1: wrap.  Every rank reports whether ITS wrapper exists before any rank enters the wrapper's collectives — a
                     # candidate that cannot be built on one rank (no librccl there, a communicator error) is skipped by all (round-4 advisor)
@@ -375,9 +375,15 @@ def main(argv=None):
     clock_before = ops.clock_probe(device)                                 # shader clock under MFMA load, chip warm from the warm-up steps
     timer = ops.KernelTimer(["lm_head_fwd"])
     ops.set_timer(timer)
-    sampler = _PowerSampler().start() if (rank == 0 and not args.no_power_sampler) else None
     dt, per_step_ms, host_loop_s, loss = timed_steps(args.steps)
     ops.set_timer(None)
+    # package power / shader clock while stepping: sampled beside `steps` EXTRA steps right after the timed region, not inside it — ten rocm-smi
+    # processes per second beside the timed steps cost 0.07 ms per step (same box, three interleaved pairs: 36.60 vs 36.54; round-4 advisor)
+    sampler = _PowerSampler().start() if (rank == 0 and not args.no_power_sampler) else None
+    if not args.no_power_sampler:
+        for _ in range(max(args.steps, 10)):
+            step()
+        torch.cuda.synchronize()
     if sampler is not None:
         sampler.stop()
     clock_after = ops.clock_probe(device)                                  # ... and right after the timed steps

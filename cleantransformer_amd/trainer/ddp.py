@@ -358,12 +358,16 @@ class DistributedDataParallel(torch.nn.Module):
               NCCL_MAX_NCHANNELS = R (RCCL runs one workgroup per channel; bench.py exports both before init_process_group, the
               communicator reads the variable when it is created), so the R channels always find a free CU and the GEMMs never wait
               for one they cannot get;
+          "persistent": the single-GPU policy unchanged (persistent launches on all 256 CUs): the fastest when the collectives' workgroups
+              co-reside with the GEMMs' or are short — nobody could measure that without a multi-GPU node, so bench.py --gpus N times it too;
           "0": leave the launcher alone."""
         mode = os.environ.get("CTMI_DDP_LAUNCH_POLICY", "shared").lower()
         if self.world_size > 1 and mode != "0" and any(p.is_cuda for p in self.module.parameters()):
             from .. import ops
             if mode == "reserve":
                 want = (False, max(0, min(128, int(os.environ.get("CTMI_DDP_COMM_CUS", "16")))))
+            elif mode == "persistent":
+                want = (False, 0)                                        # the single-GPU policy (bench.py times it as a third candidate on the node it runs on)
             else:
                 want = (True, ops.get_launch_policy()[1])
             if ops.get_launch_policy() != want:
