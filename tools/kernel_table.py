@@ -18,7 +18,6 @@ import re
 import sys
 
 src, dst, rnd = sys.argv[1], sys.argv[2], sys.argv[3]
-STEPS = 15
 T, H, V, L, S, B, NH, HD = 8192, 1024, 250880, 24, 1024, 8, 16, 64
 GF = lambda n, k: 2.0 * T * n * k                                       # noqa: E731  one [T,k] x [k,n] product
 ATT = 4.0 * B * NH * S * S * HD / 2                                      # causal-half attention forward of one layer
@@ -91,7 +90,22 @@ def energy_lines():
     return out
 
 
+LMH = "void gemm_glds_kernel<unsigned short, false, false, 0, 8, 4, true, false, false>"
+
+
+def traced_steps(run_dir, csvname="kernel_trace"):
+    """steps a run covers = launches of the LM-head forward (one per step, > 1 ms each)"""
+    f = one(f"{run_dir}/*/*_{csvname}.csv")
+    seen = set()
+    for r in csv.DictReader(open(f)):
+        if r["Kernel_Name"].startswith(LMH) and float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) > 1e6:
+            seen.add(r.get("Dispatch_Id") or r.get("Correlation_Id") or r["Start_Timestamp"])
+    return max(len(seen), 1)
+
+
 def table(run_dir, title):
+    STEPS = traced_steps(run_dir)
+    PSTEPS = traced_steps("pmc_step_FETCH_SIZE", "counter_collection") if one("pmc_step_FETCH_SIZE/*/*_counter_collection.csv") else STEPS
     stats = list(csv.DictReader(open(one(f"{run_dir}/*/*_kernel_stats.csv"))))
     fetch = per_kernel_counter("pmc_step_FETCH_SIZE", {"FETCH_SIZE"})
     write = per_kernel_counter("pmc_step_WRITE_SIZE", {"WRITE_SIZE"})
@@ -105,8 +119,8 @@ def table(run_dir, title):
         ms = sum(float(r["TotalDurationNs"]) for r in rs) / 1e6 / STEPS
         calls = sum(int(r["Calls"]) for r in rs) / STEPS
         rate = (work / (ms * 1e-3)) if work else None
-        fb = match(fetch, pat).get("FETCH_SIZE", 0.0) * 1024 * 2 / STEPS
-        wb = match(write, pat).get("WRITE_SIZE", 0.0) * 1024 / STEPS
+        fb = match(fetch, pat).get("FETCH_SIZE", 0.0) * 1024 * 2 / PSTEPS
+        wb = match(write, pat).get("WRITE_SIZE", 0.0) * 1024 / PSTEPS
         mm = match(mfma, pat)
         busy = (mm.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (mm["GRBM_GUI_ACTIVE"] / 8 * 1024)) if mm.get("GRBM_GUI_ACTIVE") else None
         e = en.get(eline) if eline else None
@@ -131,7 +145,7 @@ def table(run_dir, title):
 
 doc = [f"# {rnd}: per-kernel evidence table of the Bloom-560M SFT step (B = 8, S = 1024, bf16, one MI355X)", "",
        "Produced by `tools/kernel_table.py` from ONE `tools/collect_profiles.sh` collection (same box, same build).  Columns: kernel time from "
-       "`rocprofv3 --kernel-trace --stats` (15 steps traced, per-step = total / 15); algorithmic work from the model's shapes; *achieved* = work ÷ kernel time; "
+       "`rocprofv3 --kernel-trace --stats` (per-step = total ÷ the steps the trace covers = launches of the LM-head forward); algorithmic work from the model's shapes; *achieved* = work ÷ kernel time; "
        "*of chip peak* against 2.5 PFLOP/s dense bf16 or 8 TB/s; FETCH + WRITE from separate counter-only passes over the same command (FETCH doubled per the gfx950 note; "
        "Infinity-Cache hits are included — the counters sit at the L2 boundary), *vs algorithmic bytes* = that ÷ the bytes the kernel has to move at least; "
        "*MFMA busy* = `SQ_VALU_MFMA_BUSY_CYCLES ÷ (GRBM_GUI_ACTIVE / 8 × 1024)` (share of SIMD cycles with the matrix pipe executing, at the shader clock of the "

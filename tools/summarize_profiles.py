@@ -40,12 +40,20 @@ def pmc(counter):
     return v
 
 
-steps = 15                                                                # bench.py default: 3 warm-up + 2 (idle-queue host timing) + 10 timed
+def traced_steps(run_dir):
+    """steps a trace covers = launches of the LM-head forward (one per step): 3 warm-up + 2 idle-queue host timing + 10 timed (+ 10 beside the
+    power sampler since round 5)"""
+    tr = csv.DictReader(open(one(f"{run_dir}/*/*_kernel_trace.csv")))
+    n = sum(1 for r in tr if r["Kernel_Name"].startswith("void " + LM) and float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) > 1e6)
+    return max(n, 1)
+
+
+steps = traced_steps("prof_bench")
 a = kernel_table("prof_bench", steps, f"{rnd}: python bench.py --no-cpu-baseline (default since round 5: grouped weight gradients, the whole step on ONE stream: clean per-kernel durations)",
                  f"{rnd}_bench_kernel_summary.txt")
 import shutil as _sh
 _sh.copy(os.path.join(dst, f"{rnd}_bench_kernel_summary.txt"), os.path.join(dst, f"{rnd}_bench_1stream_kernel_summary.txt"))   # (the name rounds 1-4 used for the single-stream trace)
-b = kernel_table("prof_bench_1stream", steps, f"{rnd}: CTMI_WGRAD_GROUP=0 python bench.py --no-cpu-baseline (the round-4 form: four weight-gradient products per block on a side stream, kernels overlap)",
+b = kernel_table("prof_bench_1stream", traced_steps("prof_bench_1stream"), f"{rnd}: CTMI_WGRAD_GROUP=0 python bench.py --no-cpu-baseline (the round-4 form: four weight-gradient products per block on a side stream, kernels overlap)",
                  f"{rnd}_bench_per_product_kernel_summary.txt")
 fetch, write = pmc("FETCH_SIZE"), pmc("WRITE_SIZE")
 fk, wk = sum(fetch) / len(fetch), sum(write) / len(write)
@@ -76,7 +84,7 @@ try:
     fetch_b = sum(fs.values()) * 1024 * 2 / steps
     write_b = sum(ws.values()) * 1024 / steps
     top = sorted(((fs.get(k, 0.0) * 2048 + ws.get(k, 0.0) * 1024) / steps, k) for k in set(fs) | set(ws))[::-1][:12]
-    json.dump({"command": "python bench.py --no-cpu-baseline --no-breakdown --no-padded-sample --steps 10 --warmup 3 (15 steps traced incl. warm-up)",
+    json.dump({"command": f"python bench.py --no-cpu-baseline --no-breakdown --no-padded-sample --steps 10 --warmup 3 ({steps} steps traced incl. warm-up and the power-sampling steps)",
                "fetch_bytes_per_step": fetch_b, "write_bytes_per_step": write_b, "traffic_bytes_per_step": fetch_b + write_b,
                "note": "separate --pmc FETCH_SIZE / WRITE_SIZE passes (--kernel-trace only); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies the 128-B "
                        "requests of wide coalesced reads at 64 B); fetches served by the Infinity Cache are included (the counters sit at the L2 boundary)",
