@@ -15,11 +15,11 @@ from ._build import LIB_PATH as _DEFAULT_LIB_PATH
 # CTMI_LIB_PATH: load another build of the same sources (kernel A/B experiments under tools/; see _build.build_variant)
 LIB_PATH = os.environ.get("CTMI_LIB_PATH") or _DEFAULT_LIB_PATH
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_DGELU, EPI_RELU, EPI_DRELU, EPI_GELUG, EPI_MUL = 0, 1, 2, 3, 4, 5, 6
 MT_MAX = 24
 PROF_CLASSES = ("gemm_fwd", "gemm_dgrad", "gemm_wgrad", "lm_head", "attn_fwd", "attn_bwd", "layernorm", "loss", "optimizer", "reduce", "other")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 

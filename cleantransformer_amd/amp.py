@@ -11,9 +11,9 @@ host round-trip is the 4-byte ``found_inf`` read in ``step()``, the same one tor
 ``optimizer.step()`` (so that a skipped step does not advance Adam's bias-correction count).
 
 With the bf16 compute policy of this package (fp32 master weights and gradients, bf16 operands) scaling is not needed for range;
-it is kept because the reference's loop uses it, and with a power-of-two scale in fp32/bf16 it is exact (scaled gradients are
-bit-identical after unscaling unless something overflowed).  ``autocast`` is accepted as a no-op context: the compute dtype is
-fixed by ``config.compute_dtype`` and the fused kernels do not dispatch through torch's autocast.
+with a power-of-two scale in fp32/bf16 it is exact (scaled gradients are bit-identical after unscaling unless something overflowed).
+In fp16 (``autocast(dtype=torch.float16)`` or ``config.compute_dtype = "fp16"``: the reference's autocast precision, round 5) it does its
+real job: activation gradients travel as IEEE half, overflow to inf is what ``found_inf`` catches, a skipped step halves the scale.
 """
 from __future__ import annotations
 
@@ -29,29 +29,35 @@ _warned_default = False
 
 @contextlib.contextmanager
 def autocast(device_type=None, dtype=None, enabled=True, cache_enabled=None):
-    """``torch.cuda.amp.autocast()`` stand-in for the reference's loop (ft_bloom_DDP.py:122).  Precision is a MODEL property here
-    (``config.compute_dtype``: "bf16" or "fp32"; fp32 master weights, gradients and statistics either way) and the fused kernels
-    do not dispatch through torch's autocast, so the context changes nothing — and says what it cannot do instead of silently
-    ignoring it: the kernels have no fp16 path (the reference's default autocast dtype on a GPU, with its fp16 -> fp32 score
-    upcast at modeling_bloom.py:106-107), so
-      * ``autocast(dtype=torch.float16)`` raises;
-      * ``autocast()`` with the default dtype (what ft_bloom_DDP.py writes) warns once that the model's compute dtype is used instead
-        (bf16 has fp32's exponent range: the GradScaler around it stays exact and never has to back off)."""
+    """``torch.cuda.amp.autocast()`` / ``torch.autocast(...)`` for the reference's loop (ft_bloom_DDP.py:122).  The fused kernels do not dispatch
+    through torch's autocast; the context selects the COMPUTE DTYPE of the model forwards run inside it (``ops.effective_compute_dtype``):
+      * ``autocast(dtype=torch.float16)`` — the reference's published DDP launch (scripts/ft_bloom_DDP.sh:11 ``--use_torch_amp``; torch's default
+        autocast dtype on a GPU): activations and operand copies of the weights in IEEE half, fp32 accumulation, softmax / LayerNorm / loss
+        statistics in fp32 (a superset of the fp16 -> fp32 score upcast at modeling_bloom.py:106-107), fp32 master weights and gradients — the
+        FUNCTIONAL path (register-staged GEMM tiles, the general attention kernels); a ``GradScaler`` is needed here, as in the reference;
+      * ``autocast(dtype=torch.bfloat16)`` — the measured path (same as ``config.compute_dtype = "bf16"``);
+      * ``autocast()`` with no dtype (what ft_bloom_DDP.py literally writes) keeps the model's own ``config.compute_dtype`` and says so once: this
+        package's default mixed precision is bf16, not fp16 (no loss scaling needed for range, 2x the GEMM rate of the fp16 path here) — pass
+        ``dtype=torch.float16`` (``examples.ft_bloom_DDP.train(amp_dtype=torch.float16)``) to reproduce the reference's precision."""
     global _warned_default
     if isinstance(device_type, bool):        # torch.cuda.amp.autocast's first positional argument is `enabled` (torch.autocast's is device_type):
         enabled, device_type = device_type, None     # autocast(False) must mean "off", not device_type=False (round-3 advisor)
+    old = ops._AUTOCAST_DTYPE
     if enabled:
-        if dtype is torch.float16:
-            raise NotImplementedError("cleantransformer_amd has no fp16 compute path (bf16 / fp32 MFMA kernels only): use "
-                                      "config.compute_dtype = 'bf16' (autocast(dtype=torch.bfloat16) is accepted) — DESIGN.md §7d")
-        if dtype not in (None, torch.bfloat16, torch.float32):
-            raise NotImplementedError(f"autocast(dtype={dtype}) is not supported: compute dtypes are bf16 and fp32")
+        if dtype not in (None, torch.float16, torch.bfloat16, torch.float32):
+            raise NotImplementedError(f"autocast(dtype={dtype}) is not supported: compute dtypes are fp16, bf16 and fp32")
         if dtype is None and not _warned_default:
             _warned_default = True
             import warnings
-            warnings.warn("cleantransformer_amd.amp.autocast(): torch's default autocast dtype (fp16) is not implemented; the forward runs "
-                          "in the model's config.compute_dtype (bf16 or fp32) with fp32 statistics and master weights", stacklevel=3)
-    yield
+            warnings.warn("cleantransformer_amd.amp.autocast(): no dtype given — the forward runs in the model's config.compute_dtype (bf16 or fp32; "
+                          "fp32 statistics and master weights).  torch's default autocast dtype on a GPU is fp16: pass dtype=torch.float16 for it",
+                          stacklevel=3)
+        if dtype is not None:
+            ops._AUTOCAST_DTYPE = dtype
+    try:
+        yield
+    finally:
+        ops._AUTOCAST_DTYPE = old
 
 
 class GradScaler():

@@ -98,7 +98,7 @@ struct AT {
             uint32_t wd[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                const T e = (grow < nrows && c + j < hd) ? p[j] : (T)0;
+                const T e = (grow < nrows && c + j < hd) ? p[j] : T{};
                 if constexpr (sizeof(T) == 2) wd[j >> 1] |= (uint32_t)__builtin_bit_cast(uint16_t, e) << (16 * (j & 1));
                 else wd[j] = __builtin_bit_cast(uint32_t, e);
             }
@@ -182,6 +182,9 @@ template <typename T, int HDP> __device__ __forceinline__ typename Mma<T>::Frag 
 template <> __device__ __forceinline__ short8 frag_rm<bf16_t, 32>(const bf16_t* __restrict__ t, int row, int kofs) { return *reinterpret_cast<const short8*>(t + row * AT<bf16_t, 32>::PRM + kofs); }
 template <> __device__ __forceinline__ short8 frag_rm<bf16_t, 64>(const bf16_t* __restrict__ t, int row, int kofs) { return *reinterpret_cast<const short8*>(t + row * AT<bf16_t, 64>::PRM + kofs); }
 template <> __device__ __forceinline__ short8 frag_rm<bf16_t, 128>(const bf16_t* __restrict__ t, int row, int kofs) { return *reinterpret_cast<const short8*>(t + row * AT<bf16_t, 128>::PRM + kofs); }
+template <> __device__ __forceinline__ short8 frag_rm<f16_t, 32>(const f16_t* __restrict__ t, int row, int kofs) { return *reinterpret_cast<const short8*>(t + row * AT<f16_t, 32>::PRM + kofs); }
+template <> __device__ __forceinline__ short8 frag_rm<f16_t, 64>(const f16_t* __restrict__ t, int row, int kofs) { return *reinterpret_cast<const short8*>(t + row * AT<f16_t, 64>::PRM + kofs); }
+template <> __device__ __forceinline__ short8 frag_rm<f16_t, 128>(const f16_t* __restrict__ t, int row, int kofs) { return *reinterpret_cast<const short8*>(t + row * AT<f16_t, 128>::PRM + kofs); }
 template <> __device__ __forceinline__ float frag_rm<float, 32>(const float* __restrict__ t, int row, int kofs) { return t[row * AT<float, 32>::PRM + kofs]; }
 template <> __device__ __forceinline__ float frag_rm<float, 64>(const float* __restrict__ t, int row, int kofs) { return t[row * AT<float, 64>::PRM + kofs]; }
 template <> __device__ __forceinline__ float frag_rm<float, 128>(const float* __restrict__ t, int row, int kofs) { return t[row * AT<float, 128>::PRM + kofs]; }
@@ -200,6 +203,19 @@ template <> __device__ __forceinline__ short8 frag_global<bf16_t, false>(const b
     if (kofs + 8 <= hd && vec_ok) return *reinterpret_cast<const short8*>(row + kofs);
 #pragma unroll
     for (int j = 0; j < 8; ++j) f[j] = (kofs + j < hd) ? (short)row[kofs + j] : (short)0;
+    return f;
+}
+template <> __device__ __forceinline__ short8 frag_global<f16_t, true>(const f16_t* row, int kofs, int, bool) {
+    short8 f = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (row != nullptr) f = ldg_as1<short8>(row + kofs);
+    return f;
+}
+template <> __device__ __forceinline__ short8 frag_global<f16_t, false>(const f16_t* row, int kofs, int hd, bool vec_ok) {
+    short8 f = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (row == nullptr) return f;
+    if (kofs + 8 <= hd && vec_ok) return *reinterpret_cast<const short8*>(row + kofs);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (kofs + j < hd) ? (short)row[kofs + j].v : (short)0;
     return f;
 }
 template <> __device__ __forceinline__ float frag_global<float, false>(const float* row, int kofs, int hd, bool) {
@@ -233,7 +249,7 @@ __device__ __forceinline__ void dot_tile(f32x4 (&x)[4], const T* __restrict__ rm
 // (V, K, Q, dO) is fetched with ds_read_b64_tr_b16 — lane i of a 16-lane group addresses row R0 + (i>>2), columns
 // C0 + 4*(i&3).. and receives column C0 + i for rows R0..R0+3 (probe-verified) — so no transposed copy is ever staged.
 typedef short short4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint2 lds_tr_b16(const bf16_t* p) {
+__device__ __forceinline__ uint2 lds_tr_b16(const void* p) {
     typedef __attribute__((address_space(3))) short4_t lds_v4;
     return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(unsigned)(size_t)p));
 }
@@ -245,15 +261,15 @@ __device__ __forceinline__ void contract64(f32x4 (&acc)[HDP / 16], const T* __re
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const f32x4 lo = x[2 * ks], hi = x[2 * ks + 1];
-            uint4 pk = make_uint4(pack_bf2(lo[0], lo[1]), pack_bf2(lo[2], lo[3]), pack_bf2(hi[0], hi[1]), pack_bf2(hi[2], hi[3]));
+            uint4 pk = make_uint4(pack2<T>(lo[0], lo[1]), pack2<T>(lo[2], lo[3]), pack2<T>(hi[0], hi[1]), pack2<T>(hi[2], hi[3]));
             const short8 b = __builtin_bit_cast(short8, pk);
-            const bf16_t* base = rm_tile + (ks * 32 + g * 4 + (li >> 2)) * PRM + 4 * (li & 3);
+            const T* base = rm_tile + (ks * 32 + g * 4 + (li >> 2)) * PRM + 4 * (li & 3);
 #pragma unroll
             for (int dt = 0; dt < HDP / 16; ++dt) {
                 const uint2 a0 = lds_tr_b16(base + dt * 16);                     // rows ks*32 + g*4 .. +3
                 const uint2 a1 = lds_tr_b16(base + 16 * PRM + dt * 16);          // rows ks*32 + 16 + g*4 .. +3
                 const short8 a = __builtin_bit_cast(short8, make_uint4(a0.x, a0.y, a1.x, a1.y));
-                acc[dt] = Mma<bf16_t>::mma(a, b, acc[dt]);
+                acc[dt] = Mma<T>::mma(a, b, acc[dt]);
             }
         }
     } else {
@@ -317,13 +333,18 @@ __device__ __forceinline__ float group_sum4(float v) {
 #endif
 }
 // dot product of two operand fragments (the lane's KL consecutive head-dim elements of two rows)
-__device__ __forceinline__ float frag_dot(short8 a, short8 b) {
+template <typename T> __device__ __forceinline__ float frag_dot(short8 a, short8 b) {
     float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s += bf2f((bf16_t)a[j]) * bf2f((bf16_t)b[j]);
+    for (int j = 0; j < 8; ++j) {
+        T x, y;
+        if constexpr (std::is_same<T, f16_t>::value) { x.v = (uint16_t)a[j]; y.v = (uint16_t)b[j]; }
+        else { x = (T)a[j]; y = (T)b[j]; }
+        s += Cvt<T>::to_f(x) * Cvt<T>::to_f(y);
+    }
     return s;
 }
-__device__ __forceinline__ float frag_dot(float a, float b) { return a * b; }
+template <typename T> __device__ __forceinline__ float frag_dot(float a, float b) { return a * b; }
 
 // Per-key additive bias staged once per tile (one float per key):
 //    slope * ALiBi position            for a key that may be attended            (modeling_bloom.py:328-330)
@@ -370,7 +391,7 @@ __device__ __forceinline__ void store_own_row(T* rowp, const f32x4 (&acc)[HDP / 
         if (!FAST && d >= hd) continue;
         float v[4] = {acc[dt][0] * mul, acc[dt][1] * mul, acc[dt][2] * mul, acc[dt][3] * mul};
         if (FAST || (d + 4 <= hd && vec_ok)) {
-            if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2*>(rowp + d) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2*>(rowp + d) = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
             else *reinterpret_cast<float4*>(rowp + d) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
             for (int r = 0; r < 4; ++r) if (d + r < hd) rowp[d + r] = Cvt<T>::from_f(v[r]);
@@ -794,7 +815,7 @@ __global__ __launch_bounds__(256, CTMI_ATTN_MINW) void attn_bwd_dq_kernel(AttnP 
         const T* orow = reinterpret_cast<const T*>(p.o) + b * p.o_bs + h * p.o_hs + my_q * p.o_rs;
 #pragma unroll
         for (int kk = 0; kk < NKK; ++kk)
-            dl += frag_dot(frag_global<T, FAST>(live ? orow : nullptr, kk * MK + g * KL, hd_, vok), gf[kk]);
+            dl += frag_dot<T>(frag_global<T, FAST>(live ? orow : nullptr, kk * MK + g * KL, hd_, vok), gf[kk]);
         dl = group_sum4(dl);
         if (live && g == 0) p.delta[srow] = dl;
     }
@@ -912,7 +933,7 @@ __global__ __launch_bounds__(256, CTMI_ATTN_MINW) void attn_bwd_dq_kernel(AttnP 
 static int fill_params(AttnP& p, const ctmi_attn_desc* d, int dtype, const char* who) {
     CTMI_REQUIRE(d != nullptr, "%s: null desc", who);
     CTMI_REQUIRE(d->B > 0 && d->nh > 0 && d->Sq > 0 && d->Sk > 0 && d->hd > 0 && d->hd <= 128, "%s: bad shape (hd must be <= 128)", who);
-    CTMI_REQUIRE(dtype == CTMI_F32 || dtype == CTMI_BF16, "%s: unsupported dtype %d", who, dtype);
+    CTMI_REQUIRE(dtype == CTMI_F32 || dtype == CTMI_BF16 || dtype == CTMI_F16, "%s: unsupported dtype %d", who, dtype);
     p.B = d->B; p.nh = d->nh; p.Sq = d->Sq; p.Sk = d->Sk; p.hd = d->hd;
     p.q_bs = d->q_bs; p.q_hs = d->q_hs; p.q_rs = d->q_rs; p.k_bs = d->k_bs; p.k_hs = d->k_hs; p.k_rs = d->k_rs;
     p.v_bs = d->v_bs; p.v_hs = d->v_hs; p.v_rs = d->v_rs; p.o_bs = d->o_bs; p.o_hs = d->o_hs; p.o_rs = d->o_rs;
@@ -999,6 +1020,7 @@ extern "C" int ctmi_attn_fwd(const void* q, const void* k, const void* v, void* 
     hipStream_t st = as_stream(stream);
     ProfScope prof__(CTMI_PROF_ATTN_FWD, st);
     if (dtype == CTMI_F32) return HDP_DISPATCH(fwd_launch, float);
+    if (dtype == CTMI_F16) return HDP_DISPATCH(fwd_launch, f16_t);                       // fp16: the general kernels
     if (ctmi_attn32_fwd(p, st)) { CTMI_CHECK_LAUNCH("attn32_fwd"); return CTMI_OK; }   // training shapes: attention_w32.hip
     return HDP_DISPATCH(fwd_launch, bf16_t);
 }
@@ -1019,6 +1041,7 @@ extern "C" int ctmi_attn_bwd(const void* q, const void* k, const void* v, const 
     hipStream_t st = as_stream(stream);
     ProfScope prof__(CTMI_PROF_ATTN_BWD, st);
     if (dtype == CTMI_F32) return HDP_DISPATCH(bwd_launch, float);
+    if (dtype == CTMI_F16) return HDP_DISPATCH(bwd_launch, f16_t);
     if (ctmi_attn32_bwd(p, st)) { CTMI_CHECK_LAUNCH("attn32_bwd"); return CTMI_OK; }   // training shapes: attention_w32.hip
     return HDP_DISPATCH(bwd_launch, bf16_t);
 }

@@ -69,7 +69,7 @@ int check_block(const ctmi_bloom_block* b, const char* who) {
     CTMI_REQUIRE(b != nullptr, "%s: null block descriptor", who);
     CTMI_REQUIRE(b->B > 0 && b->S > 0 && b->H > 0 && b->nh > 0 && b->H % b->nh == 0, "%s: bad geometry B=%lld S=%lld H=%lld nh=%lld", who,
                  (long long)b->B, (long long)b->S, (long long)b->H, (long long)b->nh);
-    CTMI_REQUIRE(b->dtype == CTMI_F32 || b->dtype == CTMI_BF16, "%s: unsupported dtype %d", who, b->dtype);
+    CTMI_REQUIRE(b->dtype == CTMI_F32 || b->dtype == CTMI_BF16 || b->dtype == CTMI_F16, "%s: unsupported dtype %d", who, b->dtype);
     CTMI_REQUIRE(b->ln1_w && b->ln1_b && b->wqkv && b->bqkv && b->wd && b->bd && b->ln2_w && b->ln2_b && b->w1 && b->b1 && b->w2 && b->b2,
                  "%s: null parameter pointer", who);
     CTMI_REQUIRE(b->x && b->slab, "%s: null activation pointer", who);

@@ -7,6 +7,10 @@
 #include "../../include/ctmi355.h"
 
 typedef uint16_t bf16_t;                                   // raw bfloat16 bits
+// IEEE half (round 5: compute_dtype "fp16" — the autocast dtype of the reference's published DDP launch, ft_bloom_DDP.py:107-128 / scripts/ft_bloom_DDP.sh:11).
+// A distinct C++ type (bf16_t is a plain uint16_t) so that every kernel template gets its own instantiation.  The fp16 path is the FUNCTIONAL one:
+// register-staged GEMM tiles, the general attention kernels; the LDS-DMA GEMM family and the 128-row attention kernels stay bf16 (the measured path).
+struct f16_t { uint16_t v; };
 typedef short  short8 __attribute__((ext_vector_type(8)));   // 8 x bf16 MFMA operand (4 VGPRs)
 typedef short  short4v __attribute__((ext_vector_type(4)));
 typedef float  f32x4 __attribute__((ext_vector_type(4)));    // 16x16 MFMA accumulator
@@ -31,11 +35,25 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_native));
 }
 
+__device__ __forceinline__ float h2f(f16_t x) { return (float)__builtin_bit_cast(_Float16, x.v); }
+__device__ __forceinline__ f16_t f2h(float f) { f16_t r; r.v = __builtin_bit_cast(uint16_t, (_Float16)f); return r; }     // round-to-nearest-even, overflow -> inf (what a loss scaler looks for)
+typedef _Float16 f16x2_native __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {
+    const f32x2_native v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_native));
+}
+__device__ __forceinline__ void unpack_h2(uint32_t w, float& lo, float& hi) {
+    const f16x2_native h = __builtin_bit_cast(f16x2_native, w);
+    lo = (float)h[0]; hi = (float)h[1];
+}
+
 template <typename T> struct Cvt;
 template <> struct Cvt<float>  { static __device__ __forceinline__ float to_f(float x) { return x; }
                                  static __device__ __forceinline__ float from_f(float x) { return x; } };
 template <> struct Cvt<bf16_t> { static __device__ __forceinline__ float to_f(bf16_t x) { return bf2f(x); }
                                  static __device__ __forceinline__ bf16_t from_f(float x) { return f2bf(x); } };
+template <> struct Cvt<f16_t>  { static __device__ __forceinline__ float to_f(f16_t x) { return h2f(x); }
+                                 static __device__ __forceinline__ f16_t from_f(float x) { return f2h(x); } };
 
 // 16-byte vector of T: VEC = 16/sizeof(T) elements
 template <typename T> struct Vec16 { static constexpr int N = 16 / sizeof(T); uint4 raw; };
@@ -50,6 +68,9 @@ template <> __device__ __forceinline__ void unpack16<bf16_t>(const uint4& r, flo
     o[4] = __uint_as_float(r.z << 16); o[5] = __uint_as_float(r.z & 0xffff0000u);
     o[6] = __uint_as_float(r.w << 16); o[7] = __uint_as_float(r.w & 0xffff0000u);
 }
+template <> __device__ __forceinline__ void unpack16<f16_t>(const uint4& r, float* o) {
+    unpack_h2(r.x, o[0], o[1]); unpack_h2(r.y, o[2], o[3]); unpack_h2(r.z, o[4], o[5]); unpack_h2(r.w, o[6], o[7]);
+}
 template <typename T> __device__ __forceinline__ uint4 pack16(const float* in);
 template <> __device__ __forceinline__ uint4 pack16<float>(const float* i) {
     return make_uint4(__float_as_uint(i[0]), __float_as_uint(i[1]), __float_as_uint(i[2]), __float_as_uint(i[3]));
@@ -57,6 +78,13 @@ template <> __device__ __forceinline__ uint4 pack16<float>(const float* i) {
 template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* i) {
     return make_uint4(pack_bf2(i[0], i[1]), pack_bf2(i[2], i[3]), pack_bf2(i[4], i[5]), pack_bf2(i[6], i[7]));
 }
+template <> __device__ __forceinline__ uint4 pack16<f16_t>(const float* i) {
+    return make_uint4(pack_h2(i[0], i[1]), pack_h2(i[2], i[3]), pack_h2(i[4], i[5]), pack_h2(i[6], i[7]));
+}
+// two 16-bit elements of T from two floats (the 4- and 8-byte store helpers of the kernels)
+template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi);
+template <> __device__ __forceinline__ uint32_t pack2<bf16_t>(float lo, float hi) { return pack_bf2(lo, hi); }
+template <> __device__ __forceinline__ uint32_t pack2<f16_t>(float lo, float hi) { return pack_h2(lo, hi); }
 
 // ---------------------------------------------------------------- wave / block reductions
 __device__ __forceinline__ float wave_sum(float v) {

@@ -128,6 +128,7 @@ extern "C" int ctmi_layernorm_fwd(const void* x, const float* w, const float* b,
     if (rows == 0) return CTMI_OK;
     if (dtype == CTMI_F32) return ln_fwd_launch<float>(x, w, b, y, mean, rstd, rows, cols, eps, as_stream(stream));
     if (dtype == CTMI_BF16) return ln_fwd_launch<bf16_t>(x, w, b, y, mean, rstd, rows, cols, eps, as_stream(stream));
+    if (dtype == CTMI_F16) return ln_fwd_launch<f16_t>(x, w, b, y, mean, rstd, rows, cols, eps, as_stream(stream));
     ctmi_set_error("layernorm_fwd: unsupported dtype %d", dtype);
     return CTMI_ERR_UNSUPPORTED;
 }
@@ -540,6 +541,7 @@ int ctmi_ln_bwd_parts_internal(const void* dy, const void* x, const float* w, co
     ProfScope prof__(CTMI_PROF_LAYERNORM, st);
     if (dtype == CTMI_F32) return ln_bwd_parts<float>(dy, x, w, mean, rstd, dres, dx, ws, rows, cols, want_sums, nparts, ns, st);
     if (dtype == CTMI_BF16) return ln_bwd_parts<bf16_t>(dy, x, w, mean, rstd, dres, dx, ws, rows, cols, want_sums, nparts, ns, st);
+    if (dtype == CTMI_F16) return ln_bwd_parts<f16_t>(dy, x, w, mean, rstd, dres, dx, ws, rows, cols, want_sums, nparts, ns, st);
     ctmi_set_error("layernorm_bwd: unsupported dtype %d", dtype);
     return CTMI_ERR_UNSUPPORTED;
 }
@@ -552,6 +554,7 @@ extern "C" int ctmi_layernorm_bwd(const void* dy, const void* x, const float* w,
     CTMI_REQUIRE(rows > 0 && cols > 0, "layernorm_bwd: bad shape");
     if (dtype == CTMI_F32) return ln_bwd_launch<float>(dy, x, w, mean, rstd, dres, dx, dw, db, accumulate, ws, rows, cols, as_stream(stream));
     if (dtype == CTMI_BF16) return ln_bwd_launch<bf16_t>(dy, x, w, mean, rstd, dres, dx, dw, db, accumulate, ws, rows, cols, as_stream(stream));
+    if (dtype == CTMI_F16) return ln_bwd_launch<f16_t>(dy, x, w, mean, rstd, dres, dx, dw, db, accumulate, ws, rows, cols, as_stream(stream));
     ctmi_set_error("layernorm_bwd: unsupported dtype %d", dtype);
     return CTMI_ERR_UNSUPPORTED;
 }
@@ -642,6 +645,9 @@ int ctmi_colsum_parts_internal(const void* x, int64_t ld, float* ws, int64_t M, 
     } else if (dtype == CTMI_BF16) {
         int vec_ok = (N % 8 == 0) && (ld % 8 == 0) && aligned16(x);
         hipLaunchKernelGGL((colsum_part<bf16_t>), dim3((unsigned)cdiv64(N, 64 * 8), parts), dim3(256), 0, st, (const bf16_t*)x, ld, ws, M, N, rpp, vec_ok);
+    } else if (dtype == CTMI_F16) {
+        int vec_ok = (N % 8 == 0) && (ld % 8 == 0) && aligned16(x);
+        hipLaunchKernelGGL((colsum_part<f16_t>), dim3((unsigned)cdiv64(N, 64 * 8), parts), dim3(256), 0, st, (const f16_t*)x, ld, ws, M, N, rpp, vec_ok);
     } else { ctmi_set_error("colsum: unsupported dtype %d", dtype); return CTMI_ERR_UNSUPPORTED; }
     CTMI_CHECK_LAUNCH("colsum_part");
     *parts_out = parts;
@@ -700,6 +706,7 @@ extern "C" int ctmi_dropout(const void* x, const void* residual, void* y, int64_
     const int vec_ok = aligned16(x) && aligned16(y) && (residual == nullptr || aligned16(residual));
     if (dtype == CTMI_F32) hipLaunchKernelGGL((dropout_k<float>), dim3(grid), dim3(256), 0, as_stream(stream), (const float*)x, (const float*)residual, (float*)y, n, thr, seed, scale, vec_ok);
     else if (dtype == CTMI_BF16) hipLaunchKernelGGL((dropout_k<bf16_t>), dim3(grid), dim3(256), 0, as_stream(stream), (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, n, thr, seed, scale, vec_ok);
+    else if (dtype == CTMI_F16) hipLaunchKernelGGL((dropout_k<f16_t>), dim3(grid), dim3(256), 0, as_stream(stream), (const f16_t*)x, (const f16_t*)residual, (f16_t*)y, n, thr, seed, scale, vec_ok);
     else { ctmi_set_error("dropout: unsupported dtype %d", dtype); return CTMI_ERR_UNSUPPORTED; }
     CTMI_CHECK_LAUNCH("dropout");
     return CTMI_OK;
@@ -804,6 +811,9 @@ extern "C" int ctmi_embed_fwd(const void* table, const int64_t* ids, void* out, 
     } else if (dtype == CTMI_BF16) {
         int vec_ok = (H % 8 == 0) && aligned16(table) && aligned16(out);
         hipLaunchKernelGGL((embed_fwd_k<bf16_t>), dim3(grid), dim3(256), 0, as_stream(stream), (const bf16_t*)table, ids, (bf16_t*)out, n, H, V, vec_ok, err_flag);
+    } else if (dtype == CTMI_F16) {
+        int vec_ok = (H % 8 == 0) && aligned16(table) && aligned16(out);
+        hipLaunchKernelGGL((embed_fwd_k<f16_t>), dim3(grid), dim3(256), 0, as_stream(stream), (const f16_t*)table, ids, (f16_t*)out, n, H, V, vec_ok, err_flag);
     } else { ctmi_set_error("embed_fwd: unsupported dtype %d", dtype); return CTMI_ERR_UNSUPPORTED; }
     CTMI_CHECK_LAUNCH("embed_fwd");
     return CTMI_OK;
@@ -816,6 +826,7 @@ extern "C" int ctmi_embed_bwd(const void* dout, const int64_t* ids, float* dtabl
     int grid = (int)std::min<int64_t>(cdiv64(n, 4), 4096);
     if (dtype == CTMI_F32) hipLaunchKernelGGL((embed_bwd_k<float>), dim3(grid), dim3(256), 0, as_stream(stream), (const float*)dout, ids, dtable, n, H, V, scale);
     else if (dtype == CTMI_BF16) hipLaunchKernelGGL((embed_bwd_k<bf16_t>), dim3(grid), dim3(256), 0, as_stream(stream), (const bf16_t*)dout, ids, dtable, n, H, V, scale);
+    else if (dtype == CTMI_F16) hipLaunchKernelGGL((embed_bwd_k<f16_t>), dim3(grid), dim3(256), 0, as_stream(stream), (const f16_t*)dout, ids, dtable, n, H, V, scale);
     else { ctmi_set_error("embed_bwd: unsupported dtype %d", dtype); return CTMI_ERR_UNSUPPORTED; }
     CTMI_CHECK_LAUNCH("embed_bwd");
     return CTMI_OK;
@@ -995,6 +1006,9 @@ extern "C" int ctmi_ce_fwd(const void* logits, int64_t ld, const int64_t* labels
     } else if (dtype == CTMI_BF16) {
         int vec_ok = (ld % 8 == 0) && aligned16(logits);
         hipLaunchKernelGGL((ce_fwd_k<bf16_t>), dim3((unsigned)N), dim3(256), 0, st, (const bf16_t*)logits, ld, labels, row_lse, row_loss, C, seq, shift, ignore_index, vec_ok);
+    } else if (dtype == CTMI_F16) {
+        int vec_ok = (ld % 8 == 0) && aligned16(logits);
+        hipLaunchKernelGGL((ce_fwd_k<f16_t>), dim3((unsigned)N), dim3(256), 0, st, (const f16_t*)logits, ld, labels, row_lse, row_loss, C, seq, shift, ignore_index, vec_ok);
     } else { ctmi_set_error("ce_fwd: unsupported dtype %d", dtype); return CTMI_ERR_UNSUPPORTED; }
     CTMI_CHECK_LAUNCH("ce_fwd");
     hipLaunchKernelGGL(ce_finalize_k, dim3(1), dim3(1024), 0, st, row_loss, loss_out, N, denom_mode, denom_rows);
@@ -1015,6 +1029,9 @@ extern "C" int ctmi_ce_bwd(const void* logits, int64_t ld, const int64_t* labels
     } else if (dtype == CTMI_BF16) {
         int vec_ok = (ld % 8 == 0) && (ldd % 8 == 0) && aligned16(logits) && aligned16(dlogits);
         hipLaunchKernelGGL((ce_bwd_k<bf16_t>), dim3((unsigned)N), dim3(256), 0, st, (const bf16_t*)logits, ld, labels, row_lse, loss_out, gout, (bf16_t*)dlogits, ldd, C, seq, shift, ignore_index, vec_ok);
+    } else if (dtype == CTMI_F16) {
+        int vec_ok = (ld % 8 == 0) && (ldd % 8 == 0) && aligned16(logits) && aligned16(dlogits);
+        hipLaunchKernelGGL((ce_bwd_k<f16_t>), dim3((unsigned)N), dim3(256), 0, st, (const f16_t*)logits, ld, labels, row_lse, loss_out, gout, (f16_t*)dlogits, ldd, C, seq, shift, ignore_index, vec_ok);
     } else { ctmi_set_error("ce_bwd: unsupported dtype %d", dtype); return CTMI_ERR_UNSUPPORTED; }
     CTMI_CHECK_LAUNCH("ce_bwd");
     return CTMI_OK;
@@ -1173,7 +1190,7 @@ extern "C" int ctmi_ce_fwd_bwd(const void* logits, int64_t ld, const int64_t* la
     ProfScope prof__(CTMI_PROF_LOSS, as_stream(stream));
     CTMI_REQUIRE(logits && labels && row_lse && row_loss && loss_out && dlogits, "ce_fwd_bwd: null pointer");
     CTMI_REQUIRE(N > 0 && C > 0 && seq > 0 && N % seq == 0 && shift >= 0 && ld >= C && ldd >= C, "ce_fwd_bwd: bad shape N=%lld C=%lld seq=%lld", (long long)N, (long long)C, (long long)seq);
-    CTMI_REQUIRE(dtype == CTMI_F32 || dtype == CTMI_BF16, "ce_fwd_bwd: unsupported dtype %d", dtype);
+    CTMI_REQUIRE(dtype == CTMI_F32 || dtype == CTMI_BF16 || dtype == CTMI_F16, "ce_fwd_bwd: unsupported dtype %d", dtype);
     const int vec = dtype == CTMI_F32 ? 4 : 8;
     CTMI_REQUIRE(ld % vec == 0 && ldd % vec == 0 && aligned16(logits) && aligned16(dlogits),
                  "ce_fwd_bwd: rows must be 16-byte aligned (use ctmi_ce_fwd + ctmi_ce_bwd otherwise)");
@@ -1185,6 +1202,10 @@ extern "C" int ctmi_ce_fwd_bwd(const void* logits, int64_t ld, const int64_t* la
         auto kern = &ce_fused_k<float>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hold);
         hipLaunchKernelGGL(kern, dim3((unsigned)N), dim3(1024), lds_hold, st, (const float*)logits, ld, labels, row_lse, row_loss, loss_out, (float*)dlogits, ldd, C, seq, shift, ignore_index, grad_factor, grad_factor_dev);
+    } else if (dtype == CTMI_F16) {
+        auto kern = &ce_fused_k<f16_t>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hold);
+        hipLaunchKernelGGL(kern, dim3((unsigned)N), dim3(1024), lds_hold, st, (const f16_t*)logits, ld, labels, row_lse, row_loss, loss_out, (f16_t*)dlogits, ldd, C, seq, shift, ignore_index, grad_factor, grad_factor_dev);
     } else {
         auto kern = &ce_fused_k<bf16_t>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hold);
@@ -1218,6 +1239,7 @@ extern "C" int ctmi_scale_if(void* x, int64_t ld, int64_t rows, int64_t cols, co
     const unsigned grid = (unsigned)std::min<int64_t>(rows, 4096);
     if (dtype == CTMI_F32) hipLaunchKernelGGL((scale_if_k<float>), dim3(grid), dim3(256), 0, as_stream(stream), (float*)x, ld, rows, cols, s_dev, applied, applied_dev);
     else if (dtype == CTMI_BF16) hipLaunchKernelGGL((scale_if_k<bf16_t>), dim3(grid), dim3(256), 0, as_stream(stream), (bf16_t*)x, ld, rows, cols, s_dev, applied, applied_dev);
+    else if (dtype == CTMI_F16) hipLaunchKernelGGL((scale_if_k<f16_t>), dim3(grid), dim3(256), 0, as_stream(stream), (f16_t*)x, ld, rows, cols, s_dev, applied, applied_dev);
     else { ctmi_set_error("scale_if: unsupported dtype %d", dtype); return CTMI_ERR_UNSUPPORTED; }
     CTMI_CHECK_LAUNCH("scale_if");
     return CTMI_OK;
@@ -1296,6 +1318,7 @@ extern "C" int ctmi_ce_soft_fwd(const void* logits, int64_t ld, const float* tar
     hipStream_t st = as_stream(stream);
     if (dtype == CTMI_F32) hipLaunchKernelGGL((ce_soft_fwd_k<float>), dim3((unsigned)N), dim3(256), 0, st, (const float*)logits, ld, target, ldt, row_lse, row_tsum, row_loss, C);
     else if (dtype == CTMI_BF16) hipLaunchKernelGGL((ce_soft_fwd_k<bf16_t>), dim3((unsigned)N), dim3(256), 0, st, (const bf16_t*)logits, ld, target, ldt, row_lse, row_tsum, row_loss, C);
+    else if (dtype == CTMI_F16) hipLaunchKernelGGL((ce_soft_fwd_k<f16_t>), dim3((unsigned)N), dim3(256), 0, st, (const f16_t*)logits, ld, target, ldt, row_lse, row_tsum, row_loss, C);
     else { ctmi_set_error("ce_soft_fwd: unsupported dtype %d", dtype); return CTMI_ERR_UNSUPPORTED; }
     CTMI_CHECK_LAUNCH("ce_soft_fwd");
     hipLaunchKernelGGL(ce_soft_finalize_k, dim3(1), dim3(1024), 0, st, row_loss, loss_out, N, denom_mode == 1 ? (double)denom_rows : 1.0);
@@ -1311,6 +1334,7 @@ extern "C" int ctmi_ce_soft_bwd(const void* logits, int64_t ld, const float* tar
     hipStream_t st = as_stream(stream);
     if (dtype == CTMI_F32) hipLaunchKernelGGL((ce_soft_bwd_k<float>), dim3((unsigned)N), dim3(256), 0, st, (const float*)logits, ld, target, ldt, row_lse, row_tsum, loss_out, gout, (float*)dlogits, ldd, C);
     else if (dtype == CTMI_BF16) hipLaunchKernelGGL((ce_soft_bwd_k<bf16_t>), dim3((unsigned)N), dim3(256), 0, st, (const bf16_t*)logits, ld, target, ldt, row_lse, row_tsum, loss_out, gout, (bf16_t*)dlogits, ldd, C);
+    else if (dtype == CTMI_F16) hipLaunchKernelGGL((ce_soft_bwd_k<f16_t>), dim3((unsigned)N), dim3(256), 0, st, (const f16_t*)logits, ld, target, ldt, row_lse, row_tsum, loss_out, gout, (f16_t*)dlogits, ldd, C);
     else { ctmi_set_error("ce_soft_bwd: unsupported dtype %d", dtype); return CTMI_ERR_UNSUPPORTED; }
     CTMI_CHECK_LAUNCH("ce_soft_bwd");
     return CTMI_OK;
@@ -1522,6 +1546,9 @@ extern "C" int ctmi_cast(const void* src, int sd, void* dst, int dd, int64_t n, 
     } else if (sd == CTMI_BF16 && dd == CTMI_F32) hipLaunchKernelGGL((cast_k<bf16_t, float>), dim3(grid), dim3(256), 0, st, (const bf16_t*)src, (float*)dst, n);
     else if (sd == CTMI_F32 && dd == CTMI_F32) hipLaunchKernelGGL((cast_k<float, float>), dim3(grid), dim3(256), 0, st, (const float*)src, (float*)dst, n);
     else if (sd == CTMI_BF16 && dd == CTMI_BF16) hipLaunchKernelGGL((cast_k<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, n);
+    else if (sd == CTMI_F32 && dd == CTMI_F16) hipLaunchKernelGGL((cast_k<float, f16_t>), dim3(grid), dim3(256), 0, st, (const float*)src, (f16_t*)dst, n);
+    else if (sd == CTMI_F16 && dd == CTMI_F32) hipLaunchKernelGGL((cast_k<f16_t, float>), dim3(grid), dim3(256), 0, st, (const f16_t*)src, (float*)dst, n);
+    else if (sd == CTMI_F16 && dd == CTMI_F16) hipLaunchKernelGGL((cast_k<f16_t, f16_t>), dim3(grid), dim3(256), 0, st, (const f16_t*)src, (f16_t*)dst, n);
     else { ctmi_set_error("cast: unsupported dtypes %d->%d", sd, dd); return CTMI_ERR_UNSUPPORTED; }
     CTMI_CHECK_LAUNCH("cast");
     return CTMI_OK;
@@ -1550,6 +1577,7 @@ extern "C" int ctmi_transpose_cast(const float* src, void* dst, int dst_dtype, i
     const dim3 grid((unsigned)cdiv64(cols, 64), (unsigned)cdiv64(rows, 64));
     if (dst_dtype == CTMI_F32) hipLaunchKernelGGL((transpose_cast_k<float>), grid, dim3(256), 0, as_stream(stream), src, (float*)dst, rows, cols);
     else if (dst_dtype == CTMI_BF16) hipLaunchKernelGGL((transpose_cast_k<bf16_t>), grid, dim3(256), 0, as_stream(stream), src, (bf16_t*)dst, rows, cols);
+    else if (dst_dtype == CTMI_F16) hipLaunchKernelGGL((transpose_cast_k<f16_t>), grid, dim3(256), 0, as_stream(stream), src, (f16_t*)dst, rows, cols);
     else { ctmi_set_error("transpose_cast: unsupported dtype %d", dst_dtype); return CTMI_ERR_UNSUPPORTED; }
     CTMI_CHECK_LAUNCH("transpose_cast");
     return CTMI_OK;
@@ -1631,6 +1659,7 @@ extern "C" int ctmi_argmax(const void* x, int64_t ld, int64_t* out, int64_t rows
     CTMI_REQUIRE(x && out && rows > 0 && cols > 0 && ld >= cols, "argmax: bad args");
     if (dtype == CTMI_F32) hipLaunchKernelGGL((argmax_k<float>), dim3((unsigned)rows), dim3(256), 0, as_stream(stream), (const float*)x, ld, out, cols);
     else if (dtype == CTMI_BF16) hipLaunchKernelGGL((argmax_k<bf16_t>), dim3((unsigned)rows), dim3(256), 0, as_stream(stream), (const bf16_t*)x, ld, out, cols);
+    else if (dtype == CTMI_F16) hipLaunchKernelGGL((argmax_k<f16_t>), dim3((unsigned)rows), dim3(256), 0, as_stream(stream), (const f16_t*)x, ld, out, cols);
     else { ctmi_set_error("argmax: unsupported dtype %d", dtype); return CTMI_ERR_UNSUPPORTED; }
     CTMI_CHECK_LAUNCH("argmax");
     return CTMI_OK;
@@ -1664,6 +1693,7 @@ extern "C" int ctmi_row_lse(const void* x, int64_t ld, float* stats, int64_t row
     CTMI_REQUIRE(x && stats && rows > 0 && cols > 0 && ld >= cols, "row_lse: bad args");
     if (dtype == CTMI_F32) hipLaunchKernelGGL((row_lse_k<float>), dim3((unsigned)rows), dim3(256), 0, as_stream(stream), (const float*)x, ld, stats, cols);
     else if (dtype == CTMI_BF16) hipLaunchKernelGGL((row_lse_k<bf16_t>), dim3((unsigned)rows), dim3(256), 0, as_stream(stream), (const bf16_t*)x, ld, stats, cols);
+    else if (dtype == CTMI_F16) hipLaunchKernelGGL((row_lse_k<f16_t>), dim3((unsigned)rows), dim3(256), 0, as_stream(stream), (const f16_t*)x, ld, stats, cols);
     else { ctmi_set_error("row_lse: unsupported dtype %d", dtype); return CTMI_ERR_UNSUPPORTED; }
     CTMI_CHECK_LAUNCH("row_lse");
     return CTMI_OK;
@@ -1723,6 +1753,8 @@ extern "C" int ctmi_group_topk(const void* x, int64_t ld, const float* stats, co
                                               (const float*)x, ld, stats, add, add_mul, out_val, out_idx, group, cols, k);
     else if (dtype == CTMI_BF16) hipLaunchKernelGGL((group_topk_k<bf16_t>), dim3((unsigned)groups), dim3(1024), 0, as_stream(stream),
                                                     (const bf16_t*)x, ld, stats, add, add_mul, out_val, out_idx, group, cols, k);
+    else if (dtype == CTMI_F16) hipLaunchKernelGGL((group_topk_k<f16_t>), dim3((unsigned)groups), dim3(1024), 0, as_stream(stream),
+                                                    (const f16_t*)x, ld, stats, add, add_mul, out_val, out_idx, group, cols, k);
     else { ctmi_set_error("group_topk: unsupported dtype %d", dtype); return CTMI_ERR_UNSUPPORTED; }
     CTMI_CHECK_LAUNCH("group_topk");
     return CTMI_OK;

@@ -41,11 +41,12 @@ constexpr int glds_patch_bytes(bool pp, int wm, bool xlane = false) { return (pp
 
 template <typename T> struct Tile;
 template <> struct Tile<bf16_t> { static constexpr int BM = 128, BN = 128, BK = 64, PADK = 8, PADR = 8; };
+template <> struct Tile<f16_t>  { static constexpr int BM = 128, BN = 128, BK = 64, PADK = 8, PADR = 8; };     // (fp16: the register-staged kernel only)
 template <> struct Tile<float>  { static constexpr int BM = 128, BN = 128, BK = 16, PADK = 4, PADR = 4; };
 
 typedef short short4_t __attribute__((ext_vector_type(4)));
 // ds_read_b64_tr_b16 through the compiler builtin (hipcc then tracks its lgkmcnt itself)
-__device__ __forceinline__ uint2 lds_read_tr_b16(const bf16_t* p) {
+__device__ __forceinline__ uint2 lds_read_tr_b16(const void* p) {
     typedef __attribute__((address_space(3))) short4_t lds_v4;
     const short4_t r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(unsigned)(size_t)p);
     return __builtin_bit_cast(uint2, r);
@@ -78,7 +79,7 @@ struct OpTile {
             const T* p = g + gline * ld + gcol;
             T tmp[VEC];
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) tmp[j] = (gline < line_lim && gcol + j < col_lim) ? p[j] : (T)0;
+            for (int j = 0; j < VEC; ++j) tmp[j] = (gline < line_lim && gcol + j < col_lim) ? p[j] : T{};
             regs[i] = *reinterpret_cast<const uint4*>(tmp);
         }
     }
@@ -146,6 +147,16 @@ template <> __device__ __forceinline__ short8 OpTile<bf16_t, true, 128>::frag(co
     const uint2 hi = lds_read_tr_b16(p + 4 * PITCH);
     return __builtin_bit_cast(short8, make_uint4(lo.x, lo.y, hi.x, hi.y));
 }
+template <> __device__ __forceinline__ short8 OpTile<f16_t, false, 128>::frag(const f16_t* __restrict__ tile, int r16, int lane, int kofs) {
+    return *reinterpret_cast<const short8*>(tile + (r16 + (lane & 15)) * PITCH + kofs);
+}
+template <> __device__ __forceinline__ short8 OpTile<f16_t, true, 128>::frag(const f16_t* __restrict__ tile, int r16, int lane, int kofs) {
+    const int i = lane & 15;
+    const f16_t* p = tile + (kofs + (i >> 2)) * PITCH + r16 + 4 * (i & 3);
+    const uint2 lo = lds_read_tr_b16(p);
+    const uint2 hi = lds_read_tr_b16(p + 4 * PITCH);
+    return __builtin_bit_cast(short8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+}
 template <> __device__ __forceinline__ float OpTile<float, false, 128>::frag(const float* __restrict__ tile, int r16, int lane, int kofs) {
     return tile[(r16 + (lane & 15)) * PITCH + kofs];
 }
@@ -186,11 +197,17 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <typename TO> __device__ __forceinline__ void store4(TO* p, const float* v);
 template <> __device__ __forceinline__ void store4<float>(float* p, const float* v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
 template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float* v) { *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])); }
+template <> __device__ __forceinline__ void store4<f16_t>(f16_t* p, const float* v) { *reinterpret_cast<uint2*>(p) = make_uint2(pack_h2(v[0], v[1]), pack_h2(v[2], v[3])); }
 template <typename TO> __device__ __forceinline__ void load4(const TO* p, float* v);
 template <> __device__ __forceinline__ void load4<float>(const float* p, float* v) { float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
 template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float* v) {
     uint2 t = *reinterpret_cast<const uint2*>(p);
     v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u); v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+
+template <> __device__ __forceinline__ void load4<f16_t>(const f16_t* p, float* v) {
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    unpack_h2(t.x, v[0], v[1]); unpack_h2(t.y, v[2], v[3]);
 }
 
 template <typename T, typename TO, bool AK, bool BKM, int EPI, bool FAST>
@@ -1410,7 +1427,7 @@ static int gemm_launch(GemmArgs& g, bool fast, hipStream_t st) {
     using TB = OpTile<T, BKM, Tile<T>::BN>;
     const size_t lds = 2 * (size_t)(TA::ELEMS + TB::ELEMS) * sizeof(T);
     const unsigned grid = (unsigned)(g.tiles_m * g.tiles_n * g.splits);
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (std::is_same<T, bf16_t>::value) {                      // the LDS-DMA family is bf16 (fp16 and fp32 take the register-staged kernel below)
         if (fast && glds_enabled() && g.K % 32 == 0) {
             int tile, splits;
             const int64_t slab = g.M * g.N * (int64_t)sizeof(float);
@@ -1677,6 +1694,27 @@ static int gemm_dispatch_bf16(GemmArgs& g, int ak, int bk, int epi, int out_f32,
     return gemm_unsupported(ak, bk, epi, out_f32);
 }
 
+// fp16 storage (round 5): the same layouts and epilogues as bf16, on the register-staged kernel
+static int gemm_dispatch_f16(GemmArgs& g, int ak, int bk, int epi, int out_f32, bool fast, hipStream_t st) {
+    using T = f16_t;
+    if (!ak && !bk && !out_f32) {
+        if (epi == CTMI_EPI_NONE) return gemm_launch<T, T, false, false, CTMI_EPI_NONE>(g, fast, st);
+        if (epi == CTMI_EPI_GELU) return gemm_launch<T, T, false, false, CTMI_EPI_GELU>(g, fast, st);
+        if (epi == CTMI_EPI_GELUG) return gemm_launch<T, T, false, false, CTMI_EPI_GELUG>(g, fast, st);
+        if (epi == CTMI_EPI_RELU) return gemm_launch<T, T, false, false, CTMI_EPI_RELU>(g, fast, st);
+        if (epi == CTMI_EPI_DGELU) return gemm_launch<T, T, false, false, CTMI_EPI_DGELU>(g, fast, st);
+    }
+    if (!ak && bk && !out_f32) {
+        if (epi == CTMI_EPI_NONE) return gemm_launch<T, T, false, true, CTMI_EPI_NONE>(g, fast, st);
+        if (epi == CTMI_EPI_DGELU) return gemm_launch<T, T, false, true, CTMI_EPI_DGELU>(g, fast, st);
+        if (epi == CTMI_EPI_MUL) return gemm_launch<T, T, false, true, CTMI_EPI_MUL>(g, fast, st);
+        if (epi == CTMI_EPI_DRELU) return gemm_launch<T, T, false, true, CTMI_EPI_DRELU>(g, fast, st);
+        if (epi == CTMI_EPI_GELU) return gemm_launch<T, T, false, true, CTMI_EPI_GELU>(g, fast, st);
+    }
+    if (ak && bk && out_f32 && epi == CTMI_EPI_NONE) return gemm_launch<T, float, true, true, CTMI_EPI_NONE>(g, fast, st);
+    return gemm_unsupported(ak, bk, epi, out_f32);
+}
+
 static int gemm_dispatch_f32(GemmArgs& g, int ak, int bk, int epi, bool fast, hipStream_t st) {   // fp32 storage: output is fp32 either way
     using T = float;
     if (!ak && !bk) {
@@ -1707,7 +1745,7 @@ extern "C" int ctmi_gemm(const void* A, int64_t lda, int a_kmajor, const void* B
     CTMI_REQUIRE(lda >= (a_kmajor ? M : K) && ldb >= (b_kmajor ? N : K) && ldc >= N, "gemm: leading dimension too small");
     CTMI_REQUIRE((epilogue != CTMI_EPI_GELU && epilogue != CTMI_EPI_GELUG) || aux_out, "gemm: GELU epilogues need aux_out");
     CTMI_REQUIRE((epilogue != CTMI_EPI_DGELU && epilogue != CTMI_EPI_DRELU && epilogue != CTMI_EPI_MUL) || aux_in, "gemm: dGELU/dReLU/MUL epilogues need aux_in");
-    CTMI_REQUIRE(dtype == CTMI_F32 || dtype == CTMI_BF16, "gemm: unsupported dtype %d", dtype);
+    CTMI_REQUIRE(dtype == CTMI_F32 || dtype == CTMI_BF16 || dtype == CTMI_F16, "gemm: unsupported dtype %d", dtype);
     // profile class: a vocabulary-sized dimension marks the tied head's three products; otherwise by operand layout
     ProfScope prof__((M >= 65536 || N >= 65536 || K >= 65536) ? CTMI_PROF_LM_HEAD
                      : (a_kmajor && b_kmajor ? CTMI_PROF_GEMM_WGRAD : ((!a_kmajor && b_kmajor) ? CTMI_PROF_GEMM_DGRAD : CTMI_PROF_GEMM_FWD)), as_stream(stream));
@@ -1746,6 +1784,7 @@ extern "C" int ctmi_gemm(const void* A, int64_t lda, int a_kmajor, const void* B
         }
     }
     if (dtype == CTMI_F32) return gemm_dispatch_f32(g, a_kmajor, b_kmajor, epilogue, fast, as_stream(stream));
+    if (dtype == CTMI_F16) return gemm_dispatch_f16(g, a_kmajor, b_kmajor, epilogue, out_f32, fast, as_stream(stream));
     return gemm_dispatch_bf16(g, a_kmajor, b_kmajor, epilogue, out_f32, fast, as_stream(stream));
 }
 #endif  // CTMI_GEMM_HAS(0)

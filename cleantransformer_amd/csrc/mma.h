@@ -13,6 +13,14 @@ template <> struct Mma<bf16_t> {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
     }
 };
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+template <> struct Mma<f16_t> {
+    static constexpr int K = 32, KL = 8;
+    using Frag = short8;
+    static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+};
 template <> struct Mma<float> {
     static constexpr int K = 4, KL = 1;
     using Frag = float;

@@ -34,13 +34,13 @@ def train_step(model, batch, optimizer):
     return loss
 
 
-def train_step_amp(model, batch, optimizer, scaler):
+def train_step_amp(model, batch, optimizer, scaler, amp_dtype=None):
     """The reference's ``use_torch_amp`` branch (ft_bloom_DDP.py:121-127): scaled backward, scaler.step, scaler.update.
     NOTE the reference calls no ``zero_grad()`` on this branch, so gradients accumulate from step to step (each step adds
     scale * g_t to the already-unscaled sum) — kept, because it decides the numbers a side-by-side run prints; pass
     ``zero_grad=True`` for the loop one actually wants."""
     from ..amp import autocast
-    with autocast():
+    with autocast(dtype=amp_dtype):                                  # amp_dtype=torch.float16: the reference's precision (torch's default autocast dtype)
         outputs, _ = model(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], labels=batch["labels"])
         loss = outputs[0]
     scaler.scale(loss).backward()

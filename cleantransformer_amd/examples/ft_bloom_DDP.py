@@ -18,7 +18,7 @@ def print_rank(value, rank_set=None):
 
 
 def train(model, train_loader, epoches, save_interval=1000, print_interval=10, save_dir="./", use_torch_amp=None, apex_level=None,
-          optimizer=None, amp_zero_grad=False):
+          optimizer=None, amp_zero_grad=False, amp_dtype=None):
     """ft_bloom_DDP.py:79-156.  ``use_torch_amp`` selects the GradScaler branch (:107-128) on this package's scaler; apex
     (:91-97) does not exist on ROCm builds of this stack and is refused, as the reference refuses invalid combinations."""
     if use_torch_amp and apex_level is not None:
@@ -47,7 +47,7 @@ def train(model, train_loader, epoches, save_interval=1000, print_interval=10, s
             if scaler is not None:
                 if amp_zero_grad:
                     optimizer.zero_grad()
-                loss = train_step_amp(model, batch, optimizer, scaler)
+                loss = train_step_amp(model, batch, optimizer, scaler, amp_dtype)
             else:
                 loss = train_step(model, batch, optimizer)
             steps += 1

@@ -71,7 +71,8 @@ class BloomConfig():
 def _torch_dtype(name) -> torch.dtype:
     if isinstance(name, torch.dtype):
         return name
-    return {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}[str(name)]
+    return {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16,
+            "fp16": torch.float16, "float16": torch.float16, "half": torch.float16}[str(name)]
 
 
 def alibi_slopes(num_heads: int) -> Tensor:
@@ -564,7 +565,7 @@ class BloomModel(torch.nn.Module):
         if attention_mask is None:
             past_len = 0 if k_v_pasts[0] is None else k_v_pasts[0][0].shape[2]
             attention_mask = torch.ones((input_ids.shape[0], input_ids.shape[1] + past_len), dtype=torch.long, device=input_ids.device)
-        cd = _torch_dtype(getattr(self.config, "compute_dtype", "fp32"))
+        cd = ops.effective_compute_dtype(_torch_dtype(getattr(self.config, "compute_dtype", "fp32")))
         emb = EmbedFn.apply(input_ids, self.word_embeddings.weight, cd, self._tie)
         hidden_states = self.word_embeddings_layernorm(emb)
         actx = _AttnCtx(attention_mask, self.num_heads, self._alibi_slopes(input_ids.device))
@@ -593,7 +594,8 @@ class BloomForCausalLM(torch.nn.Module, GenerationMixin):
         return w if self.lm_head.weight is w else None
 
     def set_compute_dtype(self, dtype):
-        """'fp32' (parity mode) or 'bf16' (MFMA bf16 path, fp32 master weights / grads / optimizer state)."""
+        """'fp32' (parity mode), 'bf16' (the measured MFMA path) or 'fp16' (functional path: the reference's autocast dtype); fp32 master weights /
+        grads / optimizer state in every mode."""
         self.config.compute_dtype = dtype
         return self
 

@@ -348,7 +348,7 @@ class GPTModel(torch.nn.Module):
             position_ids = attention_mask.long().cumsum(-1) - 1
             position_ids.masked_fill_(attention_mask == 0, 1)
             position_ids = position_ids[:, -S:]
-        cd = _torch_dtype(getattr(self.config, "compute_dtype", "fp32"))
+        cd = ops.effective_compute_dtype(_torch_dtype(getattr(self.config, "compute_dtype", "fp32")))
         minfo = ops.MaskInfo(attention_mask)                                         # the additive (1-mask)*finfo.min of :171-175
         tok = EmbedFn.apply(input_ids, self.tokens_embed.weight, cd, self._tie)
         pos = EmbedFn.apply(position_ids.contiguous(), self.position_embed.weight, cd, None)

@@ -16,7 +16,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import AttnDesc, BF16, F32, check
+from ._lib import AttnDesc, BF16, F16, F32, check
 
 Tensor = torch.Tensor
 
@@ -34,7 +34,20 @@ def dt_code(dtype: torch.dtype) -> int:
         return F32
     if dtype == torch.bfloat16:
         return BF16
-    raise _lib.CtmiError(f"unsupported compute dtype {dtype}: the ctmi355 kernels run fp32 or bf16")
+    if dtype == torch.float16:
+        return F16
+    raise _lib.CtmiError(f"unsupported compute dtype {dtype}: the ctmi355 kernels run fp32, bf16 or fp16")
+
+
+# amp.autocast(dtype=...) override of a model's config.compute_dtype for the forwards run inside the context (and their backwards: the saved
+# activations carry the dtype).  Process-wide like torch's autocast state is thread-wide; the training loop is single-threaded on the forward side.
+_AUTOCAST_DTYPE = None
+
+
+def effective_compute_dtype(model_dtype: torch.dtype) -> torch.dtype:
+    """The dtype a model forward computes in: amp.autocast(dtype=torch.float16 / torch.bfloat16)'s while such a context is active (torch.autocast
+    semantics: the context, not the module, picks the matmul dtype — ft_bloom_DDP.py:122), else the model's own config.compute_dtype."""
+    return _AUTOCAST_DTYPE if _AUTOCAST_DTYPE is not None else model_dtype
 
 
 def _need_cuda(*ts):
@@ -1043,12 +1056,15 @@ class _ZeroPadded(threading.local):
 ZERO_PADDED = _ZeroPadded()
 
 def compute_weight(p: Tensor, dtype: torch.dtype) -> Tensor:
-    """The matrix `p` (an fp32 master parameter) in the compute dtype.  fp32 -> p itself.  bf16 -> a cached shadow,
-    refreshed when p's version counter moved (torch optimizers / load_state_dict) and written directly by the fused
-    optimizer (which does not move the counter)."""
+    """The matrix `p` (an fp32 master parameter) in the compute dtype.  fp32 -> p itself.  bf16 / fp16 -> a cached shadow,
+    refreshed when p's version counter moved (torch optimizers / load_state_dict), when the compute dtype changed (an autocast
+    context around a model of another dtype), or when the fused optimizer — which does not move the counter — invalidated it; a
+    bf16 shadow is written directly by the fused optimizer instead."""
     if dtype == torch.float32 or p.dtype == dtype:
         return p.detach()
     sh = getattr(p, "_ct_shadow", None)
+    if sh is not None and sh.dtype != dtype:
+        sh = None                                                           # one shadow per parameter: the compute dtype changed
     if sh is None or sh.device != p.device or sh.shape != p.shape or getattr(p, "_ct_shadow_ver", -1) != p._version \
             or getattr(p, "_ct_shadow_ptr", 0) != p.data_ptr():
         if (sh is None or sh.shape != p.shape or sh.device != p.device) and p.dim() == 2 and p.shape[0] % PAD_ROWS != 0:

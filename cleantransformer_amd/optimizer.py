@@ -86,8 +86,11 @@ class AdamW():
         for t, idx in by_step.items():
             ps = [self.params[i] for i in idx]
             shadows = [getattr(p, "_ct_shadow", None) for p in ps]
-            for p, sh in zip(ps, shadows):                 # a stale shadow would be overwritten anyway; keep its tag in sync
-                if sh is not None:
+            for k, (p, sh) in enumerate(zip(ps, shadows)):
+                if sh is not None and sh.dtype != torch.bfloat16:
+                    shadows[k] = None                       # the fused kernel writes bf16 shadows only: an fp16 shadow is re-cast by the next forward
+                    p._ct_shadow_ver = -1
+                elif sh is not None:                        # a stale shadow would be overwritten anyway; keep its tag in sync
                     p._ct_shadow_ver, p._ct_shadow_ptr = p._version, p.data_ptr()
             ops.adamw_step(ps, [p.grad for p in ps], [self.momentum_buffer[i] for i in idx],
                            [self.rmsp_buffer[i] for i in idx], shadows,
@@ -144,8 +147,11 @@ class SGD():
                 continue
             ps = [self.params[i] for i in idx]
             shadows = [getattr(p, "_ct_shadow", None) for p in ps]
-            for p, sh in zip(ps, shadows):
-                if sh is not None:
+            for k, (p, sh) in enumerate(zip(ps, shadows)):
+                if sh is not None and sh.dtype != torch.bfloat16:
+                    shadows[k] = None
+                    p._ct_shadow_ver = -1
+                elif sh is not None:
                     p._ct_shadow_ver, p._ct_shadow_ptr = p._version, p.data_ptr()
             ops.sgd_step(ps, [p.grad for p in ps], [self.momentum_buffer[i] for i in idx] if self.momentum else None, shadows,
                          lr=self.lr, momentum=self.momentum or 0.0, dampening=self.dampening or 0.0,

@@ -102,33 +102,37 @@ def test_torch_gradscaler_drives_the_fused_optimizer(monkeypatch):
     assert opt.steps[0] == 3
 
 
-def test_autocast_refuses_fp16_and_accepts_the_implemented_dtypes():
-    """ft_bloom_DDP.py:122 writes `with autocast():` (fp16 on a GPU).  There is no fp16 kernel path: an explicit fp16 request raises,
-    the default form warns once, bf16 / fp32 / disabled are silent no-ops."""
+def test_autocast_selects_the_compute_dtype_of_the_forwards_inside_it():
+    """ft_bloom_DDP.py:122 writes `with autocast():` (fp16 on a GPU).  Round 5: the context selects the compute dtype of the model forwards run
+    inside it (ops.effective_compute_dtype) — fp16 (the reference's), bf16 or fp32; nested contexts restore; disabled contexts change nothing;
+    the default form keeps the model's own dtype and says so once; other dtypes are refused."""
     import warnings
-    from cleantransformer_amd import amp
-    with pytest.raises(NotImplementedError):
-        with amp.autocast(dtype=torch.float16):
-            pass
+    from cleantransformer_amd import amp, ops
+    assert ops.effective_compute_dtype(torch.bfloat16) is torch.bfloat16
+    with amp.autocast(dtype=torch.float16):
+        assert ops.effective_compute_dtype(torch.bfloat16) is torch.float16
+        with amp.autocast(dtype=torch.bfloat16):
+            assert ops.effective_compute_dtype(torch.float32) is torch.bfloat16
+        assert ops.effective_compute_dtype(torch.float32) is torch.float16
+        with amp.autocast(False, dtype=torch.float32):        # torch.cuda.amp.autocast(enabled, ...): the first positional argument is `enabled`
+            assert ops.effective_compute_dtype(torch.float32) is torch.float16
+    assert ops.effective_compute_dtype(torch.float32) is torch.float32
     with pytest.raises(NotImplementedError):
         with amp.autocast("cuda", torch.float64):
             pass
+    try:
+        with amp.autocast(True, dtype=torch.float16):
+            raise KeyError("boom")
+    except KeyError:
+        pass
+    assert ops._AUTOCAST_DTYPE is None                        # restored when the body raises
     with warnings.catch_warnings():
         warnings.simplefilter("error")
         with amp.autocast(dtype=torch.bfloat16):
             pass
         with amp.autocast(dtype=torch.float16, enabled=False):
-            pass
-        with amp.autocast(False, dtype=torch.float16):        # torch.cuda.amp.autocast(enabled, ...): the first positional argument is `enabled`
-            pass
-    with pytest.raises(NotImplementedError):
-        with amp.autocast(True, dtype=torch.float16):
-            pass
+            assert ops.effective_compute_dtype(torch.bfloat16) is torch.bfloat16
     amp._warned_default = False
     with pytest.warns(UserWarning, match="fp16"):
         with amp.autocast():
-            pass
-    with warnings.catch_warnings():
-        warnings.simplefilter("error")
-        with amp.autocast():                                  # only once
-            pass
+            assert ops.effective_compute_dtype(torch.bfloat16) is torch.bfloat16

@@ -165,3 +165,113 @@ def test_scaler_registration_ends_with_the_scaler_and_a_moved_scale_is_noticed()
     assert torch.equal(lg.grad.float(), plain)
     off = GradScaler(init_scale=8.0, enabled=False)
     assert off.scale(loss.detach()) is not None and ops.current_expected_loss_grad()[1] is None
+
+
+# ------------------------------------------------------------------------------------------------ fp16 (round 5)
+def _golden_batch():
+    return {"input_ids": T(TINY["ids"]).to(DEV), "attention_mask": T(TINY["mask"]).to(DEV), "labels": T(TINY["ids"]).clone().to(DEV)}
+
+
+@pytest.mark.parametrize("how", ["config", "autocast"])
+def test_fp16_tiny_trajectory_with_dynamic_loss_scaling_tracks_the_fp32_golden(how):
+    """The reference's published DDP launch trains under torch.autocast (fp16 on a GPU) with a GradScaler (ft_bloom_DDP.py:107-128,
+    scripts/ft_bloom_DDP.sh:11).  Here: compute_dtype "fp16" — or an fp32-configured model under amp.autocast(dtype=torch.float16) — with the
+    package's GradScaler at its default initial scale, four steps on the golden batch: the loss follows the reference's fp32 trajectory within the
+    bf16 bars (fp16 has three more mantissa bits: it lands well inside), gradients are fp32, activations fp16, the scaler never backs off, and the
+    gradient norm after unscaling matches the golden one."""
+    import math
+    from test_gpu_bloom import build
+    from cleantransformer_amd.amp import GradScaler, autocast
+    from cleantransformer_amd.optimizer import AdamW
+    V, H, L, nh, B, S = [int(v) for v in TINY["cfg"]]
+    batch = _golden_batch()
+    m = build(V, H, L, nh, "fp16" if how == "config" else "fp32")
+    opt = AdamW(m.parameters(), lr=1e-5, weight_decay=0.01, decoupled=True)
+    scaler = GradScaler()
+    for t in range(4):
+        opt.zero_grad()
+        if how == "config":
+            (loss, logits, _), _ = m(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], labels=batch["labels"])
+        else:
+            with autocast(dtype=torch.float16):
+                (loss, logits, _), _ = m(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], labels=batch["labels"])
+        assert logits.dtype == torch.float16
+        scaler.scale(loss).backward()
+        scaler.unscale_(opt)
+        gn = math.sqrt(sum(float(p.grad.double().pow(2).sum()) for p in m.parameters()))
+        assert all(p.grad.dtype == torch.float32 for p in m.parameters())
+        assert scaler.step(opt) is None or True                       # (AdamW.step returns None)
+        scaler.update()
+        assert abs(float(loss) - TINY["traj"][t, 0]) <= 3e-3 * TINY["traj"][t, 0], (t, float(loss), TINY["traj"][t, 0])
+        assert abs(gn - TINY["traj"][t, 1]) <= 3e-2 * TINY["traj"][t, 1], (t, gn, TINY["traj"][t, 1])
+    assert scaler.get_scale() == 65536.0 and opt.steps[0] == 5
+    if how == "autocast":                                             # outside the context the same model is an fp32 model again
+        (loss, logits, _), _ = m(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], labels=batch["labels"])
+        assert logits.dtype == torch.float32
+
+
+def test_fp16_overflow_is_found_and_skips_the_step_then_training_resumes():
+    """An fp16 run whose loss scale is too large overflows IN the half-precision gradients (not by hand-injected infs): found_inf is raised by the
+    unscale kernel, the step is skipped, the scale halves, Adam's step count does not advance; a few skipped steps later the scale fits and the
+    loop trains (the loss falls)."""
+    from test_gpu_bloom import build
+    from cleantransformer_amd.amp import GradScaler
+    from cleantransformer_amd.optimizer import AdamW
+    V, H, L, nh, B, S = [int(v) for v in TINY["cfg"]]
+    batch = _golden_batch()
+    m = build(V, H, L, nh, "fp16")
+    opt = AdamW(m.parameters(), lr=1e-3, weight_decay=0.0, decoupled=True)
+    scaler = GradScaler(init_scale=2.0 ** 30, growth_interval=1000)      # dlogits ~ 2^30 / (B (S-1)) overflows 65504
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    skipped, losses = 0, []
+    for t in range(40):
+        opt.zero_grad()
+        (loss, _, _), _ = m(**batch)
+        scaler.scale(loss).backward()
+        s0 = scaler.get_scale()
+        scaler.step(opt)
+        scaler.update()
+        if scaler.get_scale() < s0:
+            skipped += 1
+            assert opt.steps[0] == 1 + (t + 1 - skipped)
+            if skipped == 1:
+                for n, p in m.named_parameters():
+                    assert torch.equal(p.detach(), before[n]), n          # a skipped step changes nothing
+        else:
+            losses.append(float(loss))
+    assert skipped >= 5 and scaler.get_scale() == 2.0 ** (30 - skipped), (skipped, scaler.get_scale())
+    assert len(losses) >= 20 and losses[-1] < losses[0] - 0.05, losses
+
+
+def test_fp16_c1_config_trajectory_tracks_the_reference():
+    """BASELINE configs[0] (Bloom-560M 2-layer slice, B=2 S=128, full vocabulary) in fp16 with dynamic loss scaling against the reference-generated
+    fp32 trajectory of tests/golden/c1_bloom.json: loss 3e-3, gradient norm 3e-2 (the bf16 bars), token ids of the first forward equal on
+    >= 99 % of the positions (half-precision logits may flip near-ties among 250 880 candidates)."""
+    import json
+    import math
+    from test_gpu_bloom import build
+    from cleantransformer_amd.amp import GradScaler
+    from cleantransformer_amd.optimizer import AdamW
+    doc = json.load(open(os.path.join(HERE, "golden", "c1_bloom.json")))
+    c = doc["cfg"]
+    m = build(c["V"], c["H"], c["L"], c["nh"], "fp16")
+    ids = torch.randint(0, c["V"], (c["B"], c["S"]), generator=torch.Generator().manual_seed(7))
+    am = torch.ones(c["B"], c["S"], dtype=torch.long)
+    am[c["pad_row"], c["pad_from"]:] = 0
+    ids, am = ids.to(DEV), am.to(DEV)
+    opt = AdamW(m.parameters(), lr=1e-5, weight_decay=0.01, decoupled=True)
+    scaler = GradScaler()
+    for t in range(4):
+        (loss, logits, _), _ = m(input_ids=ids, attention_mask=am, labels=ids.clone())
+        opt.zero_grad()
+        scaler.scale(loss).backward()
+        scaler.unscale_(opt)
+        gn = math.sqrt(sum(float(p.grad.double().pow(2).sum()) for p in m.parameters()))
+        scaler.step(opt)
+        scaler.update()
+        if t == 0:
+            agree = (logits.argmax(-1).cpu() == torch.tensor(doc["argmax"])).float().mean()
+            assert float(agree) >= 0.99, float(agree)
+        assert abs(float(loss) - doc["traj"][t][0]) <= 3e-3 * doc["traj"][t][0], (t, float(loss), doc["traj"][t])
+        assert abs(gn - doc["traj"][t][1]) <= 3e-2 * doc["traj"][t][1], (t, gn, doc["traj"][t])
+    assert scaler.get_scale() == 65536.0
