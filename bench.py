@@ -216,7 +216,9 @@ def main(argv=None):
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--seq", type=int, default=1024)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp16"],
+                    help="compute dtype; bf16 is the metric's (BASELINE.json) and the measured path, fp16 the functional one of round 5 (no loss scaling in this loop: "
+                         "timing only), fp32 parity mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", default="full", choices=["full", "short"], help="short: skip the 24-layer S=1024 CPU sample")
     ap.add_argument("--comm-dtype", default="fp32", choices=["fp32", "bf16"],

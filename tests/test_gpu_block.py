@@ -210,7 +210,7 @@ def _block_inputs(B, S, H, nh, dtype, seed, pad):
 GEOS = [(2, 16, 64, 8), (2, 96, 256, 4), (1, 200, 1024, 16), (2, 256, 1024, 16)]
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("post", [False, True])
 @pytest.mark.parametrize("B,S,H,nh", GEOS)
 def test_block_one_call_equals_per_op_sequence(dtype, post, B, S, H, nh):

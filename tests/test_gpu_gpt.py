@@ -98,11 +98,13 @@ def test_gpt_greedy_decode_bit_exact():
     assert np.array_equal(out.cpu().numpy(), GPT["greedy_out"])
 
 
-def test_gpt_bf16_mode_tracks_fp32():
-    m = build(tiny("gpt2"), cd="bf16")
+@pytest.mark.parametrize("cd,td", [("bf16", torch.bfloat16), ("fp16", torch.float16)])
+def test_gpt_bf16_mode_tracks_fp32(cd, td):
+    """(round 5: and fp16 — Conv1D [in,out] weights, GPT-2's dropouts off in the golden, the -1e4 future fill through the general attention kernels)"""
+    m = build(tiny("gpt2"), cd=cd)
     ids, am = T(GPT["ids"]).to(DEV), T(GPT["mask"]).to(DEV)
     (loss, logits, _), _ = m(ids, attention_mask=am, labels=ids.clone())
-    assert logits.dtype == torch.bfloat16
+    assert logits.dtype == td
     assert abs(float(loss) - float(GPT["gpt2_loss0"])) <= 5e-3 * float(GPT["gpt2_loss0"])
     loss.backward()
     gn = gnorm(m)
