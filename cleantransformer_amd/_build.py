@@ -10,9 +10,9 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libctmi355.so")
-# (source, object, extra flags): gemm.hip is built as four translation units so its template instantiations compile in parallel
+# (source, object, extra flags): gemm.hip is built as seven translation units (fp32 + entry point, three bf16 families, three fp16 families) so its template instantiations compile in parallel
 SOURCES = [("elementwise.hip", "elementwise.o", []), ("attention.hip", "attention.o", []), ("attention_w32.hip", "attention_w32.o", ["-fno-slp-vectorize"]), ("probe.hip", "probe.o", []), ("prof.hip", "prof.o", []), ("comm.hip", "comm.o", []), ("block.hip", "block.o", [])] + \
-          [("gemm.hip", f"gemm_p{i}.o", [f"-DCTMI_GEMM_PART={i}"]) for i in range(4)]
+          [("gemm.hip", f"gemm_p{i}.o", [f"-DCTMI_GEMM_PART={i}"]) for i in range(7)]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wno-unused-value"]
 

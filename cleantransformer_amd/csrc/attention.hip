@@ -1020,7 +1020,10 @@ extern "C" int ctmi_attn_fwd(const void* q, const void* k, const void* v, void* 
     hipStream_t st = as_stream(stream);
     ProfScope prof__(CTMI_PROF_ATTN_FWD, st);
     if (dtype == CTMI_F32) return HDP_DISPATCH(fwd_launch, float);
-    if (dtype == CTMI_F16) return HDP_DISPATCH(fwd_launch, f16_t);                       // fp16: the general kernels
+    if (dtype == CTMI_F16) {                                                             // fp16: the same two kernel families
+        if (ctmi_attn32_fwd(p, st, 1)) { CTMI_CHECK_LAUNCH("attn32_fwd"); return CTMI_OK; }
+        return HDP_DISPATCH(fwd_launch, f16_t);
+    }
     if (ctmi_attn32_fwd(p, st)) { CTMI_CHECK_LAUNCH("attn32_fwd"); return CTMI_OK; }   // training shapes: attention_w32.hip
     return HDP_DISPATCH(fwd_launch, bf16_t);
 }
@@ -1041,7 +1044,10 @@ extern "C" int ctmi_attn_bwd(const void* q, const void* k, const void* v, const 
     hipStream_t st = as_stream(stream);
     ProfScope prof__(CTMI_PROF_ATTN_BWD, st);
     if (dtype == CTMI_F32) return HDP_DISPATCH(bwd_launch, float);
-    if (dtype == CTMI_F16) return HDP_DISPATCH(bwd_launch, f16_t);
+    if (dtype == CTMI_F16) {
+        if (ctmi_attn32_bwd(p, st, 1)) { CTMI_CHECK_LAUNCH("attn32_bwd"); return CTMI_OK; }
+        return HDP_DISPATCH(bwd_launch, f16_t);
+    }
     if (ctmi_attn32_bwd(p, st)) { CTMI_CHECK_LAUNCH("attn32_bwd"); return CTMI_OK; }   // training shapes: attention_w32.hip
     return HDP_DISPATCH(bwd_launch, bf16_t);
 }

@@ -33,6 +33,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8_w32 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_w32 __attribute__((ext_vector_type(8)));
 typedef short short4_w32 __attribute__((ext_vector_type(4)));
 
 // forward: 4-wave workgroups (128 query rows), three per CU at head_dim 64 (168 registers, 3 waves per SIMD from workgroups that no
@@ -73,8 +74,15 @@ typedef short short4_w32 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-__device__ __forceinline__ f32x16 mfma32(short8 a, short8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_w32, a), __builtin_bit_cast(bf16x8_w32, b), c, 0, 0, 0);
+// F16 (round 5): the same kernels on IEEE-half operands — v_mfma_f32_32x32x16_f16, half conversions of P / dS and of the outputs; everything
+// between the matrix instructions (scores, statistics, masks as C operands) is fp32 and does not change
+template <bool F16> __device__ __forceinline__ f32x16 mfma32(short8 a, short8 b, f32x16 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_w32, a), __builtin_bit_cast(f16x8_w32, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_w32, a), __builtin_bit_cast(bf16x8_w32, b), c, 0, 0, 0);
+}
+template <bool F16> __device__ __forceinline__ uint32_t pk2(float lo, float hi) { if constexpr (F16) return pack_h2(lo, hi); else return pack_bf2(lo, hi); }
+template <bool F16> __device__ __forceinline__ float el2f(short x) {
+    if constexpr (F16) { f16_t h; h.v = (uint16_t)x; return h2f(h); } else return bf2f((bf16_t)x);
 }
 __device__ __forceinline__ float max3(float a, float b, float c) {
     float r;
@@ -119,8 +127,8 @@ __device__ __forceinline__ uint2 lds_tr16(const unsigned char* p) {
     typedef __attribute__((address_space(3))) short4_w32 lds_v4;
     return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(unsigned)(size_t)p));
 }
-__device__ __forceinline__ short8 pack8(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
-    return __builtin_bit_cast(short8, make_uint4(pack_bf2(a0, a1), pack_bf2(a2, a3), pack_bf2(a4, a5), pack_bf2(a6, a7)));
+template <bool F16> __device__ __forceinline__ short8 pack8(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
+    return __builtin_bit_cast(short8, make_uint4(pk2<F16>(a0, a1), pk2<F16>(a2, a3), pk2<F16>(a4, a5), pk2<F16>(a6, a7)));
 }
 
 // One streamed operand tile: 64 rows x HD bf16, row-major, rows of ROWB bytes = CPR 16-byte chunks, chunk c of row r stored at
@@ -168,7 +176,7 @@ template <int NW> __device__ __forceinline__ int row_block(int wid) { return NW 
 
 // X^T accumulators (acc[db][r] = X[own row = lane & 31][d = db*32 + (r&3) + 8*(r>>2) + 4*(lane>>5)]) -> bf16 rows in HBM, through a
 // wave-private LDS patch so that every store instruction writes whole contiguous row pieces (16 bytes per lane).
-template <int HD>
+template <int HD, bool F16>
 __device__ __forceinline__ void store_tile32(const f32x16 (&acc)[HD / 32], float mul, bf16_t* g0, int64_t rs, unsigned char* scr, int lane) {
     constexpr int PITCH = HD * 2 + 16, CPR = HD / 8;
     const int l32 = lane & 31, hi = lane >> 5;
@@ -176,7 +184,7 @@ __device__ __forceinline__ void store_tile32(const f32x16 (&acc)[HD / 32], float
     for (int db = 0; db < HD / 32; ++db)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint2 pk = make_uint2(pack_bf2(acc[db][4 * j] * mul, acc[db][4 * j + 1] * mul), pack_bf2(acc[db][4 * j + 2] * mul, acc[db][4 * j + 3] * mul));
+            const uint2 pk = make_uint2(pk2<F16>(acc[db][4 * j] * mul, acc[db][4 * j + 1] * mul), pk2<F16>(acc[db][4 * j + 2] * mul, acc[db][4 * j + 3] * mul));
             *reinterpret_cast<uint2*>(scr + l32 * PITCH + (db * 32 + 8 * j + 4 * hi) * 2) = pk;
         }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -246,7 +254,7 @@ __device__ __forceinline__ void mfma_results_fence() {
 //     future on the diagonal tile (no select after the MFMAs: at the merge of a masked and an unmasked path hipcc copies the whole
 //     accumulator out, one v_mov per score on every tile),
 //   * scores stay in units of 1/scale ("raw") and p = exp2(raw*c - max*c), c = scale*log2(e): ONE fma + ONE exp2 per score.
-template <int HD, int NW, bool REPLACE>       // REPLACE: future scores are REPLACED by a value other than finfo.min (GPT-2's -1e4)
+template <int HD, int NW, bool REPLACE, bool F16 = false>       // REPLACE: future scores are REPLACED by a value other than finfo.min (GPT-2's -1e4); F16: IEEE-half operands
 __global__ __launch_bounds__(NW * 64, NW == 4 ? (HD == 64 ? 3 : 2) : NW / 4) void attn32_fwd_kernel(AttnP p) {
     using W = WT<HD, NW>;
     constexpr int NDS = HD / 16, NDB = HD / 32, TILE = W::TILE, STAGE = 2 * TILE, NPC = W::NPC, RPB = 32 * NW, NST = CTMI_W32_FWD_NST;
@@ -355,8 +363,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (HD == 64 ? 3 : 2) : NW / 4) voi
             }
 #pragma unroll
             for (int ds = 0; ds < NDS; ++ds) {
-                x[0] = mfma32(W::fragA(ks, l32, ds * 2 + hi), qf[ds], x[0]);   // raw score = q.k + bias/scale (padding: finfo.min absorbs the dot)
-                x[1] = mfma32(W::fragA(ks, 32 + l32, ds * 2 + hi), qf[ds], x[1]);
+                x[0] = mfma32<F16>(W::fragA(ks, l32, ds * 2 + hi), qf[ds], x[0]);   // raw score = q.k + bias/scale (padding: finfo.min absorbs the dot)
+                x[1] = mfma32<F16>(W::fragA(ks, 32 + l32, ds * 2 + hi), qf[ds], x[1]);
             }
             mfma_results_fence();
             if (REPLACE && diag) {                                           // GPT-2's -1e4 replacement: padding keys keep finfo.min
@@ -408,7 +416,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (HD == 64 ? 3 : 2) : NW / 4) voi
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
-                    pb[kk][s] = pack8(x[kk][8 * s], x[kk][8 * s + 1], x[kk][8 * s + 2], x[kk][8 * s + 3],
+                    pb[kk][s] = pack8<F16>(x[kk][8 * s], x[kk][8 * s + 1], x[kk][8 * s + 2], x[kk][8 * s + 3],
                                       x[kk][8 * s + 4], x[kk][8 * s + 5], x[kk][8 * s + 6], x[kk][8 * s + 7]);
             lsum = __builtin_fmaf(lsum, alpha, (rs[0] + rs[1]) + (rs[2] + rs[3]));
             if (__any(m_new > m)) {                                          // wave-uniform: rescale only when some row max moved
@@ -423,7 +431,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (HD == 64 ? 3 : 2) : NW / 4) voi
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
-                    for (int db = 0; db < NDB; ++db) o[db] = mfma32(W::fragT(vs, kk * 32 + 16 * s, db, lane), pb[kk][s], o[db]);
+                    for (int db = 0; db < NDB; ++db) o[db] = mfma32<F16>(W::fragT(vs, kk * 32 + 16 * s, db, lane), pb[kk][s], o[db]);
         }
         W32_TICK(tX);
         st = st == NST - 1 ? 0 : st + 1;
@@ -433,7 +441,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (HD == 64 ? 3 : 2) : NW / 4) voi
     __builtin_amdgcn_s_barrier();                                           // every wave is done with the ring: reuse it as store patches
     if (active) {
         bf16_t* op = reinterpret_cast<bf16_t*>(p.out) + b * p.o_bs + h * p.o_hs + (int64_t)q0w * p.o_rs;
-        store_tile32<HD>(o, 1.0f / lsum, op, p.o_rs, smem + wid * 32 * (HD * 2 + 16), lane);
+        store_tile32<HD, F16>(o, 1.0f / lsum, op, p.o_rs, smem + wid * 32 * (HD * 2 + 16), lane);
         if (hi == 0) {
             const int64_t srow = (b * p.nh + h) * p.Sq + q0w + l32;
             p.stat_m[srow] = m <= FINFO_MIN ? FINFO_MIN : m * p.scale;
@@ -450,7 +458,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (HD == 64 ? 3 : 2) : NW / 4) voi
 // ------------------------------------------------------------------------------------------------ backward: dQ
 // own rows = queries.  Per key tile: S^T = K Q^T, dP^T = V dO^T (both with the own query in the accumulator column),
 // P = exp2(s2 - m2) / l, dS^T = P (dP^T - delta), masked entries dS = 0;  dQ^T += K^T dS^T.  Also forms delta = rowsum(dO * O).
-template <int HD, int NW>
+template <int HD, int NW, bool F16 = false>
 __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 3 : NW / 4) void attn32_dq_kernel(AttnP p) {
     using W = WT<HD, NW>;
     constexpr int NDS = HD / 16, NDB = HD / 32, TILE = W::TILE, STAGE = 2 * TILE, NPC = W::NPC, RPB = 32 * NW, NST = CTMI_W32_BWD_NST;
@@ -510,7 +518,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 3 : NW / 4) void a
             gf[ds] = ldg1<short8>(gp + ro + ds * 16 + hi * 8);
             const short8 of = ldg1<short8>(op + ro + ds * 16 + hi * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) dl += bf2f((bf16_t)gf[ds][j]) * bf2f((bf16_t)of[j]);
+            for (int j = 0; j < 8; ++j) dl += el2f<F16>(gf[ds][j]) * el2f<F16>(of[j]);
         }
         // P = exp2(raw * c - m2 - log2 l): 1/l folded into the exponent.  An all-masked row (finfo.min statistic) has only finfo.min
         // scores in this kernel, P = 0 whatever the finite offset.
@@ -571,10 +579,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 3 : NW / 4) void a
             }
 #pragma unroll
             for (int ds = 0; ds < NDS; ++ds) {
-                x[0] = mfma32(W::fragA(ks, l32, ds * 2 + hi), qf[ds], x[0]);
-                x[1] = mfma32(W::fragA(ks, 32 + l32, ds * 2 + hi), qf[ds], x[1]);
-                y[0] = mfma32(W::fragA(vs, l32, ds * 2 + hi), gf[ds], y[0]);
-                y[1] = mfma32(W::fragA(vs, 32 + l32, ds * 2 + hi), gf[ds], y[1]);
+                x[0] = mfma32<F16>(W::fragA(ks, l32, ds * 2 + hi), qf[ds], x[0]);
+                x[1] = mfma32<F16>(W::fragA(ks, 32 + l32, ds * 2 + hi), qf[ds], x[1]);
+                y[0] = mfma32<F16>(W::fragA(vs, l32, ds * 2 + hi), gf[ds], y[0]);
+                y[1] = mfma32<F16>(W::fragA(vs, 32 + l32, ds * 2 + hi), gf[ds], y[1]);
             }
             // per score: one fma, one exp2, one sub, one mul
 #pragma unroll
@@ -588,10 +596,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 3 : NW / 4) void a
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const short8 db8 = pack8(y[kk][8 * s], y[kk][8 * s + 1], y[kk][8 * s + 2], y[kk][8 * s + 3],
+                    const short8 db8 = pack8<F16>(y[kk][8 * s], y[kk][8 * s + 1], y[kk][8 * s + 2], y[kk][8 * s + 3],
                                              y[kk][8 * s + 4], y[kk][8 * s + 5], y[kk][8 * s + 6], y[kk][8 * s + 7]);
 #pragma unroll
-                    for (int db = 0; db < NDB; ++db) dq[db] = mfma32(W::fragT(ks, kk * 32 + 16 * s, db, lane), db8, dq[db]);
+                    for (int db = 0; db < NDB; ++db) dq[db] = mfma32<F16>(W::fragT(ks, kk * 32 + 16 * s, db, lane), db8, dq[db]);
                 }
         }
         st = st == NST - 1 ? 0 : st + 1;
@@ -600,7 +608,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 3 : NW / 4) void a
     __builtin_amdgcn_s_barrier();
     if (active) {
         bf16_t* dqp = reinterpret_cast<bf16_t*>(p.dq) + b * p.q_bs + h * p.q_hs + (int64_t)q0w * p.q_rs;
-        store_tile32<HD>(dq, p.scale, dqp, p.q_rs, smem + wid * 32 * (HD * 2 + 16), lane);
+        store_tile32<HD, F16>(dq, p.scale, dqp, p.q_rs, smem + wid * 32 * (HD * 2 + 16), lane);
     }
 }
 
@@ -608,7 +616,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 3 : NW / 4) void a
 // own rows = keys.  Per query tile: S = Q K^T and dP = dO V^T (own key in the accumulator column), P = exp2(s2 - m2[q]) / l[q],
 // dS = P (dP - delta[q]); dV^T += dO^T P, dK^T += Q^T dS.  Masked entries (padding key, causal future): P keeps the fill value's
 // probability (non-zero only in all-masked rows, which are uniform), dS = 0.
-template <int HD, int NW>
+template <int HD, int NW, bool F16 = false>
 __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 2 : NW / 4) void attn32_dkdv_kernel(AttnP p) {
     using W = WT<HD, NW>;
     constexpr int NDS = HD / 16, NDB = HD / 32, TILE = W::TILE, STAGE = 2 * TILE, NPC = W::NPC, RPB = 32 * NW, NST = CTMI_W32_BWD_NST;
@@ -743,10 +751,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 2 : NW / 4) void a
             }
 #pragma unroll
             for (int ds = 0; ds < NDS; ++ds) {
-                x[0] = mfma32(W::fragA(qs, l32, ds * 2 + hi), kf[ds], x[0]);
-                x[1] = mfma32(W::fragA(qs, 32 + l32, ds * 2 + hi), kf[ds], x[1]);
-                y[0] = mfma32(W::fragA(gs, l32, ds * 2 + hi), vf[ds], y[0]);
-                y[1] = mfma32(W::fragA(gs, 32 + l32, ds * 2 + hi), vf[ds], y[1]);
+                x[0] = mfma32<F16>(W::fragA(qs, l32, ds * 2 + hi), kf[ds], x[0]);
+                x[1] = mfma32<F16>(W::fragA(qs, 32 + l32, ds * 2 + hi), kf[ds], x[1]);
+                y[0] = mfma32<F16>(W::fragA(gs, l32, ds * 2 + hi), vf[ds], y[0]);
+                y[1] = mfma32<F16>(W::fragA(gs, 32 + l32, ds * 2 + hi), vf[ds], y[1]);
             }
             if (!allq) {
                 // every query row has an unmasked key, so a masked pair has P = 0 and dS = 0: a padding key gets there by itself (its
@@ -784,14 +792,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 2 : NW / 4) void a
             for (int qq = 0; qq < 2; ++qq)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const short8 pb = pack8(x[qq][8 * s], x[qq][8 * s + 1], x[qq][8 * s + 2], x[qq][8 * s + 3],
+                    const short8 pb = pack8<F16>(x[qq][8 * s], x[qq][8 * s + 1], x[qq][8 * s + 2], x[qq][8 * s + 3],
                                             x[qq][8 * s + 4], x[qq][8 * s + 5], x[qq][8 * s + 6], x[qq][8 * s + 7]);
-                    const short8 sb = pack8(y[qq][8 * s], y[qq][8 * s + 1], y[qq][8 * s + 2], y[qq][8 * s + 3],
+                    const short8 sb = pack8<F16>(y[qq][8 * s], y[qq][8 * s + 1], y[qq][8 * s + 2], y[qq][8 * s + 3],
                                             y[qq][8 * s + 4], y[qq][8 * s + 5], y[qq][8 * s + 6], y[qq][8 * s + 7]);
 #pragma unroll
                     for (int db = 0; db < NDB; ++db) {
-                        dv[db] = mfma32(W::fragT(gs, qq * 32 + 16 * s, db, lane), pb, dv[db]);
-                        dk[db] = mfma32(W::fragT(qs, qq * 32 + 16 * s, db, lane), sb, dk[db]);
+                        dv[db] = mfma32<F16>(W::fragT(gs, qq * 32 + 16 * s, db, lane), pb, dv[db]);
+                        dk[db] = mfma32<F16>(W::fragT(qs, qq * 32 + 16 * s, db, lane), sb, dk[db]);
                     }
                 }
         }
@@ -809,8 +817,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 2 : NW / 4) void a
         bf16_t* dkp = reinterpret_cast<bf16_t*>(p.dk) + b * p.k_bs + h * p.k_hs + (int64_t)k0w * p.k_rs;
         bf16_t* dvp = reinterpret_cast<bf16_t*>(p.dv) + b * p.v_bs + h * p.v_hs + (int64_t)k0w * p.v_rs;
         unsigned char* scr = smem + wid * 32 * (HD * 2 + 16);
-        store_tile32<HD>(dk, p.scale, dkp, p.k_rs, scr, lane);
-        store_tile32<HD>(dv, 1.0f, dvp, p.v_rs, scr, lane);
+        store_tile32<HD, F16>(dk, p.scale, dkp, p.k_rs, scr, lane);
+        store_tile32<HD, F16>(dv, 1.0f, dvp, p.v_rs, scr, lane);
     }
 }
 
@@ -841,13 +849,21 @@ extern "C" int ctmi_attn_set_path(int mask) {
     return prev;
 }
 
-int ctmi_attn32_fwd(const AttnP& p, hipStream_t st) {
+int ctmi_attn32_fwd(const AttnP& p, hipStream_t st, int f16) {
     if (!w32_ok(p) || !(w32_mask() & 1)) return 0;
     const int64_t BH = p.B * p.nh;
     constexpr int NW = CTMI_W32_FWD_NW, RPB = 32 * NW;
     const bool replace = p.future_fill > FINFO_MIN;
     const int64_t grid = ((p.Sq + RPB - 1) / RPB) * BH;
-    if (p.hd == 64) {
+    if (f16) {
+        if (p.hd == 64) {
+            if (replace) launch32(&attn32_fwd_kernel<64, NW, true, true>, grid, 64 * NW, lds_kv<64, NW>(p, CTMI_W32_FWD_NST), st, p);
+            else launch32(&attn32_fwd_kernel<64, NW, false, true>, grid, 64 * NW, lds_kv<64, NW>(p, CTMI_W32_FWD_NST), st, p);
+        } else {
+            if (replace) launch32(&attn32_fwd_kernel<128, NW, true, true>, grid, 64 * NW, lds_kv<128, NW>(p, CTMI_W32_FWD_NST), st, p);
+            else launch32(&attn32_fwd_kernel<128, NW, false, true>, grid, 64 * NW, lds_kv<128, NW>(p, CTMI_W32_FWD_NST), st, p);
+        }
+    } else if (p.hd == 64) {
         if (replace) launch32(&attn32_fwd_kernel<64, NW, true>, grid, 64 * NW, lds_kv<64, NW>(p, CTMI_W32_FWD_NST), st, p);
         else launch32(&attn32_fwd_kernel<64, NW, false>, grid, 64 * NW, lds_kv<64, NW>(p, CTMI_W32_FWD_NST), st, p);
     } else {
@@ -857,13 +873,18 @@ int ctmi_attn32_fwd(const AttnP& p, hipStream_t st) {
     return 1;
 }
 
-int ctmi_attn32_bwd(const AttnP& p, hipStream_t st) {
+int ctmi_attn32_bwd(const AttnP& p, hipStream_t st, int f16) {
     // head_dim 128: the 32-row accumulators of the backward (dK^T and dV^T: 128 registers) leave one wave per SIMD, and the general
     // 16-row kernels are faster there (B=4 S=2048 nh=32: 797 vs 915 us; after the instruction diet 812 vs 899) — only the forward takes this path at head_dim 128
     if (!w32_ok(p) || !(w32_mask() & 2) || p.hd != 64) return 0;
     const int64_t BH = p.B * p.nh;
     // dQ first: it also publishes delta = rowsum(dO * O) for the dK/dV kernel (same stream: ordered)
     constexpr int NW = CTMI_W32_BWD_NW, RPB = 32 * NW, NST = CTMI_W32_BWD_NST;
+    if (f16) {
+        launch32(&attn32_dq_kernel<64, NW, true>, ((p.Sq + RPB - 1) / RPB) * BH, 64 * NW, lds_kv<64, NW>(p, NST), st, p);
+        launch32(&attn32_dkdv_kernel<64, NW, true>, ((p.Sk + RPB - 1) / RPB) * BH, 64 * NW, lds_qg<64, NW>(p, NST), st, p);
+        return 1;
+    }
     launch32(&attn32_dq_kernel<64, NW>, ((p.Sq + RPB - 1) / RPB) * BH, 64 * NW, lds_kv<64, NW>(p, NST), st, p);
     launch32(&attn32_dkdv_kernel<64, NW>, ((p.Sk + RPB - 1) / RPB) * BH, 64 * NW, lds_qg<64, NW>(p, NST), st, p);
     return 1;

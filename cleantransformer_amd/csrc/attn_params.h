@@ -22,5 +22,5 @@ struct AttnP {
 
 // fast path (attention_w32.hip): returns 1 when it launched the kernels, 0 when the problem is outside its envelope (the
 // caller then takes the general kernels), < 0 never.
-int ctmi_attn32_fwd(const AttnP& p, hipStream_t st);
-int ctmi_attn32_bwd(const AttnP& p, hipStream_t st);
+int ctmi_attn32_fwd(const AttnP& p, hipStream_t st, int f16 = 0);      // f16: IEEE-half operands (round 5)
+int ctmi_attn32_bwd(const AttnP& p, hipStream_t st, int f16 = 0);

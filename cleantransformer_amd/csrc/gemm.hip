@@ -191,7 +191,8 @@ struct GroupedArgs : GemmArgs { GroupProb p[WG_MAXP]; const int4* items; int nit
 constexpr int WG_PART = 16, WG_COLSUM = 32, WG_HALF1 = 64;
 template <bool GRP, int WM> struct GrpRegs { };
 template <int WM> struct GrpRegs<true, WM> { f32x4 accs; bool cs_on; };             // column-sum accumulator of this wave's 16-row block, and whether the tile has one
-#define WG_ONES8 (short8{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80})   /* eight bf16 1.0 */
+#define WG_ONES8 (std::is_same<T, f16_t>::value ? short8{0x3C00, 0x3C00, 0x3C00, 0x3C00, 0x3C00, 0x3C00, 0x3C00, 0x3C00} \
+                                                : short8{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80})   /* eight 1.0 in the operand type (half: 0x3C00, bf16: 0x3F80) */
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <typename TO> __device__ __forceinline__ void store4(TO* p, const float* v);
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 //     s_barrier per K-step orders LDS-DMA writes against the other waves' reads.  The DMA instructions are inline
 //     asm, so hipcc neither counts nor drains them.
 // Requires: bf16, 16-byte aligned operands, K % 32 == 0 (per split).  Anything else takes the v1 kernel above.
-__device__ __forceinline__ void glds16(const bf16_t* gsrc, unsigned lds_dst /* wave-uniform LDS byte address */) {
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst /* wave-uniform LDS byte address */) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
@@ -415,7 +416,7 @@ struct GTile {
     //   16-byte slots of the 256-byte bank row exactly once.
     //  KMAJOR image: [k][ROWS] (rows contiguous).  32-byte blocks of a k-row are XOR-ed with kkey(k) (3 bits), so the
     //   8 k-rows touched by one half-wave of ds_read_b64_tr_b16 land in 8 different 32-byte bank groups.
-    static __device__ __forceinline__ const bf16_t* src(const bf16_t* __restrict__ g, int64_t ld, int64_t row0, int64_t row_lim, int P) {
+    template <typename E> static __device__ __forceinline__ const E* src(const E* __restrict__ g, int64_t ld, int64_t row0, int64_t row_lim, int P) {
         if (!KMAJOR) {
             const int row = P >> 2, cp = P & 3;
             const int c = cp ^ swz4((row >> 2) & 3);
@@ -447,9 +448,9 @@ struct GTile {
     }
 };
 
-template <typename TO, bool AK, bool BKM, int EPI, int WM, int WGN, bool PP, bool RES, bool XLANE, bool GRP, typename GA>
+template <typename TO, bool AK, bool BKM, int EPI, int WM, int WGN, bool PP, bool RES, bool XLANE, bool GRP, typename GA, typename TE = bf16_t>
 __device__ __forceinline__ void glds_body(const GA g) {   // (by value: through a reference hipcc kept a 16-byte piece of the kernel arguments in scratch memory, reloaded in every epilogue)
-    using T = bf16_t;
+    using T = TE;                                                           // bf16_t (the measured path) or f16_t (round 5: same schedules, v_mfma_f32_16x16x32_f16)
     static_assert(!GRP || (PP && WM == 4 && WGN == 4 && AK && BKM && EPI == CTMI_EPI_NONE && sizeof(TO) == 4), "grouped launches: weight gradients on the 128x256 ping-pong tile");
     constexpr int NW = 2 * WGN;                                             // waves: 2 along M x WGN along N
     constexpr int BM = WM * 32, BN = WGN * 64, BK = 32, NST = glds_ring(PP, WM, XLANE);
@@ -1214,11 +1215,18 @@ template <typename TO, bool AK, bool BKM, int EPI, int WM, int WGN, bool PP = fa
 __global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel(GemmArgs g) {
     glds_body<TO, AK, BKM, EPI, WM, WGN, PP, RES, XLANE, false, GemmArgs>(g);
 }
+template <typename TO, bool AK, bool BKM, int EPI, int WM, int WGN, bool PP = false, bool RES = false, bool XLANE = false>
+__global__ __launch_bounds__(128 * WGN, 2) void gemm_glds_kernel_f16(GemmArgs g) {
+    glds_body<TO, AK, BKM, EPI, WM, WGN, PP, RES, XLANE, false, GemmArgs, f16_t>(g);
+}
 // the grouped weight-gradient launch (see GroupedArgs): the 128x256 ping-pong tile of gemm_glds_kernel<float, true, true, 0, 4, 4, true> walking a
 // host-built work list over several problems
 #if CTMI_GEMM_HAS(3) || CTMI_GEMM_PART == 8
 __global__ __launch_bounds__(512, 2) void gemm_wgrad_grouped_kernel(GroupedArgs g) {
     glds_body<float, true, true, CTMI_EPI_NONE, 4, 4, true, false, false, true, GroupedArgs>(g);
+}
+__global__ __launch_bounds__(512, 2) void gemm_wgrad_grouped_kernel_f16(GroupedArgs g) {             // IEEE-half operands (the column sums then multiply by a fragment of half ones)
+    glds_body<float, true, true, CTMI_EPI_NONE, 4, 4, true, false, false, true, GroupedArgs, f16_t>(g);
 }
 // second launch of a grouped call that cut tiles in two along K: C = partial 0 + partial 1 (and the column sums), one 32-row slice of a tile per workgroup
 struct WgReduceArgs { GroupProb p[WG_MAXP]; const int4* tiles; int ntiles; };           // tiles: x = problem | WG_COLSUM, y = first row, z = first column
@@ -1256,7 +1264,7 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ s
 static bool shared_mode();
 static int reserved_cus();
 
-template <typename TO, bool AK, bool BKM, int EPI, int WM, int WGN, bool PP = false, bool RES = false, bool XLANE = false>
+template <typename TE, typename TO, bool AK, bool BKM, int EPI, int WM, int WGN, bool PP = false, bool RES = false, bool XLANE = false>
 static void glds_launch(GemmArgs& g, hipStream_t st) {
     constexpr int BM = WM * 32, BN = WGN * 64;
     const size_t lds = glds_ring(PP, WM, XLANE) * (size_t)(GTile<AK, BM>::BYTES + GTile<BKM, BN>::BYTES) + glds_patch_bytes(PP, WM, XLANE);
@@ -1274,9 +1282,15 @@ static void glds_launch(GemmArgs& g, hipStream_t st) {
     const int64_t per_cu = (int64_t)std::min<size_t>((size_t)(WGN == 4 ? 1 : 8), (160 * 1024) / lds);
     const int64_t slots = (256 - reserve) / 8 * 8 * per_cu;                  // multiple of 8: the XCD-aware item order needs it
     const unsigned grid = (unsigned)((persist && nwork > slots) ? slots : nwork);
-    auto kern = &gemm_glds_kernel<TO, AK, BKM, EPI, WM, WGN, PP, RES, XLANE>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * WGN), lds, st, g);
+    if constexpr (std::is_same<TE, f16_t>::value) {
+        auto kern = &gemm_glds_kernel_f16<TO, AK, BKM, EPI, WM, WGN, PP, RES, XLANE>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * WGN), lds, st, g);
+    } else {
+        auto kern = &gemm_glds_kernel<TO, AK, BKM, EPI, WM, WGN, PP, RES, XLANE>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * WGN), lds, st, g);
+    }
 }
 
 // tile / split choice for the LDS-DMA path:
@@ -1427,7 +1441,7 @@ static int gemm_launch(GemmArgs& g, bool fast, hipStream_t st) {
     using TB = OpTile<T, BKM, Tile<T>::BN>;
     const size_t lds = 2 * (size_t)(TA::ELEMS + TB::ELEMS) * sizeof(T);
     const unsigned grid = (unsigned)(g.tiles_m * g.tiles_n * g.splits);
-    if constexpr (std::is_same<T, bf16_t>::value) {                      // the LDS-DMA family is bf16 (fp16 and fp32 take the register-staged kernel below)
+    if constexpr (std::is_same<T, bf16_t>::value || std::is_same<T, f16_t>::value) {   // the LDS-DMA family: bf16 and (round 5) fp16; fp32 takes the register-staged kernel below
         if (fast && glds_enabled() && g.K % 32 == 0) {
             int tile, splits;
             const int64_t slab = g.M * g.N * (int64_t)sizeof(float);
@@ -1445,14 +1459,14 @@ static int gemm_launch(GemmArgs& g, bool fast, hipStream_t st) {
             constexpr bool CAN_XLANE = !AK && !BKM && sizeof(TO) == 2 && (EPI == CTMI_EPI_NONE || EPI == CTMI_EPI_GELU);
             bool xl = false;
             if constexpr (CAN_XLANE) xl = tile == 3 && !g.nt_c && !res && g.vec8;
-            if (xl) { if constexpr (CAN_XLANE) glds_launch<TO, AK, BKM, EPI, 8, 4, true, false, true>(g, st); }
-            else if (tile == 3) { if constexpr (CAN_RES) { if (res) glds_launch<TO, AK, BKM, EPI, 8, 4, true, true>(g, st); else glds_launch<TO, AK, BKM, EPI, 8, 4, true>(g, st); }
-                             else glds_launch<TO, AK, BKM, EPI, 8, 4, true>(g, st); }
-            else if (tile == 4) { if constexpr (CAN_RES) { if (res) glds_launch<TO, AK, BKM, EPI, 4, 4, true, true>(g, st); else glds_launch<TO, AK, BKM, EPI, 4, 4, true>(g, st); }
-                                  else glds_launch<TO, AK, BKM, EPI, 4, 4, true>(g, st); }
-            else if (tile == 2) glds_launch<TO, AK, BKM, EPI, 8, 4>(g, st);
-            else if (tile == 1) glds_launch<TO, AK, BKM, EPI, 8, 2>(g, st);
-            else glds_launch<TO, AK, BKM, EPI, 4, 2>(g, st);
+            if (xl) { if constexpr (CAN_XLANE) glds_launch<T, TO, AK, BKM, EPI, 8, 4, true, false, true>(g, st); }
+            else if (tile == 3) { if constexpr (CAN_RES) { if (res) glds_launch<T, TO, AK, BKM, EPI, 8, 4, true, true>(g, st); else glds_launch<T, TO, AK, BKM, EPI, 8, 4, true>(g, st); }
+                             else glds_launch<T, TO, AK, BKM, EPI, 8, 4, true>(g, st); }
+            else if (tile == 4) { if constexpr (CAN_RES) { if (res) glds_launch<T, TO, AK, BKM, EPI, 4, 4, true, true>(g, st); else glds_launch<T, TO, AK, BKM, EPI, 4, 4, true>(g, st); }
+                                  else glds_launch<T, TO, AK, BKM, EPI, 4, 4, true>(g, st); }
+            else if (tile == 2) glds_launch<T, TO, AK, BKM, EPI, 8, 4>(g, st);
+            else if (tile == 1) glds_launch<T, TO, AK, BKM, EPI, 8, 2>(g, st);
+            else glds_launch<T, TO, AK, BKM, EPI, 4, 2>(g, st);
             CTMI_CHECK_LAUNCH("gemm_glds");
             if (g.splits > 1) {
                 const int64_t total = g.M * g.N;
@@ -1488,6 +1502,9 @@ static int gemm_launch(GemmArgs& g, bool fast, hipStream_t st) {
 int ctmi_gemm_bf16_nt(GemmArgs& g, int epi, bool fast, hipStream_t st);
 int ctmi_gemm_bf16_nn(GemmArgs& g, int epi, bool fast, hipStream_t st);
 int ctmi_gemm_bf16_tn(GemmArgs& g, int epi, bool fast, hipStream_t st);
+int ctmi_gemm_f16_nt(GemmArgs& g, int epi, bool fast, hipStream_t st);
+int ctmi_gemm_f16_nn(GemmArgs& g, int epi, bool fast, hipStream_t st);
+int ctmi_gemm_f16_tn(GemmArgs& g, int epi, bool fast, hipStream_t st);
 static int gemm_unsupported(int ak, int bk, int epi, int out_f32) {
     ctmi_set_error("gemm: unsupported combination a_kmajor=%d b_kmajor=%d epilogue=%d out_f32=%d", ak, bk, epi, out_f32);
     return CTMI_ERR_UNSUPPORTED;
@@ -1599,7 +1616,7 @@ int ctmi_wgrad_group_mode() {
 }
 
 bool ctmi_wgrad_grouped_ok(const ctmi_wgrad_problem* pr, int n, int64_t T, int dtype) {
-    if (ctmi_wgrad_group_mode() == 0 || !glds_enabled() || dtype != CTMI_BF16 || n < 1 || n > WG_MAXP || T < 64 || T % 32 != 0 || T / 32 > 0x7fff) return false;
+    if (ctmi_wgrad_group_mode() == 0 || !glds_enabled() || (dtype != CTMI_BF16 && dtype != CTMI_F16) || n < 1 || n > WG_MAXP || T < 64 || T % 32 != 0 || T / 32 > 0x7fff) return false;
     for (int i = 0; i < n; ++i) {
         const int64_t M = pr[i].in_out ? pr[i].n_in : pr[i].n_out, N = pr[i].in_out ? pr[i].n_out : pr[i].n_in;
         if (M <= 0 || N <= 0 || M % 128 != 0 || N % 256 != 0) return false;
@@ -1616,7 +1633,7 @@ bool ctmi_wgrad_grouped_ok(const ctmi_wgrad_problem* pr, int n, int64_t T, int d
 extern "C" int ctmi_wgrad_grouped(const ctmi_wgrad_problem* pr, int n, int64_t T, int dtype, void* workspace, int64_t workspace_bytes, void* stream) {
     CTMI_REQUIRE(pr != nullptr, "wgrad_grouped: null problem list");
     if (!ctmi_wgrad_grouped_ok(pr, n, T, dtype)) {
-        ctmi_set_error("wgrad_grouped: unsupported problem set (bf16, <= %d problems, rows a multiple of 128 and columns of 256 of every gradient, T %% 32 == 0, "
+        ctmi_set_error("wgrad_grouped: unsupported problem set (bf16 / fp16, <= %d problems, rows a multiple of 128 and columns of 256 of every gradient, T %% 32 == 0, "
                        "16-byte aligned operands, no bias gradient with an [in,out] weight; CTMI_WGRAD_GROUP != 0)", WG_MAXP);
         return CTMI_ERR_UNSUPPORTED;
     }
@@ -1672,8 +1689,9 @@ extern "C" int ctmi_wgrad_grouped(const ctmi_wgrad_problem* pr, int n, int64_t T
     }
     constexpr size_t lds = 6 * (size_t)(GTile<true, 128>::BYTES + GTile<true, 256>::BYTES);
     const unsigned grid = (unsigned)((persist && tab.nitems > slots) ? slots : tab.nitems);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wgrad_grouped_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(gemm_wgrad_grouped_kernel, dim3(grid), dim3(512), lds, st, g);
+    auto kern = dtype == CTMI_F16 ? &gemm_wgrad_grouped_kernel_f16 : &gemm_wgrad_grouped_kernel;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, g);
     CTMI_CHECK_LAUNCH("wgrad_grouped");
     if (tab.nsplit) {
         WgReduceArgs z = {};
@@ -1686,6 +1704,35 @@ extern "C" int ctmi_wgrad_grouped(const ctmi_wgrad_problem* pr, int n, int64_t T
 }
 #endif
 
+#if CTMI_GEMM_HAS(4)
+int ctmi_gemm_f16_nt(GemmArgs& g, int epi, bool fast, hipStream_t st) {
+    using T = f16_t;
+    if (epi == CTMI_EPI_NONE) return gemm_launch<T, T, false, false, CTMI_EPI_NONE>(g, fast, st);
+    if (epi == CTMI_EPI_GELU) return gemm_launch<T, T, false, false, CTMI_EPI_GELU>(g, fast, st);
+    if (epi == CTMI_EPI_GELUG) return gemm_launch<T, T, false, false, CTMI_EPI_GELUG>(g, fast, st);
+    if (epi == CTMI_EPI_RELU) return gemm_launch<T, T, false, false, CTMI_EPI_RELU>(g, fast, st);
+    if (epi == CTMI_EPI_DGELU) return gemm_launch<T, T, false, false, CTMI_EPI_DGELU>(g, fast, st);
+    return gemm_unsupported(0, 0, epi, 0);
+}
+#endif
+#if CTMI_GEMM_HAS(5)
+int ctmi_gemm_f16_nn(GemmArgs& g, int epi, bool fast, hipStream_t st) {
+    using T = f16_t;
+    if (epi == CTMI_EPI_NONE) return gemm_launch<T, T, false, true, CTMI_EPI_NONE>(g, fast, st);
+    if (epi == CTMI_EPI_DGELU) return gemm_launch<T, T, false, true, CTMI_EPI_DGELU>(g, fast, st);
+    if (epi == CTMI_EPI_MUL) return gemm_launch<T, T, false, true, CTMI_EPI_MUL>(g, fast, st);
+    if (epi == CTMI_EPI_DRELU) return gemm_launch<T, T, false, true, CTMI_EPI_DRELU>(g, fast, st);
+    if (epi == CTMI_EPI_GELU) return gemm_launch<T, T, false, true, CTMI_EPI_GELU>(g, fast, st);
+    return gemm_unsupported(0, 1, epi, 0);
+}
+#endif
+#if CTMI_GEMM_HAS(6)
+int ctmi_gemm_f16_tn(GemmArgs& g, int epi, bool fast, hipStream_t st) {
+    if (epi == CTMI_EPI_NONE) return gemm_launch<f16_t, float, true, true, CTMI_EPI_NONE>(g, fast, st);
+    return gemm_unsupported(1, 1, epi, 1);
+}
+#endif
+
 #if CTMI_GEMM_HAS(0)
 static int gemm_dispatch_bf16(GemmArgs& g, int ak, int bk, int epi, int out_f32, bool fast, hipStream_t st) {
     if (!ak && !bk && !out_f32) return ctmi_gemm_bf16_nt(g, epi, fast, st);
@@ -1694,24 +1741,11 @@ static int gemm_dispatch_bf16(GemmArgs& g, int ak, int bk, int epi, int out_f32,
     return gemm_unsupported(ak, bk, epi, out_f32);
 }
 
-// fp16 storage (round 5): the same layouts and epilogues as bf16, on the register-staged kernel
+// fp16 storage (round 5): the same layouts, epilogues and tile families as bf16 (translation-unit parts 4 / 5 / 6)
 static int gemm_dispatch_f16(GemmArgs& g, int ak, int bk, int epi, int out_f32, bool fast, hipStream_t st) {
-    using T = f16_t;
-    if (!ak && !bk && !out_f32) {
-        if (epi == CTMI_EPI_NONE) return gemm_launch<T, T, false, false, CTMI_EPI_NONE>(g, fast, st);
-        if (epi == CTMI_EPI_GELU) return gemm_launch<T, T, false, false, CTMI_EPI_GELU>(g, fast, st);
-        if (epi == CTMI_EPI_GELUG) return gemm_launch<T, T, false, false, CTMI_EPI_GELUG>(g, fast, st);
-        if (epi == CTMI_EPI_RELU) return gemm_launch<T, T, false, false, CTMI_EPI_RELU>(g, fast, st);
-        if (epi == CTMI_EPI_DGELU) return gemm_launch<T, T, false, false, CTMI_EPI_DGELU>(g, fast, st);
-    }
-    if (!ak && bk && !out_f32) {
-        if (epi == CTMI_EPI_NONE) return gemm_launch<T, T, false, true, CTMI_EPI_NONE>(g, fast, st);
-        if (epi == CTMI_EPI_DGELU) return gemm_launch<T, T, false, true, CTMI_EPI_DGELU>(g, fast, st);
-        if (epi == CTMI_EPI_MUL) return gemm_launch<T, T, false, true, CTMI_EPI_MUL>(g, fast, st);
-        if (epi == CTMI_EPI_DRELU) return gemm_launch<T, T, false, true, CTMI_EPI_DRELU>(g, fast, st);
-        if (epi == CTMI_EPI_GELU) return gemm_launch<T, T, false, true, CTMI_EPI_GELU>(g, fast, st);
-    }
-    if (ak && bk && out_f32 && epi == CTMI_EPI_NONE) return gemm_launch<T, float, true, true, CTMI_EPI_NONE>(g, fast, st);
+    if (!ak && !bk && !out_f32) return ctmi_gemm_f16_nt(g, epi, fast, st);
+    if (!ak && bk && !out_f32) return ctmi_gemm_f16_nn(g, epi, fast, st);
+    if (ak && bk && out_f32) return ctmi_gemm_f16_tn(g, epi, fast, st);
     return gemm_unsupported(ak, bk, epi, out_f32);
 }
 

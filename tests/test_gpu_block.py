@@ -241,7 +241,7 @@ def test_block_one_call_equals_per_op_sequence(dtype, post, B, S, H, nh):
     # the bias column sums): same formula, but hipcc's fp contraction may differ by an ulp, so those are compared to rounding.
     rt = 2e-5 if dtype == torch.float32 else 2e-2
     # round 5: bf16 blocks whose geometry fits the grouped weight-gradient launch (csrc/gemm.hip ctmi_wgrad_grouped) take it in the one-call form
-    grouped = dtype == torch.bfloat16 and H % 256 == 0 and T % 32 == 0 and T >= 64 and os.environ.get("CTMI_WGRAD_GROUP", "1") != "0"
+    grouped = dtype != torch.float32 and H % 256 == 0 and T % 32 == 0 and T >= 64 and os.environ.get("CTMI_WGRAD_GROUP", "1") != "0"
     for side in (False, True):
         dx, grads = results[side]
         assert relerr(dx, dx_ref) < rt, f"dx side={side}"

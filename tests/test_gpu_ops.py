@@ -333,9 +333,11 @@ def _w32_mask(kind, B, S):
     return am
 
 
+@pytest.mark.parametrize("td", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("B,S,nh,hd,kind,fill", W32_CASES)
-def test_attention_128row_kernels_vs_oracle_and_general_kernels(B, S, nh, hd, kind, fill):
-    """csrc/attention_w32.hip (the bf16 training path: 32x32x16 MFMA, masks and row terms as MFMA C operands) on shapes with left /
+def test_attention_128row_kernels_vs_oracle_and_general_kernels(B, S, nh, hd, kind, fill, td):
+    """(round 5: the same kernels on IEEE-half operands as well — v_mfma_f32_32x32x16_f16 — with the same bounds: fp16 only has more mantissa.)
+    csrc/attention_w32.hip (the bf16 training path: 32x32x16 MFMA, masks and row terms as MFMA C operands) on shapes with left /
     right / scattered padding, both fill kinds and both head sizes: against the CPU oracle (finfo.min fill; modeling_bloom.py:84-116),
     against the general kernels of csrc/attention.hip in the same process (GPT-2's -1e4 replacement, whose left-padding quirk rows the
     general kernels reproduce from the reference's golden: tests/test_gpu_gpt.py), on the PUBLISHED statistics (row maximum in the
@@ -345,16 +347,17 @@ def test_attention_128row_kernels_vs_oracle_and_general_kernels(B, S, nh, hd, ki
     from cleantransformer_amd.models.modeling_bloom import alibi_slopes
     FMIN = torch.finfo(torch.float32).min
     H = nh * hd
+    bf = lo(td)
     qkv, go = bf(rnd(B, S, 3 * H, seed=S + hd, scale=0.7)), bf(rnd(B, S, H, seed=S + hd + 1, scale=0.5))
     am = _w32_mask(kind, B, S)
     mask = o.MaskInfo(am.to(DEV))
     slopes = alibi_slopes(nh).to(DEV)
-    qd, god = qkv.reshape(B * S, 3 * H).to(DEV).to(torch.bfloat16), go.reshape(B * S, H).to(DEV).to(torch.bfloat16)
+    qd, god = qkv.reshape(B * S, 3 * H).to(DEV).to(td), go.reshape(B * S, H).to(DEV).to(td)
 
     def run(path_fwd, path_bwd):
         desc = o.fused_qkv_desc(B, S, nh, hd, causal=True)
         desc.future_fill = fill
-        out = torch.empty((B * S, H), dtype=torch.bfloat16, device=DEV)
+        out = torch.empty((B * S, H), dtype=td, device=DEV)
         o.set_attn_path(path_fwd)
         sm, sl = o.attn_fwd(qd, qd[:, hd:], qd[:, 2 * hd:], out, desc, slopes, mask)
         dq = torch.zeros_like(qd)

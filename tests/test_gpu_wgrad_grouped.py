@@ -25,9 +25,9 @@ def lib():
     return _lib
 
 
-def _problems(T, shapes, seed, scale=0.5):
+def _problems(T, shapes, seed, scale=0.5, dtype=torch.bfloat16):
     g = torch.Generator(device=DEV).manual_seed(seed)
-    bfr = lambda *sh: (torch.randn(*sh, generator=g, device=DEV) * scale).to(torch.bfloat16)   # noqa: E731
+    bfr = lambda *sh: (torch.randn(*sh, generator=g, device=DEV) * scale).to(dtype)   # noqa: E731
     return [(bfr(T, n_out), bfr(T, n_in), want_db) for (n_out, n_in, want_db) in shapes]
 
 
@@ -83,6 +83,20 @@ def test_grouped_weight_gradients_vs_fp64_and_per_product(T, shapes):
     for (a, ab), (b, bb) in zip(outs, again):
         assert torch.equal(a, b)
         assert (ab is None and bb is None) or torch.equal(ab, bb)
+
+
+def test_grouped_weight_gradients_on_half_operands():
+    """the fp16 twin of the kernel (round 5: v_mfma_f32_16x16x32_f16, the column sums against a fragment of HALF ones): the measured step's problem
+    set and a small one with odd K-steps, against fp64 of the same half-rounded operands and against the per-product fp16 kernels"""
+    o = ops()
+    for T, shapes in ((8192, BLOOM), (96, [(128, 256, True), (256, 512, False), (384, 256, True)])):
+        probs = _problems(T, shapes, seed=T + 3, dtype=torch.float16)
+        outs = o.wgrad_grouped(probs)
+        torch.cuda.synchronize()
+        for i, ((dy, x, want), (dw, db)) in enumerate(zip(probs, outs)):
+            _check_fp64(f"fp16 problem {i} T={T}", dy, x, dw, db)
+            single = o.linear_wgrad(dy, x)
+            assert float((dw.double() - single.double()).norm() / (single.double().norm() + 1e-30)) < 2e-6, i
 
 
 def test_grouped_weight_gradients_in_out_layout():

@@ -61,6 +61,8 @@ def test_gemm_kernels_fit_their_occupancy(kernels):
     """Round 5: with the ablation / timing / experiment branches out of csrc/gemm.hip NO LDS-DMA GEMM kernel spills (round 4 shipped the
     256-row ping-pong tiles at 256 VGPRs + up to 31 spilled), and every tile keeps headroom below its occupancy step."""
     gemms = pick(kernels, "void gemm_glds_kernel<")
+    gemms.update(pick(kernels, "void gemm_glds_kernel_f16<"))                  # (round 5: the fp16 twins of the same schedules)
+    gemms.update(pick(kernels, "gemm_wgrad_grouped_kernel"))
     for name, k in gemms.items():
         assert k["vgpr_count"] <= 240, (name, k["vgpr_count"])                 # two waves per SIMD (eight-wave tiles: one workgroup per CU)
         assert k["agpr_count"] == 0, (name, k["agpr_count"])

@@ -8,7 +8,7 @@ LDS-DMA piece in flight.  Rounds 1-3 shipped that wait at the head of the steady
 (all 128-row tiles, the XLANE 256-row tiles — ~190 of the 290 GEMM launches of a step): every K-step drained the three-stage ring.  It is
 invisible in the source and in any parity test; this tool makes it visible.
 
-For every kernel of csrc/gemm.hip (three translation-unit parts) and csrc/attention_w32.hip: compile to assembly (device only), find the
+For every kernel of csrc/gemm.hip (six translation-unit parts: three bf16 families, three fp16 families) and csrc/attention_w32.hip: compile to assembly (device only), find the
 innermost loops that contain >= 8 MFMAs and >= 1 LDS-DMA instruction in <= 400 lines (the steady loops), and report every `s_waitcnt` with
 `vmcnt(0)` in them that is NOT inside an inline-asm region — and every hand-written (inline-asm) `vmcnt(N)` of a steady loop whose N is not a
 multiple of the pieces the loop issues per trip (a miscounted immediate).  Exit status 1 if there is any.
@@ -102,7 +102,7 @@ def main(argv):
         extra = ["-DCTMI_GEMM_PART=9", f"-DCTMI_ONE_KERNEL={argv[1]}", *argv[2:]]
         jobs = [("gemm.hip", os.path.join(tmp, "one.s"), extra)]
     else:
-        jobs = [("gemm.hip", os.path.join(tmp, f"gemm_p{p}.s"), [f"-DCTMI_GEMM_PART={p}", *argv]) for p in (1, 2, 3)]
+        jobs = [("gemm.hip", os.path.join(tmp, f"gemm_p{p}.s"), [f"-DCTMI_GEMM_PART={p}", *argv]) for p in (1, 2, 3, 4, 5, 6)]
         jobs.append(("attention_w32.hip", os.path.join(tmp, "attention_w32.s"), ["-fno-slp-vectorize", *argv]))
     if jobs is not None:
         with ThreadPoolExecutor(max_workers=4) as ex:
