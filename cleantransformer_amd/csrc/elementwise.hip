@@ -1352,7 +1352,7 @@ struct MTPack {
     bf16_t* shadow[CTMI_MT_MAX];
     int64_t n[CTMI_MT_MAX];
 };
-struct AdamHyper { float lr, b1, b2, eps, wd, bc1, bc2, sqrt_bc2, gscale; int decoupled, mutate_grad; };
+struct AdamHyper { float lr, b1, b2, eps, wd, bc1, bc2, sqrt_bc2, gscale; int decoupled, mutate_grad, shadow_f16; };
 
 __device__ __forceinline__ void adam_one(float& p, float& g, float& m, float& v, const AdamHyper& h) {
     g *= h.gscale;
@@ -1379,14 +1379,15 @@ __global__ __launch_bounds__(256) void adamw_mt_k(MTPack pk, AdamHyper h) {
         adam_one(P.z, G.z, M.z, V.z, h); adam_one(P.w, G.w, M.w, V.w, h);
         stg_stream(p + 4 * i, P); stg_stream(m + 4 * i, M); stg_stream(v + 4 * i, V);
         if (h.mutate_grad) stg_stream(g + 4 * i, G);
-        if (sh) reinterpret_cast<uint2*>(sh)[i] = make_uint2(pack_bf2(P.x, P.y), pack_bf2(P.z, P.w));
+        // the operand copy of the weights in the compute dtype (bf16, or IEEE half since round 5), written in the same pass
+        if (sh) reinterpret_cast<uint2*>(sh)[i] = h.shadow_f16 ? make_uint2(pack_h2(P.x, P.y), pack_h2(P.z, P.w)) : make_uint2(pack_bf2(P.x, P.y), pack_bf2(P.z, P.w));
     }
     for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         float P = p[i], G = g[i], M = m[i], V = v[i];
         adam_one(P, G, M, V, h);
         p[i] = P; m[i] = M; v[i] = V;
         if (h.mutate_grad) g[i] = G;
-        if (sh) sh[i] = f2bf(P);
+        if (sh) sh[i] = h.shadow_f16 ? f2h(P).v : f2bf(P);
     }
 }
 
@@ -1405,6 +1406,8 @@ extern "C" int ctmi_adamw_step(float* const* p, float* const* g, float* const* m
     h.lr = lr; h.b1 = beta1; h.b2 = beta2; h.eps = eps; h.wd = weight_decay;
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     h.bc1 = (float)bc1; h.bc2 = (float)bc2; h.sqrt_bc2 = (float)sqrt(bc2);
+    h.shadow_f16 = (mutate_grad & CTMI_OPT_SHADOW_F16) ? 1 : 0;
+    mutate_grad &= 1;
     h.gscale = grad_scale; h.decoupled = decoupled; h.mutate_grad = (mutate_grad && !decoupled && weight_decay != 0.f) || (mutate_grad && grad_scale != 1.0f);
     for (int base = 0; base < count; base += CTMI_MT_MAX) {
         const int c = std::min(CTMI_MT_MAX, count - base);
@@ -1482,7 +1485,7 @@ extern "C" int ctmi_amp_update(float* state, float growth, float backoff, int in
     return CTMI_OK;
 }
 
-struct SgdHyper { float lr, momentum, dampening, wd; int first; };
+struct SgdHyper { float lr, momentum, dampening, wd; int first, shadow_f16; };
 __global__ __launch_bounds__(256) void sgd_mt_k(MTPack pk, SgdHyper h) {
     const int ti = blockIdx.y;
     const int64_t n = pk.n[ti];
@@ -1498,14 +1501,14 @@ __global__ __launch_bounds__(256) void sgd_mt_k(MTPack pk, SgdHyper h) {
         g[i] = G;                                                // the reference leaves param.grad = buf / decayed grad
         P -= h.lr * G;
         p[i] = P;
-        if (sh) sh[i] = f2bf(P);
+        if (sh) sh[i] = h.shadow_f16 ? f2h(P).v : f2bf(P);
     }
 }
 extern "C" int ctmi_sgd_step(float* const* p, float* const* g, float* const* buf, void* const* shadow, const int64_t* n,
                              int count, float lr, float momentum, float dampening, float weight_decay, int first_step, void* stream) {
     ProfScope prof__(CTMI_PROF_OPTIMIZER, as_stream(stream));
     CTMI_REQUIRE(p && g && n && count >= 0, "sgd_step: bad args");
-    SgdHyper h{lr, momentum, dampening, weight_decay, first_step};
+    SgdHyper h{lr, momentum, dampening, weight_decay, first_step & 1, (first_step & CTMI_OPT_SHADOW_F16) ? 1 : 0};
     for (int base = 0; base < count; base += CTMI_MT_MAX) {
         const int c = std::min(CTMI_MT_MAX, count - base);
         MTPack pk;

@@ -989,6 +989,14 @@ def _ptr_array(ts):
     return arr
 
 
+def _shadow_flag(shadows) -> int:
+    """the operand copies one fused optimizer launch writes are all bf16 or all IEEE half (the optimizers group by dtype)"""
+    dts = {s_.dtype for s_ in (shadows or []) if s_ is not None}
+    if len(dts) > 1 or (dts and next(iter(dts)) not in (torch.bfloat16, torch.float16)):
+        raise _lib.CtmiError(f"fused optimizer: the operand copies of one launch must share one 16-bit dtype, got {dts}")
+    return _lib.OPT_SHADOW_F16 if dts == {torch.float16} else 0
+
+
 def adamw_step(params, grads, exp_avg, exp_avg_sq, shadows, *, lr, beta1, beta2, eps, weight_decay, step, decoupled,
                mutate_grad=False, grad_scale=1.0) -> None:
     n = len(params)
@@ -998,7 +1006,7 @@ def adamw_step(params, grads, exp_avg, exp_avg_sq, shadows, *, lr, beta1, beta2,
     sh = _ptr_array(shadows) if shadows is not None else None
     check(_lib.load().ctmi_adamw_step(_ptr_array(params), _ptr_array(grads), _ptr_array(exp_avg), _ptr_array(exp_avg_sq), sh,
                                       sizes, n, float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
-                                      int(decoupled), int(mutate_grad), float(grad_scale), _stream()), "adamw_step")
+                                      int(decoupled), int(bool(mutate_grad)) | _shadow_flag(shadows), float(grad_scale), _stream()), "adamw_step")
 
 
 def amp_unscale(grads, state: Tensor) -> None:
@@ -1024,7 +1032,7 @@ def sgd_step(params, grads, bufs, shadows, *, lr, momentum, dampening, weight_de
     sizes = (C.c_int64 * n)(*[p.numel() for p in params])
     check(_lib.load().ctmi_sgd_step(_ptr_array(params), _ptr_array(grads), _ptr_array(bufs) if bufs is not None else None,
                                     _ptr_array(shadows) if shadows is not None else None, sizes, n, float(lr), float(momentum or 0.0),
-                                    float(dampening or 0.0), float(weight_decay or 0.0), int(first_step), _stream()), "sgd_step")
+                                    float(dampening or 0.0), float(weight_decay or 0.0), int(bool(first_step)) | _shadow_flag(shadows), _stream()), "sgd_step")
 
 
 # ------------------------------------------------------------------------------------------------ bf16 shadows

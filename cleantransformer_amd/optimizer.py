@@ -25,6 +25,24 @@ def _flatten_param_groups(params):
     return out
 
 
+def _shadows_of(ps):
+    """The compute-dtype operand copies (ops.compute_weight's `_ct_shadow`) the fused kernel writes in the same pass — bf16 or IEEE half, ONE dtype
+    per launch: if the parameters of a launch carry copies of both (a model that ran under two autocast dtypes), the minority is dropped from the
+    fused write and re-cast by the next forward instead.  A stale copy is overwritten anyway; its tag is kept in sync."""
+    shadows = [getattr(p, "_ct_shadow", None) for p in ps]
+    dts = [sh.dtype for sh in shadows if sh is not None]
+    keep = max(set(dts), key=dts.count) if dts else None
+    for k, (p, sh) in enumerate(zip(ps, shadows)):
+        if sh is None:
+            continue
+        if sh.dtype != keep:
+            shadows[k] = None
+            p._ct_shadow_ver = -1
+        else:
+            p._ct_shadow_ver, p._ct_shadow_ptr = p._version, p.data_ptr()
+    return shadows
+
+
 class AdamW():
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoupled=False,
                  grad_scale=1.0):
@@ -85,13 +103,7 @@ class AdamW():
             by_step.setdefault(self.steps[i], []).append(i)
         for t, idx in by_step.items():
             ps = [self.params[i] for i in idx]
-            shadows = [getattr(p, "_ct_shadow", None) for p in ps]
-            for k, (p, sh) in enumerate(zip(ps, shadows)):
-                if sh is not None and sh.dtype != torch.bfloat16:
-                    shadows[k] = None                       # the fused kernel writes bf16 shadows only: an fp16 shadow is re-cast by the next forward
-                    p._ct_shadow_ver = -1
-                elif sh is not None:                        # a stale shadow would be overwritten anyway; keep its tag in sync
-                    p._ct_shadow_ver, p._ct_shadow_ptr = p._version, p.data_ptr()
+            shadows = _shadows_of(ps)
             ops.adamw_step(ps, [p.grad for p in ps], [self.momentum_buffer[i] for i in idx],
                            [self.rmsp_buffer[i] for i in idx], shadows,
                            lr=self.lr, beta1=self.beta1, beta2=self.beta2, eps=self.eps,
@@ -146,13 +158,7 @@ class SGD():
             if not idx:
                 continue
             ps = [self.params[i] for i in idx]
-            shadows = [getattr(p, "_ct_shadow", None) for p in ps]
-            for k, (p, sh) in enumerate(zip(ps, shadows)):
-                if sh is not None and sh.dtype != torch.bfloat16:
-                    shadows[k] = None
-                    p._ct_shadow_ver = -1
-                elif sh is not None:
-                    p._ct_shadow_ver, p._ct_shadow_ptr = p._version, p.data_ptr()
+            shadows = _shadows_of(ps)
             ops.sgd_step(ps, [p.grad for p in ps], [self.momentum_buffer[i] for i in idx] if self.momentum else None, shadows,
                          lr=self.lr, momentum=self.momentum or 0.0, dampening=self.dampening or 0.0,
                          weight_decay=self.weight_decay or 0.0, first_step=is_first)

@@ -263,6 +263,8 @@ uint32_t ctmi_dropout_threshold(float p);
  *   decoupled=1: p *= 1-lr*wd;  p -= (lr/(1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
  *   grad_scale: multiplies g on read (1/world for deferred DDP averaging, or a clip coefficient). */
 #define CTMI_MT_MAX 24
+/* (ABI v14) the `shadow` copies are bf16 unless CTMI_OPT_SHADOW_F16 is OR-ed into `mutate_grad` (AdamW) / `first_step` (SGD): IEEE half then */
+#define CTMI_OPT_SHADOW_F16 2
 int ctmi_adamw_step(float* const* p /*host*/, float* const* g /*host*/, float* const* m /*host*/, float* const* v /*host*/,
                     void* const* shadow /*host, entries may be NULL*/, const int64_t* n /*host*/, int count,
                     float lr, float beta1, float beta2, float eps, float weight_decay, int step,

@@ -590,18 +590,29 @@ def test_adamw_accepts_generator_and_many_tensors():
         check(f"adamw.many[{i}]", p, ref[i], 1e-5, 1e-7)
 
 
-def test_adamw_refreshes_bf16_shadow():
+@pytest.mark.parametrize("cd", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_adamw_refreshes_bf16_shadow(cd):
+    """the fused optimizers write the operand copy of a weight in the same pass — bf16, or IEEE half (CTMI_OPT_SHADOW_F16, round 5); a parameter
+    whose copy changes dtype (an autocast context of another dtype) gets a new copy from the next compute_weight()"""
     o = ops()
-    from cleantransformer_amd.optimizer import AdamW
+    from cleantransformer_amd.optimizer import AdamW, SGD
+    rd = lo(cd)
     p = torch.nn.Parameter(rnd(300, 40, seed=3).to(DEV))
-    sh = o.compute_weight(p, torch.bfloat16)
-    assert torch.equal(sh.float().cpu(), bf(p.detach().cpu()))
+    sh = o.compute_weight(p, cd)
+    assert sh.dtype == cd and torch.equal(sh.float().cpu(), rd(p.detach().cpu()))
     opt = AdamW([p], lr=1e-1, decoupled=True)
     p.grad = rnd(300, 40, seed=4).to(DEV)
     opt.step()
-    sh2 = o.compute_weight(p, torch.bfloat16)
+    sh2 = o.compute_weight(p, cd)
     assert sh2.data_ptr() == sh.data_ptr()                                           # written in place by the fused kernel
-    assert torch.equal(sh2.float().cpu(), bf(p.detach().cpu()))
+    assert torch.equal(sh2.float().cpu(), rd(p.detach().cpu()))
+    sgd = SGD([p], lr=1e-2)
+    p.grad = rnd(300, 40, seed=5).to(DEV)
+    sgd.step()
+    assert torch.equal(o.compute_weight(p, cd).float().cpu(), rd(p.detach().cpu()))
+    other = torch.float16 if cd == torch.bfloat16 else torch.bfloat16
+    sh3 = o.compute_weight(p, other)
+    assert sh3.dtype == other and torch.equal(sh3.float().cpu(), lo(other)(p.detach().cpu()))
 
 
 def test_sgd_trajectory_matches_reference():
