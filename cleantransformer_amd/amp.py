@@ -33,11 +33,11 @@ def autocast(device_type=None, dtype=None, enabled=True, cache_enabled=None):
     through torch's autocast; the context selects the COMPUTE DTYPE of the model forwards run inside it (``ops.effective_compute_dtype``):
       * ``autocast(dtype=torch.float16)`` — the reference's published DDP launch (scripts/ft_bloom_DDP.sh:11 ``--use_torch_amp``; torch's default
         autocast dtype on a GPU): activations and operand copies of the weights in IEEE half, fp32 accumulation, softmax / LayerNorm / loss
-        statistics in fp32 (a superset of the fp16 -> fp32 score upcast at modeling_bloom.py:106-107), fp32 master weights and gradients — the
-        FUNCTIONAL path (register-staged GEMM tiles, the general attention kernels); a ``GradScaler`` is needed here, as in the reference;
+        statistics in fp32 (a superset of the fp16 -> fp32 score upcast at modeling_bloom.py:106-107), fp32 master weights and gradients, on fp16
+        twins of the bf16 kernel families; a ``GradScaler`` is needed here, as in the reference;
       * ``autocast(dtype=torch.bfloat16)`` — the measured path (same as ``config.compute_dtype = "bf16"``);
       * ``autocast()`` with no dtype (what ft_bloom_DDP.py literally writes) keeps the model's own ``config.compute_dtype`` and says so once: this
-        package's default mixed precision is bf16, not fp16 (no loss scaling needed for range, 2x the GEMM rate of the fp16 path here) — pass
+        package's default mixed precision is bf16, not fp16 (no loss scaling needed for range) — pass
         ``dtype=torch.float16`` (``examples.ft_bloom_DDP.train(amp_dtype=torch.float16)``) to reproduce the reference's precision."""
     global _warned_default
     if isinstance(device_type, bool):        # torch.cuda.amp.autocast's first positional argument is `enabled` (torch.autocast's is device_type):

@@ -8,8 +8,8 @@
 
 typedef uint16_t bf16_t;                                   // raw bfloat16 bits
 // IEEE half (round 5: compute_dtype "fp16" — the autocast dtype of the reference's published DDP launch, ft_bloom_DDP.py:107-128 / scripts/ft_bloom_DDP.sh:11).
-// A distinct C++ type (bf16_t is a plain uint16_t) so that every kernel template gets its own instantiation.  The fp16 path is the FUNCTIONAL one:
-// register-staged GEMM tiles, the general attention kernels; the LDS-DMA GEMM family and the 128-row attention kernels stay bf16 (the measured path).
+// A distinct C++ type (bf16_t is a plain uint16_t) so that every kernel template gets its own instantiation: the LDS-DMA GEMM family, the grouped
+// weight gradients and the 128-row attention kernels have fp16 twins of their bf16 forms (same schedules, the f16 MFMA), like every other kernel.
 struct f16_t { uint16_t v; };
 typedef short  short8 __attribute__((ext_vector_type(8)));   // 8 x bf16 MFMA operand (4 VGPRs)
 typedef short  short4v __attribute__((ext_vector_type(4)));

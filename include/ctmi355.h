@@ -30,7 +30,7 @@ extern "C" {
 
 enum ctmi_dtype { CTMI_F32 = 0, CTMI_BF16 = 1, CTMI_F16 = 2 };
 /* CTMI_F16 (ABI v14): IEEE half storage with fp32 accumulation and statistics — torch.autocast(dtype=float16) of examples/ft_bloom_DDP.py:107-128.
- * The functional path (register-staged GEMM tiles, the general attention kernels); CTMI_BF16 is the measured one. */
+ * Every kernel family of the bf16 path has an fp16 twin (v_mfma_f32_16x16x32_f16 / 32x32x16_f16); CTMI_BF16 is the metric's dtype. */
 enum ctmi_status { CTMI_OK = 0, CTMI_ERR_ARG = -1, CTMI_ERR_LAUNCH = -2, CTMI_ERR_UNSUPPORTED = -3 };
 
 int ctmi_abi_version(void);
