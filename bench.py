@@ -217,8 +217,8 @@ def main(argv=None):
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--seq", type=int, default=1024)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp16"],
-                    help="compute dtype; bf16 is the metric's (BASELINE.json) and the measured path, fp16 the functional one of round 5 (no loss scaling in this loop: "
-                         "timing only), fp32 parity mode")
+                    help="compute dtype; bf16 is the metric's (BASELINE.json); fp16 runs the reference's autocast loop (GradScaler: scale, unscale + inf check, step, "
+                         "update); fp32 parity mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", default="full", choices=["full", "short"], help="short: skip the 24-layer S=1024 CPU sample")
     ap.add_argument("--comm-dtype", default="fp32", choices=["fp32", "bf16"],
@@ -266,10 +266,23 @@ def main(argv=None):
     batch = {"ids": ids, "am": am, "labels": labels}
     holder = {"net": model}
 
+    scaler = None
+    if args.dtype == "fp16":
+        # half-precision gradients need loss scaling — the reference's --use_torch_amp loop (ft_bloom_DDP.py:121-127): without it the softmax part of
+        # dlogits underflows, the backward operands are mostly exact zeros, the matrix pipe draws less power and the step looks ~1 ms FASTER than it is
+        # (measured: profiles/r05_dtype_step.txt; tools/probes/mfma_energy.hip has the all-zero-operand rates)
+        from cleantransformer_amd.amp import GradScaler
+        scaler = GradScaler()
+
     def step():
         outputs, _ = holder["net"](input_ids=batch["ids"], attention_mask=batch["am"], labels=batch["labels"])
         loss = outputs[0]
         opt.zero_grad()
+        if scaler is not None:
+            scaler.scale(loss).backward()
+            scaler.step(opt)
+            scaler.update()
+            return loss
         loss.backward()
         opt.step()
         return loss
