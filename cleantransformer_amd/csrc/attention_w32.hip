@@ -459,7 +459,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (HD == 64 ? 3 : 2) : NW / 4) voi
 // own rows = queries.  Per key tile: S^T = K Q^T, dP^T = V dO^T (both with the own query in the accumulator column),
 // P = exp2(s2 - m2) / l, dS^T = P (dP^T - delta), masked entries dS = 0;  dQ^T += K^T dS^T.  Also forms delta = rowsum(dO * O).
 template <int HD, int NW, bool F16 = false>
-__global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 3 : NW / 4) void attn32_dq_kernel(AttnP p) {
+__global__ __launch_bounds__(NW * 64, NW == 4 ? (HD == 64 ? 3 : 2) : NW / 4) void attn32_dq_kernel(AttnP p) {
     using W = WT<HD, NW>;
     constexpr int NDS = HD / 16, NDB = HD / 32, TILE = W::TILE, STAGE = 2 * TILE, NPC = W::NPC, RPB = 32 * NW, NST = CTMI_W32_BWD_NST;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -552,55 +552,63 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 3 : NW / 4) void a
             const unsigned char* ks = smem + st * STAGE;
             const unsigned char* vs = ks + TILE;
             const int kv0 = t * 64;
-            f32x16 x[2], y[2];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { y[0][r] = 0.f; y[1][r] = 0.f; }
+            // NK halves of the 64-key tile are in flight together: both at head_dim 64 (four independent MFMA chains); ONE at head_dim 128
+            // (round 5: 32 accumulator registers less — with the 64 of dQ^T and the 64 of the own-row fragments that is what keeps two waves per SIMD)
+            constexpr int NK = HD == 128 ? 1 : 2;
             const int thr = q0w + l32 - kv0 - 4 * hi;                       // key offset cc usable iff cc <= thr (not in the causal future)
+#pragma unroll
+            for (int k0h = 0; k0h < 2; k0h += NK) {
+            f32x16 x[NK], y[NK];
+#pragma unroll
+            for (int kk = 0; kk < NK; ++kk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) y[kk][r] = 0.f;
             // A masked pair must give dS = 0.  A padding key does by itself (bias finfo.min -> P = exp2(-huge) = 0); the causal future of
             // the diagonal tile gets finfo.min through the same C operand (a select after the MFMAs costs a register copy per score on
             // every tile, see the forward).  An all-masked query row (LEFT padding) then has P = 0 everywhere: its exponent offset is 0.
             if (kv0 + 63 > q0w) {
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
+                for (int kk = 0; kk < NK; ++kk)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const f32x4 kb4 = *reinterpret_cast<const f32x4*>(kbS + kv0 + kk * 32 + 8 * j + 4 * hi);
+                        const f32x4 kb4 = *reinterpret_cast<const f32x4*>(kbS + kv0 + (k0h + kk) * 32 + 8 * j + 4 * hi);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) x[kk][4 * j + e] = (kk * 32 + 8 * j + e > thr) ? FINFO_MIN : kb4[e];
+                        for (int e = 0; e < 4; ++e) x[kk][4 * j + e] = ((k0h + kk) * 32 + 8 * j + e > thr) ? FINFO_MIN : kb4[e];
                     }
             } else {
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
+                for (int kk = 0; kk < NK; ++kk)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const f32x4 kb4 = *reinterpret_cast<const f32x4*>(kbS + kv0 + kk * 32 + 8 * j + 4 * hi);
+                        const f32x4 kb4 = *reinterpret_cast<const f32x4*>(kbS + kv0 + (k0h + kk) * 32 + 8 * j + 4 * hi);
                         x[kk][4 * j] = kb4[0]; x[kk][4 * j + 1] = kb4[1]; x[kk][4 * j + 2] = kb4[2]; x[kk][4 * j + 3] = kb4[3];
                     }
             }
 #pragma unroll
             for (int ds = 0; ds < NDS; ++ds) {
-                x[0] = mfma32<F16>(W::fragA(ks, l32, ds * 2 + hi), qf[ds], x[0]);
-                x[1] = mfma32<F16>(W::fragA(ks, 32 + l32, ds * 2 + hi), qf[ds], x[1]);
-                y[0] = mfma32<F16>(W::fragA(vs, l32, ds * 2 + hi), gf[ds], y[0]);
-                y[1] = mfma32<F16>(W::fragA(vs, 32 + l32, ds * 2 + hi), gf[ds], y[1]);
+#pragma unroll
+                for (int kk = 0; kk < NK; ++kk) x[kk] = mfma32<F16>(W::fragA(ks, (k0h + kk) * 32 + l32, ds * 2 + hi), qf[ds], x[kk]);
+#pragma unroll
+                for (int kk = 0; kk < NK; ++kk) y[kk] = mfma32<F16>(W::fragA(vs, (k0h + kk) * 32 + l32, ds * 2 + hi), gf[ds], y[kk]);
             }
             // per score: one fma, one exp2, one sub, one mul
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
+            for (int kk = 0; kk < NK; ++kk)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(x[kk][r], c, nm2l));
                     y[kk][r] = pr * (y[kk][r] - dl);
                 }
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
+            for (int kk = 0; kk < NK; ++kk)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const short8 db8 = pack8<F16>(y[kk][8 * s], y[kk][8 * s + 1], y[kk][8 * s + 2], y[kk][8 * s + 3],
                                              y[kk][8 * s + 4], y[kk][8 * s + 5], y[kk][8 * s + 6], y[kk][8 * s + 7]);
 #pragma unroll
-                    for (int db = 0; db < NDB; ++db) dq[db] = mfma32<F16>(W::fragT(ks, kk * 32 + 16 * s, db, lane), db8, dq[db]);
+                    for (int db = 0; db < NDB; ++db) dq[db] = mfma32<F16>(W::fragT(ks, (k0h + kk) * 32 + 16 * s, db, lane), db8, dq[db]);
                 }
+            }
         }
         st = st == NST - 1 ? 0 : st + 1;
     }
@@ -616,8 +624,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 3 : NW / 4) void a
 // own rows = keys.  Per query tile: S = Q K^T and dP = dO V^T (own key in the accumulator column), P = exp2(s2 - m2[q]) / l[q],
 // dS = P (dP - delta[q]); dV^T += dO^T P, dK^T += Q^T dS.  Masked entries (padding key, causal future): P keeps the fill value's
 // probability (non-zero only in all-masked rows, which are uniform), dS = 0.
-template <int HD, int NW, bool F16 = false>
-__global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 2 : NW / 4) void attn32_dkdv_kernel(AttnP p) {
+// MODE (round 5, head_dim 128): 0 = dK and dV in one pass (head_dim 64: 254 registers, two waves per SIMD); 1 = dV only, 2 = dK only — at head_dim 128
+// the two 32-row accumulators (128 registers) plus the K and V fragments (64) left ONE wave per SIMD and the general 16-row kernels were faster
+// (797 vs 915 us at B=4 S=2048 nh=32); split, the dV pass needs no V fragments, no dP and no delta, the dK pass no dV accumulator, both keep two
+// waves per SIMD, and the scores are recomputed once more (the kernel is bound by vector issue and occupancy, not by its matrix work).
+template <int HD, int NW, bool F16 = false, int MODE = 0>
+__global__ __launch_bounds__(NW * 64, (NW == 4 && (HD == 64 || MODE != 0)) ? 2 : NW / 4) void attn32_dkdv_kernel(AttnP p) {
+    constexpr bool DO_DV = MODE != 2, DO_DK = MODE != 1;
     using W = WT<HD, NW>;
     constexpr int NDS = HD / 16, NDB = HD / 32, TILE = W::TILE, STAGE = 2 * TILE, NPC = W::NPC, RPB = 32 * NW, NST = CTMI_W32_BWD_NST;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -690,7 +703,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 2 : NW / 4) void a
 #pragma unroll
         for (int ds = 0; ds < NDS; ++ds) {
             kf[ds] = ldg1<short8>(kp + key * p.k_rs + ds * 16 + hi * 8);
-            vf[ds] = ldg1<short8>(vp + key * p.v_rs + ds * 16 + hi * 8);
+            if constexpr (DO_DK) vf[ds] = ldg1<short8>(vp + key * p.v_rs + ds * 16 + hi * 8);
+            else vf[ds] = short8{0, 0, 0, 0, 0, 0, 0, 0};
         }
         const float slope2 = p.slopes ? p.slopes[h] * LOG2E_F : 0.f;
         const int valid = p.kvalid != nullptr ? (int)p.kvalid[b * p.Sk + key] : 1;
@@ -705,7 +719,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 2 : NW / 4) void a
     float lane_fill = key_pad ? FINFO_MIN : ff2;                            // what a masked score of this lane's key is replaced by
     __syncthreads();
 #pragma unroll
-    for (int ds = 0; ds < NDS; ++ds) { pin(kf[ds]); pin(vf[ds]); }
+    for (int ds = 0; ds < NDS; ++ds) { pin(kf[ds]); if constexpr (DO_DK) pin(vf[ds]); }
     pin(kb_lane); pin(lane_fill);
 
     f32x16 dk[NDB], dv[NDB];
@@ -725,24 +739,30 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 2 : NW / 4) void a
         if (active && t >= my_first) {
             const unsigned char* qs = smem + st * STAGE;
             const unsigned char* gs = qs + TILE;
-            f32x16 x[2], y[2];
+            // NQ halves of the 64-query tile are in flight together: both at head_dim 64; ONE in the dK pass at head_dim 128 (32 accumulator registers less)
+            constexpr int NQ = (HD == 128 && MODE == 2) ? 1 : 2;
             // masked(cc) for the query at offset cc = qq*32 + 8*j + e of this lane's group: padding key, or query index < key index
             const int thr = key_pad ? 0x7fffffff : (k0w + l32 - t * 64 - 4 * hi);
             const bool diag = t * 64 < k0w + 31;                            // some (query, key) pair of the tile is in the causal future
+#pragma unroll
+            for (int q0h = 0; q0h < 2; q0h += NQ) {
+            f32x16 x[NQ], y[NQ];
             if (allq) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { x[0][r] = 0.f; x[1][r] = 0.f; y[0][r] = 0.f; y[1][r] = 0.f; }
+                for (int qq = 0; qq < NQ; ++qq)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { x[qq][r] = 0.f; y[qq][r] = 0.f; }
             } else {
 #pragma unroll
-                for (int qq = 0; qq < 2; ++qq)
+                for (int qq = 0; qq < NQ; ++qq)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const int qi = t * 64 + qq * 32 + 8 * j + 4 * hi;
+                        const int qi = t * 64 + (q0h + qq) * 32 + 8 * j + 4 * hi;
                         const f32x4 a4 = *reinterpret_cast<const f32x4*>(m2S + qi);
                         const f32x4 d4 = *reinterpret_cast<const f32x4*>(dlS + qi);
                         if (diag) {                                            // masked pair: score finfo.min -> P = 0, dS = 0
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) x[qq][4 * j + e] = (qq * 32 + 8 * j + e < thr) ? FINFO_MIN : a4[e];
+                            for (int e = 0; e < 4; ++e) x[qq][4 * j + e] = ((q0h + qq) * 32 + 8 * j + e < thr) ? FINFO_MIN : a4[e];
                         } else {
                             x[qq][4 * j] = a4[0]; x[qq][4 * j + 1] = a4[1]; x[qq][4 * j + 2] = a4[2]; x[qq][4 * j + 3] = a4[3];
                         }
@@ -751,16 +771,18 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 2 : NW / 4) void a
             }
 #pragma unroll
             for (int ds = 0; ds < NDS; ++ds) {
-                x[0] = mfma32<F16>(W::fragA(qs, l32, ds * 2 + hi), kf[ds], x[0]);
-                x[1] = mfma32<F16>(W::fragA(qs, 32 + l32, ds * 2 + hi), kf[ds], x[1]);
-                y[0] = mfma32<F16>(W::fragA(gs, l32, ds * 2 + hi), vf[ds], y[0]);
-                y[1] = mfma32<F16>(W::fragA(gs, 32 + l32, ds * 2 + hi), vf[ds], y[1]);
+#pragma unroll
+                for (int qq = 0; qq < NQ; ++qq) x[qq] = mfma32<F16>(W::fragA(qs, (q0h + qq) * 32 + l32, ds * 2 + hi), kf[ds], x[qq]);
+                if constexpr (DO_DK) {                                          // dP = dO V^T: only dS (hence dK) needs it
+#pragma unroll
+                    for (int qq = 0; qq < NQ; ++qq) y[qq] = mfma32<F16>(W::fragA(gs, (q0h + qq) * 32 + l32, ds * 2 + hi), vf[ds], y[qq]);
+                }
             }
             if (!allq) {
                 // every query row has an unmasked key, so a masked pair has P = 0 and dS = 0: a padding key gets there by itself (its
                 // bias is finfo.min), the causal future through the C operand above.  Per score: one fma, one exp2, one mul.
 #pragma unroll
-                for (int qq = 0; qq < 2; ++qq)
+                for (int qq = 0; qq < NQ; ++qq)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(x[qq][r], c, kb_lane));
@@ -769,17 +791,17 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 2 : NW / 4) void a
                     }
             } else {
 #pragma unroll
-            for (int qq = 0; qq < 2; ++qq)
+            for (int qq = 0; qq < NQ; ++qq)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int qi = t * 64 + qq * 32 + 8 * j + 4 * hi;
+                    const int qi = t * 64 + (q0h + qq) * 32 + 8 * j + 4 * hi;
                     const f32x4 mm = *reinterpret_cast<const f32x4*>(m2S + qi);
                     const f32x4 il4 = *reinterpret_cast<const f32x4*>(ilS + qi);
                     const f32x4 dl4 = *reinterpret_cast<const f32x4*>(dlS + qi);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int r = 4 * j + e;
-                        const bool msk = (qq * 32 + 8 * j + e) < thr;
+                        const bool msk = ((q0h + qq) * 32 + 8 * j + e) < thr;
                         const float s2 = msk ? lane_fill : __builtin_fmaf(x[qq][r], c, kb_lane);
                         const float pr = __builtin_amdgcn_exp2f(s2 - mm[e]) * il4[e];
                         const float d = msk ? 0.f : pr * (y[qq][r] - dl4[e]);
@@ -789,7 +811,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 2 : NW / 4) void a
                 }
             }
 #pragma unroll
-            for (int qq = 0; qq < 2; ++qq)
+            for (int qq = 0; qq < NQ; ++qq)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const short8 pb = pack8<F16>(x[qq][8 * s], x[qq][8 * s + 1], x[qq][8 * s + 2], x[qq][8 * s + 3],
@@ -798,10 +820,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 2 : NW / 4) void a
                                             y[qq][8 * s + 4], y[qq][8 * s + 5], y[qq][8 * s + 6], y[qq][8 * s + 7]);
 #pragma unroll
                     for (int db = 0; db < NDB; ++db) {
-                        dv[db] = mfma32<F16>(W::fragT(gs, qq * 32 + 16 * s, db, lane), pb, dv[db]);
-                        dk[db] = mfma32<F16>(W::fragT(qs, qq * 32 + 16 * s, db, lane), sb, dk[db]);
+                        if constexpr (DO_DV) dv[db] = mfma32<F16>(W::fragT(gs, (q0h + qq) * 32 + 16 * s, db, lane), pb, dv[db]);
+                        if constexpr (DO_DK) dk[db] = mfma32<F16>(W::fragT(qs, (q0h + qq) * 32 + 16 * s, db, lane), sb, dk[db]);
                     }
                 }
+            }
         }
         st = st == NST - 1 ? 0 : st + 1;
     }
@@ -817,8 +840,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD == 64) ? 2 : NW / 4) void a
         bf16_t* dkp = reinterpret_cast<bf16_t*>(p.dk) + b * p.k_bs + h * p.k_hs + (int64_t)k0w * p.k_rs;
         bf16_t* dvp = reinterpret_cast<bf16_t*>(p.dv) + b * p.v_bs + h * p.v_hs + (int64_t)k0w * p.v_rs;
         unsigned char* scr = smem + wid * 32 * (HD * 2 + 16);
-        store_tile32<HD, F16>(dk, p.scale, dkp, p.k_rs, scr, lane);
-        store_tile32<HD, F16>(dv, 1.0f, dvp, p.v_rs, scr, lane);
+        if constexpr (DO_DK) store_tile32<HD, F16>(dk, p.scale, dkp, p.k_rs, scr, lane);
+        if constexpr (DO_DV) store_tile32<HD, F16>(dv, 1.0f, dvp, p.v_rs, scr, lane);
     }
 }
 
@@ -876,10 +899,23 @@ int ctmi_attn32_fwd(const AttnP& p, hipStream_t st, int f16) {
 int ctmi_attn32_bwd(const AttnP& p, hipStream_t st, int f16) {
     // head_dim 128: the 32-row accumulators of the backward (dK^T and dV^T: 128 registers) leave one wave per SIMD, and the general
     // 16-row kernels are faster there (B=4 S=2048 nh=32: 797 vs 915 us; after the instruction diet 812 vs 899) — only the forward takes this path at head_dim 128
-    if (!w32_ok(p) || !(w32_mask() & 2) || p.hd != 64) return 0;
+    if (!w32_ok(p) || !(w32_mask() & 2)) return 0;
     const int64_t BH = p.B * p.nh;
     // dQ first: it also publishes delta = rowsum(dO * O) for the dK/dV kernel (same stream: ordered)
     constexpr int NW = CTMI_W32_BWD_NW, RPB = 32 * NW, NST = CTMI_W32_BWD_NST;
+    if (p.hd == 128) {                                                           // round 5: dQ, then dV and dK in two passes (see MODE)
+        const int64_t gq = ((p.Sq + RPB - 1) / RPB) * BH, gk = ((p.Sk + RPB - 1) / RPB) * BH;
+        if (f16) {
+            launch32(&attn32_dq_kernel<128, NW, true>, gq, 64 * NW, lds_kv<128, NW>(p, NST), st, p);
+            launch32(&attn32_dkdv_kernel<128, NW, true, 1>, gk, 64 * NW, lds_qg<128, NW>(p, NST), st, p);
+            launch32(&attn32_dkdv_kernel<128, NW, true, 2>, gk, 64 * NW, lds_qg<128, NW>(p, NST), st, p);
+        } else {
+            launch32(&attn32_dq_kernel<128, NW, false>, gq, 64 * NW, lds_kv<128, NW>(p, NST), st, p);
+            launch32(&attn32_dkdv_kernel<128, NW, false, 1>, gk, 64 * NW, lds_qg<128, NW>(p, NST), st, p);
+            launch32(&attn32_dkdv_kernel<128, NW, false, 2>, gk, 64 * NW, lds_qg<128, NW>(p, NST), st, p);
+        }
+        return 1;
+    }
     if (f16) {
         launch32(&attn32_dq_kernel<64, NW, true>, ((p.Sq + RPB - 1) / RPB) * BH, 64 * NW, lds_kv<64, NW>(p, NST), st, p);
         launch32(&attn32_dkdv_kernel<64, NW, true>, ((p.Sk + RPB - 1) / RPB) * BH, 64 * NW, lds_qg<64, NW>(p, NST), st, p);
