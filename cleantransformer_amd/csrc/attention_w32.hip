@@ -634,9 +634,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && (HD == 64 || MODE != 0)) ? 2 :
     using W = WT<HD, NW>;
     constexpr int NDS = HD / 16, NDB = HD / 32, TILE = W::TILE, STAGE = 2 * TILE, NPC = W::NPC, RPB = 32 * NW, NST = CTMI_W32_BWD_NST;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* m2S = reinterpret_cast<float*>(smem + NST * STAGE);                // [Sq] row max in log2 units | [Sq] 1/l | [Sq] delta
-    float* ilS = m2S + p.Sq;
-    float* dlS = ilS + p.Sq;
+    // per-query statistics, see lds_qg(): [Sq] score offset | [Sq] delta (not in the dV pass, which has no dS)
+    float* m2S = reinterpret_cast<float*>(smem + NST * STAGE);
+    float* dlS = m2S + p.Sq;
     const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, hi = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rbw = row_block<NW>(wid);
@@ -644,6 +644,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && (HD == 64 || MODE != 0)) ? 2 :
     const int vid = blockIdx.x;
     const int kblk = vid / BH, bh = vid % BH;                                // early key blocks (most query tiles) first
     const int64_t h = bh % p.nh, b = bh / p.nh;
+    const float* slG = p.stat_l + (b * p.nh + h) * p.Sq;                     // exact path (left padding): l is read from L2, not staged
     const int k0 = kblk * RPB, k0w = k0 + 32 * rbw;
     const bool active = k0w < (int)p.Sk;
     // all-masked query rows (LEFT padding) are uniform over ALL keys -> they reach every key block
@@ -684,13 +685,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && (HD == 64 || MODE != 0)) ? 2 :
             const float mm = sm[q], ll = sl[q];
             if (allq) {                                                      // exact path (all-masked query rows exist in this batch row)
                 m2S[q] = mm <= FINFO_MIN ? FINFO_MIN : mm * LOG2E_F;
-                ilS[q] = 1.0f / ll;
-                dlS[q] = sd[q];
+                if constexpr (DO_DK) dlS[q] = sd[q];
             } else {
                 // fast path: both per-query terms enter as the C operands of the tile's first MFMAs — the score accumulator starts at
                 // -(m2 + log2 l) / c (raw units), the dP accumulator at -delta — and the loop is P = exp2(fma(raw, c, bias)), dS = P * dPd
                 m2S[q] = -(mm * LOG2E_F + __builtin_amdgcn_logf(ll)) * rc;
-                dlS[q] = -sd[q];
+                if constexpr (DO_DK) dlS[q] = -sd[q];
             }
         }
     }
@@ -759,7 +759,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && (HD == 64 || MODE != 0)) ? 2 :
                     for (int j = 0; j < 4; ++j) {
                         const int qi = t * 64 + (q0h + qq) * 32 + 8 * j + 4 * hi;
                         const f32x4 a4 = *reinterpret_cast<const f32x4*>(m2S + qi);
-                        const f32x4 d4 = *reinterpret_cast<const f32x4*>(dlS + qi);
+                        f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
+                        if constexpr (DO_DK) d4 = *reinterpret_cast<const f32x4*>(dlS + qi);
                         if (diag) {                                            // masked pair: score finfo.min -> P = 0, dS = 0
 #pragma unroll
                             for (int e = 0; e < 4; ++e) x[qq][4 * j + e] = ((q0h + qq) * 32 + 8 * j + e < thr) ? FINFO_MIN : a4[e];
@@ -796,14 +797,15 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && (HD == 64 || MODE != 0)) ? 2 :
                 for (int j = 0; j < 4; ++j) {
                     const int qi = t * 64 + (q0h + qq) * 32 + 8 * j + 4 * hi;
                     const f32x4 mm = *reinterpret_cast<const f32x4*>(m2S + qi);
-                    const f32x4 il4 = *reinterpret_cast<const f32x4*>(ilS + qi);
-                    const f32x4 dl4 = *reinterpret_cast<const f32x4*>(dlS + qi);
+                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(slG + qi);
+                    f32x4 dl4 = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (DO_DK) dl4 = *reinterpret_cast<const f32x4*>(dlS + qi);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int r = 4 * j + e;
                         const bool msk = ((q0h + qq) * 32 + 8 * j + e) < thr;
                         const float s2 = msk ? lane_fill : __builtin_fmaf(x[qq][r], c, kb_lane);
-                        const float pr = __builtin_amdgcn_exp2f(s2 - mm[e]) * il4[e];
+                        const float pr = __builtin_amdgcn_exp2f(s2 - mm[e]) * (1.0f / l4[e]);
                         const float d = msk ? 0.f : pr * (y[qq][r] - dl4[e]);
                         x[qq][r] = pr;
                         y[qq][r] = d;
@@ -862,7 +864,12 @@ void launch32(K kern, int64_t grid, int threads, size_t lds, hipStream_t st, con
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, st, p);
 }
 template <int HD, int NW> size_t lds_kv(const AttnP& p, int nst = 3) { return nst * (size_t)(2 * WT<HD, NW>::TILE) + 4 * (size_t)p.Sk; }
-template <int HD, int NW> size_t lds_qg(const AttnP& p, int nst = 3) { return nst * (size_t)(2 * WT<HD, NW>::TILE) + 12 * (size_t)p.Sq; }
+// the key-owned kernel keeps per-query statistics of the whole sequence in LDS: the score offset and delta, 8 bytes per query (4 in the
+// dV pass, which has no dS); the exact path of left-padded batch rows reads l from L2.  At head_dim 128, S = 2048 that is 64 + 16 KiB:
+// two workgroups per CU (with 1/l staged too it was 88 KiB: one, and the kernel ran at one wave per SIMD whatever its register count).
+template <int HD, int NW> size_t lds_qg(const AttnP& p, int nst = 3, int mode = 0) {
+    return nst * (size_t)(2 * WT<HD, NW>::TILE) + (mode == 1 ? 4 : 8) * (size_t)p.Sq;
+}
 
 }  // namespace
 
@@ -897,8 +904,11 @@ int ctmi_attn32_fwd(const AttnP& p, hipStream_t st, int f16) {
 }
 
 int ctmi_attn32_bwd(const AttnP& p, hipStream_t st, int f16) {
-    // head_dim 128: the 32-row accumulators of the backward (dK^T and dV^T: 128 registers) leave one wave per SIMD, and the general
-    // 16-row kernels are faster there (B=4 S=2048 nh=32: 797 vs 915 us; after the instruction diet 812 vs 899) — only the forward takes this path at head_dim 128
+    // head_dim 128: dK^T and dV^T together are 128 accumulator registers, which leaves one wave per SIMD (256 VGPRs + 230 AGPRs used as
+    // spill space; round 4: 915 us against the general kernels' 797 at B=4 S=2048 nh=32). Round 5 splits the key-owned kernel in two
+    // passes (MODE 1: dV, MODE 2: dK) that each fit two waves per SIMD; the price is one more score recompute (8 matmul units against the
+    // general kernels' 7; the algorithm has 5). Measured per kernel, same shape: dQ 228 us (904 TF/s executed), dV 237, dK 323 —
+    // 775-788 us together against 797 (profiles/r05_attention_paths.txt).
     if (!w32_ok(p) || !(w32_mask() & 2)) return 0;
     const int64_t BH = p.B * p.nh;
     // dQ first: it also publishes delta = rowsum(dO * O) for the dK/dV kernel (same stream: ordered)
@@ -907,11 +917,11 @@ int ctmi_attn32_bwd(const AttnP& p, hipStream_t st, int f16) {
         const int64_t gq = ((p.Sq + RPB - 1) / RPB) * BH, gk = ((p.Sk + RPB - 1) / RPB) * BH;
         if (f16) {
             launch32(&attn32_dq_kernel<128, NW, true>, gq, 64 * NW, lds_kv<128, NW>(p, NST), st, p);
-            launch32(&attn32_dkdv_kernel<128, NW, true, 1>, gk, 64 * NW, lds_qg<128, NW>(p, NST), st, p);
+            launch32(&attn32_dkdv_kernel<128, NW, true, 1>, gk, 64 * NW, lds_qg<128, NW>(p, NST, 1), st, p);
             launch32(&attn32_dkdv_kernel<128, NW, true, 2>, gk, 64 * NW, lds_qg<128, NW>(p, NST), st, p);
         } else {
             launch32(&attn32_dq_kernel<128, NW, false>, gq, 64 * NW, lds_kv<128, NW>(p, NST), st, p);
-            launch32(&attn32_dkdv_kernel<128, NW, false, 1>, gk, 64 * NW, lds_qg<128, NW>(p, NST), st, p);
+            launch32(&attn32_dkdv_kernel<128, NW, false, 1>, gk, 64 * NW, lds_qg<128, NW>(p, NST, 1), st, p);
             launch32(&attn32_dkdv_kernel<128, NW, false, 2>, gk, 64 * NW, lds_qg<128, NW>(p, NST), st, p);
         }
         return 1;
