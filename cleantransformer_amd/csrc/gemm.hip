@@ -1281,7 +1281,14 @@ static void glds_launch(GemmArgs& g, hipStream_t st) {
     const int reserve = reserved_cus();
     const int64_t per_cu = (int64_t)std::min<size_t>((size_t)(WGN == 4 ? 1 : 8), (160 * 1024) / lds);
     const int64_t slots = (256 - reserve) / 8 * 8 * per_cu;                  // multiple of 8: the XCD-aware item order needs it
-    const unsigned grid = (unsigned)((persist && nwork > slots) ? slots : nwork);
+    // Long tiles are launched one workgroup per tile even under the persistent policy: the prefetch across tile boundaries is worth ~2 us per
+    // tile, nothing against a 256-K-step tile, and workgroups that the dispatcher starts in order stay closer together than persistent ones
+    // that drift over 15 tiles each — the four column tiles that share a dlogits panel of the LM-head weight gradient then find it in their
+    // XCD's L2: FETCH 13.2 -> 8.6 GB per launch, 3.47 -> 3.45 ms (profiles/r05_lmhead_wgrad_launch.txt).  CTMI_GEMM_PERSIST_KSTEPS overrides (0: no limit).
+    static int persist_ksteps = -1;
+    if (persist_ksteps < 0) { const char* e = getenv("CTMI_GEMM_PERSIST_KSTEPS"); persist_ksteps = e ? atoi(e) : 128; }
+    const bool long_tiles = persist_ksteps > 0 && g.k_per_split / 32 > persist_ksteps;
+    const unsigned grid = (unsigned)((persist && !long_tiles && nwork > slots) ? slots : nwork);
     if constexpr (std::is_same<TE, f16_t>::value) {
         auto kern = &gemm_glds_kernel_f16<TO, AK, BKM, EPI, WM, WGN, PP, RES, XLANE>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
