@@ -9,7 +9,8 @@ from cleantransformer_amd import ops
 from tools.microbench import timeit, rnd
 
 T = 8192
-for N in ((250880,) if os.environ.get('KS_LM') else (250880, 4096)):
+NS = tuple(int(v) for v in os.environ['KS_N'].split(',')) if os.environ.get('KS_N') else ((250880,) if os.environ.get('KS_LM') else (250880, 4096))
+for N in NS:
     pts = []
     for K in ((1024, 4096) if os.environ.get('KS_LM') else (256, 512, 1024, 2048, 4096)):
         x, w = rnd(T, K), rnd(N, K)
