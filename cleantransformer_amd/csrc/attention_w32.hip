@@ -626,8 +626,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? (HD == 64 ? 3 : 2) : NW / 4) voi
 // probability (non-zero only in all-masked rows, which are uniform), dS = 0.
 // MODE (round 5, head_dim 128): 0 = dK and dV in one pass (head_dim 64: 254 registers, two waves per SIMD); 1 = dV only, 2 = dK only — at head_dim 128
 // the two 32-row accumulators (128 registers) plus the K and V fragments (64) left ONE wave per SIMD and the general 16-row kernels were faster
-// (797 vs 915 us at B=4 S=2048 nh=32); split, the dV pass needs no V fragments, no dP and no delta, the dK pass no dV accumulator, both keep two
-// waves per SIMD, and the scores are recomputed once more (the kernel is bound by vector issue and occupancy, not by its matrix work).
+// (797 vs 915 us at B=4 S=2048 nh=32); split, the dV pass needs no V fragments, no dP and no delta, the dK pass no dV accumulator, both fit two
+// waves per SIMD in registers — and in LDS, which was the second limit: see lds_qg() — and the scores are recomputed once more (the kernel is
+// bound by vector issue and occupancy, not by its matrix work): 653 us.
 template <int HD, int NW, bool F16 = false, int MODE = 0>
 __global__ __launch_bounds__(NW * 64, (NW == 4 && (HD == 64 || MODE != 0)) ? 2 : NW / 4) void attn32_dkdv_kernel(AttnP p) {
     constexpr bool DO_DV = MODE != 2, DO_DK = MODE != 1;
