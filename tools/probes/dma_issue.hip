@@ -26,11 +26,11 @@ __global__ __launch_bounds__(512, 2) void k(const unsigned char* __restrict__ sr
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds0 = (unsigned)(size_t)lds + wid * (PIECES * 4 * 1024);                 // 4 ring slots of PIECES KiB per wave
-    const size_t window = SRC == 0 ? 32768 : (size_t)2 << 20;
+    const size_t window = SRC == 0 ? 32768 : (SRC == 3 ? 65536 : (size_t)2 << 20);       // SRC 3 (round 5): the half-line pieces of SRC 2, re-read hot (L2 hits)
     const unsigned char* base = src + (size_t)blockIdx.x * ((size_t)2 << 20);
     // lane -> source bytes of a piece: SRC 2: 16 rows x 64 B out of 128-byte-pitch rows (half lines); else 1 KiB contiguous
-    const unsigned lane_off = SRC == 2 ? (unsigned)((lane >> 2) * 128 + (lane & 3) * 16) : (unsigned)lane * 16;
-    const unsigned piece_bytes = SRC == 2 ? 2048 : 1024;
+    const unsigned lane_off = (SRC == 2 || SRC == 3) ? (unsigned)((lane >> 2) * 128 + (lane & 3) * 16) : (unsigned)lane * 16;
+    const unsigned piece_bytes = (SRC == 2 || SRC == 3) ? 2048 : 1024;
     const unsigned char* pa[PIECES];
     unsigned voff[PIECES];
 #pragma unroll
@@ -117,7 +117,7 @@ template <int FORM, int SRC, int MIX> void run(const unsigned char* src, uint32_
     const double per_piece = dma / nd / (TRIPS * (double)PIECES);
     const int issuing = (MIX == 2 && active > 4) ? 4 : active;
     printf("%-7s src=%-14s mix=%-22s issuing waves %d: %7.1f cycles/piece/wave  = %6.1f B/clk/CU", FORM == 0 ? "global" : "buffer",
-           SRC == 0 ? "hot" : (SRC == 1 ? "stream" : "stream-halfline"), MIX == 0 ? "dma only" : (MIX == 1 ? "12 ds_read + 4 dma" : "same, beside MFMA"),
+           SRC == 0 ? "hot" : (SRC == 1 ? "stream" : (SRC == 2 ? "stream-halfline" : "hot-halfline")), MIX == 0 ? "dma only" : (MIX == 1 ? "12 ds_read + 4 dma" : "same, beside MFMA"),
            issuing, per_piece, 1024.0 * issuing / per_piece);
     if (MIX == 2) printf("   (MFMA partner: %5.1f cycles/MFMA)", mf / nm / (TRIPS * 32.0));
     printf("\n");
@@ -130,6 +130,9 @@ int main() {
     for (int active : {1, 2, 4, 8}) { run<0, 0, 0>(src, cyc, sink, active); run<1, 0, 0>(src, cyc, sink, active); }
     for (int active : {4, 8}) { run<0, 1, 0>(src, cyc, sink, active); run<1, 1, 0>(src, cyc, sink, active); run<0, 2, 0>(src, cyc, sink, active); run<1, 2, 0>(src, cyc, sink, active); }
     for (int active : {4, 8}) { run<0, 0, 1>(src, cyc, sink, active); run<1, 0, 1>(src, cyc, sink, active); run<0, 2, 1>(src, cyc, sink, active); run<1, 2, 1>(src, cyc, sink, active); }
+    for (int active : {1, 2, 4, 8}) run<0, 3, 0>(src, cyc, sink, active);                    // round 5: hot half-line pieces
+    for (int active : {4, 8}) run<0, 3, 1>(src, cyc, sink, active);
+    run<0, 3, 2>(src, cyc, sink, 4);
     run<0, 0, 2>(src, cyc, sink, 4); run<1, 0, 2>(src, cyc, sink, 4); run<0, 2, 2>(src, cyc, sink, 4); run<1, 2, 2>(src, cyc, sink, 4);
     return 0;
 }
