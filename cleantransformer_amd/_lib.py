@@ -20,7 +20,7 @@ OPT_SHADOW_F16 = 2                    # OR-ed into the mutate_grad / first_step 
 EPI_NONE, EPI_GELU, EPI_DGELU, EPI_RELU, EPI_DRELU, EPI_GELUG, EPI_MUL = 0, 1, 2, 3, 4, 5, 6
 MT_MAX = 24
 PROF_CLASSES = ("gemm_fwd", "gemm_dgrad", "gemm_wgrad", "lm_head", "attn_fwd", "attn_bwd", "layernorm", "loss", "optimizer", "reduce", "other")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 
@@ -124,6 +124,7 @@ PROTOTYPES = {
     "ctmi_scores_filter": (i32, [vp, i64, f32, vp, i64, f32, vp, i64, i64, i64, vp]),
     "ctmi_probe": (i32, [i32, vp, vp, vp]),
     "ctmi_clock_probe": (i32, [i32, vp, vp]),
+    "ctmi_probe_dyn_lds": (i32, [i64, vp, vp]),
     "ctmi_profile_begin": (i32, []),
     "ctmi_profile_end": (i32, [C.POINTER(f32), C.POINTER(i32)]),
 }

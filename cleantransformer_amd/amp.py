@@ -68,17 +68,28 @@ class GradScaler():
         self._init_scale, self._growth, self._backoff, self._interval = float(init_scale), growth_factor, backoff_factor, int(growth_interval)
         self._state = None                                   # device float[3]: scale, growth tracker, found_inf (lazily placed)
         self._unscaled = set()                                # ids of optimizers already unscaled this step
+        if enabled and torch.cuda.is_available():
+            # register the device scale NOW, not at the first scale(): the first forward of a new scaler already folds it into dlogits —
+            # in fp16 that is a matter of correctness, not only of a saved pass (an unscaled half dlogits underflows; round-5 advisor)
+            self._ensure(torch.device("cuda", torch.cuda.current_device()))
 
     # ------------------------------------------------------------------------------------------------ state
     def _ensure(self, device):
+        device = torch.device(device)
         if self._state is None:
-            self._state = torch.tensor([self._init_scale, 0.0, 0.0], dtype=torch.float32, device=device)
-            if self._state.is_cuda:
-                # from the next forward on, the fused loss folds this scale into dlogits (ops.set_expected_loss_grad): the backward of
-                # scaler.scale(loss) then finds its upstream gradient already applied and skips the rescale pass over [T,V]
-                from . import ops
-                ops.set_expected_loss_grad(scale=self._state[0:1], owner=self)
+            self._place(torch.tensor([self._init_scale, 0.0, 0.0], dtype=torch.float32, device=device))
+        elif device.type == "cuda" and self._state.is_cuda and device.index is not None and self._state.device != device:
+            # constructed (eagerly) on another GPU than the one the loss lives on: the state follows the loss and registers again
+            self._place(self._state.to(device))
         return self._state
+
+    def _place(self, state):
+        self._state = state
+        if state.is_cuda:
+            # from the next forward on, the fused loss folds this scale into dlogits (ops.set_expected_loss_grad): the backward of
+            # scaler.scale(loss) then finds its upstream gradient already applied and skips the rescale pass over [T,V]
+            from . import ops
+            ops.set_expected_loss_grad(scale=state[0:1], owner=self)
 
     def is_enabled(self):
         return self._enabled

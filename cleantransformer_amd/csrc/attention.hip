@@ -957,7 +957,7 @@ static int fill_params(AttnP& p, const ctmi_attn_desc* d, int dtype, const char*
 
 template <typename K>
 static void launch_k(K kern, int64_t grid, size_t lds, hipStream_t st, AttnP& p) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    ctmi_dyn_lds(reinterpret_cast<const void*>(kern), lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, p);
 }
 

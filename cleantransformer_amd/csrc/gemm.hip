@@ -1291,11 +1291,11 @@ static void glds_launch(GemmArgs& g, hipStream_t st) {
     const unsigned grid = (unsigned)((persist && !long_tiles && nwork > slots) ? slots : nwork);
     if constexpr (std::is_same<TE, f16_t>::value) {
         auto kern = &gemm_glds_kernel_f16<TO, AK, BKM, EPI, WM, WGN, PP, RES, XLANE>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        ctmi_dyn_lds(reinterpret_cast<const void*>(kern), lds);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * WGN), lds, st, g);
     } else {
         auto kern = &gemm_glds_kernel<TO, AK, BKM, EPI, WM, WGN, PP, RES, XLANE>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        ctmi_dyn_lds(reinterpret_cast<const void*>(kern), lds);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * WGN), lds, st, g);
     }
 }
@@ -1486,11 +1486,11 @@ static int gemm_launch(GemmArgs& g, bool fast, hipStream_t st) {
     }
     if (fast) {
         auto kern = &gemm_kernel<T, TO, AK, BKM, EPI, true>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        ctmi_dyn_lds(reinterpret_cast<const void*>(kern), lds);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, g);
     } else {
         auto kern = &gemm_kernel<T, TO, AK, BKM, EPI, false>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        ctmi_dyn_lds(reinterpret_cast<const void*>(kern), lds);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, g);
     }
     CTMI_CHECK_LAUNCH("gemm");
@@ -1697,7 +1697,7 @@ extern "C" int ctmi_wgrad_grouped(const ctmi_wgrad_problem* pr, int n, int64_t T
     constexpr size_t lds = 6 * (size_t)(GTile<true, 128>::BYTES + GTile<true, 256>::BYTES);
     const unsigned grid = (unsigned)((persist && tab.nitems > slots) ? slots : tab.nitems);
     auto kern = dtype == CTMI_F16 ? &gemm_wgrad_grouped_kernel_f16 : &gemm_wgrad_grouped_kernel;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    ctmi_dyn_lds(reinterpret_cast<const void*>(kern), lds);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, g);
     CTMI_CHECK_LAUNCH("wgrad_grouped");
     if (tab.nsplit) {

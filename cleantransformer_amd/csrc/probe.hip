@@ -66,3 +66,19 @@ extern "C" int ctmi_probe(int which, const float* in, float* out, void* stream) 
     CTMI_CHECK_LAUNCH("probe");
     return CTMI_OK;
 }
+
+// Dynamic-LDS opt-in probe (tests only): asks for `bytes` of dynamic LDS for a trivial kernel through the same ctmi_dyn_lds every product launch
+// uses, and launches it.  A request beyond the CU's 160 KiB must come back as CTMI_ERR_LAUNCH with the attribute call's message — not be dropped.
+__global__ void dyn_lds_probe_kernel(unsigned* __restrict__ out) {
+    extern __shared__ unsigned dyn_lds_probe_smem[];
+    dyn_lds_probe_smem[threadIdx.x] = threadIdx.x;
+    __syncthreads();
+    if (threadIdx.x == 0 && out) out[0] = dyn_lds_probe_smem[63];
+}
+extern "C" int ctmi_probe_dyn_lds(int64_t bytes, unsigned* out, void* stream) {
+    CTMI_REQUIRE(bytes >= 256, "probe_dyn_lds: at least 256 bytes");
+    ctmi_dyn_lds(reinterpret_cast<const void*>(&dyn_lds_probe_kernel), (size_t)bytes);
+    hipLaunchKernelGGL(dyn_lds_probe_kernel, dim3(1), dim3(64), (size_t)bytes, as_stream(stream), out);
+    CTMI_CHECK_LAUNCH("probe_dyn_lds");
+    return CTMI_OK;
+}

@@ -402,11 +402,17 @@ class ShiftedCrossEntropyFn(torch.autograd.Function):
         lab = lab if lab.is_contiguous() else lab.contiguous()
         ctx.shape = (B, S, V)
         ctx.fused = bool(_FUSED_CE and ctx.needs_input_grad[0] and ops.ce_fused_ok(l2))
+        fac, fdev = ops.current_expected_loss_grad()
+        if fdev is not None and fdev.device != l2.device:
+            fdev = None
+        if ctx.fused and l2.dtype == torch.float16 and fdev is None:
+            # IEEE half cannot hold an UNSCALED dlogits: (p - y) / N at V = 250 880, T = 8192 is ~5e-10, below the smallest half subnormal,
+            # and a scale that arrives only in backward would multiply zeros.  Without a registered device scale (a torch.amp.GradScaler,
+            # or no scaler at all) the two-pass form is used: its backward receives the real upstream gradient in fp32 and applies it
+            # BEFORE the half cast, as the reference's fp32 CE under autocast does (round-5 advisor).
+            ctx.fused = False
         if ctx.fused:
             # the upstream gradient the loop announced (1 / accumulation steps, a GradScaler's device scale; 1 otherwise) rides in this pass
-            fac, fdev = ops.current_expected_loss_grad()
-            if fdev is not None and fdev.device != l2.device:
-                fdev = None
             if fdev is not None:
                 # a private snapshot: the node compares the gradient that arrives in backward with what THIS forward folded, also when the
                 # scaler's live scale has moved in between (update() / load_state_dict() between forward and backward; round-4 advisor)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CTMI_ABI_VERSION 14
+#define CTMI_ABI_VERSION 15
 
 enum ctmi_dtype { CTMI_F32 = 0, CTMI_BF16 = 1, CTMI_F16 = 2 };
 /* CTMI_F16 (ABI v14): IEEE half storage with fp32 accumulation and statistics — torch.autocast(dtype=float16) of examples/ft_bloom_DDP.py:107-128.
@@ -380,6 +380,9 @@ int ctmi_probe(int which, const float* in /* device */, float* out /* device, 25
  * workgroup 0 writes out[0] = elapsed shader cycles (s_memtime), out[1] = elapsed ticks of the constant 100 MHz counter (s_memrealtime):
  * shader clock under matrix load = 100 MHz * out[0] / out[1].  bench.py launches it right before and right after the timed region. */
 int ctmi_clock_probe(int mfma_iters, unsigned long long* out /* device, 2 x u64 */, void* stream);
+/* dynamic-LDS opt-in probe (tests only; no reference counterpart): requests `bytes` of dynamic LDS for a trivial kernel through the helper every
+ * product launch uses (hipFuncSetAttribute, return CHECKED) and launches it; a request beyond the 160 KiB of a CU returns CTMI_ERR_LAUNCH. */
+int ctmi_probe_dyn_lds(int64_t bytes, unsigned* out /* device, 1 x u32, may be NULL */, void* stream);
 
 #ifdef __cplusplus
 }

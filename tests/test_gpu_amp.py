@@ -275,3 +275,61 @@ def test_fp16_c1_config_trajectory_tracks_the_reference():
         assert abs(float(loss) - doc["traj"][t][0]) <= 3e-3 * doc["traj"][t][0], (t, float(loss), doc["traj"][t])
         assert abs(gn - doc["traj"][t][1]) <= 3e-2 * doc["traj"][t][1], (t, gn, doc["traj"][t])
     assert scaler.get_scale() == 65536.0
+
+
+@pytest.mark.parametrize("who", ["none", "ours_first_step", "torch_scaler"])
+def test_fp16_dlogits_at_full_vocabulary_do_not_underflow_before_the_scale(who):
+    """Round-5 advisor: at V = 250 880 the softmax part of dlogits, p / N, is ~5e-10 — below the smallest half subnormal (6e-8).  Whatever
+    scaler drives the loop, and on its FIRST step too, the 2^16 loss scale must reach dlogits in fp32 BEFORE the half cast (as the reference's
+    fp32 CE under autocast does): (a) no registered device scale (plain backward of a pre-scaled loss / torch.amp.GradScaler) -> the
+    two-pass loss; (b) this package's GradScaler registers its scale at construction -> the fused one-pass loss already folds it."""
+    import gc
+    from cleantransformer_amd import ops
+    from cleantransformer_amd.amp import GradScaler
+    from cleantransformer_amd.models.modeling_bloom import ShiftedCrossEntropyFn
+    gc.collect()
+    ops.set_expected_loss_grad(factor=1.0, scale=False)
+    g = torch.Generator().manual_seed(11)
+    B, S, V = 2, 256, 250880
+    logits = (torch.randn(B, S, V, generator=g) * 2.0).to(DEV).to(torch.float16)
+    labels = torch.randint(0, V, (B, S), generator=g).to(DEV)
+    labels[0, 5:9] = -100
+    SCALE = 65536.0
+    lg = logits.clone().requires_grad_(True)
+    sc = None
+    if who == "ours_first_step":
+        sc = GradScaler(init_scale=SCALE)
+        assert ops.current_expected_loss_grad()[1] is not None             # registered before any scale() call
+        loss = ShiftedCrossEntropyFn.apply(lg, labels)
+        sc.scale(loss).backward()
+    elif who == "torch_scaler":
+        sc = torch.amp.GradScaler("cuda", init_scale=SCALE)
+        loss = ShiftedCrossEntropyFn.apply(lg, labels)
+        sc.scale(loss).backward()
+    else:
+        loss = ShiftedCrossEntropyFn.apply(lg, labels)
+        (loss * SCALE).backward()
+    # fp32 restatement of modeling_bloom.py:224-230 on the same half logits
+    x = logits[:, :-1].float().reshape(-1, V)
+    y = labels[:, 1:].reshape(-1)
+    keep = y != -100
+    lse = torch.logsumexp(x, dim=-1, keepdim=True)
+    n = int(keep.sum())
+    got = lg.grad[:, :-1].reshape(-1, V)
+    assert torch.all(lg.grad[:, -1] == 0)
+    rows = torch.arange(0, x.shape[0], 37, device=DEV)                      # a sample of rows, every column
+    ref = torch.exp(x[rows] - lse[rows]) * (SCALE / n)
+    ref[torch.arange(len(rows), device=DEV), y[rows].clamp(min=0)] -= SCALE / n
+    ref = ref * keep[rows].unsqueeze(1)
+    refh = ref.to(torch.float16).float()
+    gh = got[rows].float()
+    # the softmax terms survive: most of a kept row is non-zero, and the values are the fp32 gradient rounded once to half
+    kept_rows = keep[rows]
+    assert float((gh[kept_rows] != 0).float().mean()) > 0.5, "dlogits flushed to zero: the loss scale arrived after the half cast"
+    err = (gh - refh).abs().max()
+    tol = 2.0 ** -9 * float(ref.abs().max()) + 2.0 ** -24                  # one half rounding (+ a subnormal step)
+    assert float(err) <= tol, (float(err), tol)
+    assert abs(float(loss) - float((lse.squeeze(1) - x.gather(1, y.clamp(min=0).unsqueeze(1)).squeeze(1))[keep].mean())) < 1e-3
+    del sc
+    gc.collect()
+    ops.set_expected_loss_grad(factor=1.0, scale=False)
