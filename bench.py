@@ -297,13 +297,13 @@ def main(argv=None):
             os.environ["CTMI_DDP_BACKEND"] = backend
             os.environ["CTMI_DDP_LAUNCH_POLICY"] = policy
             return DDP(model, device_ids=[local_rank], comm_dtype=comm_dtype)
-        chosen = (args.ddp_backend, os.environ.get("CTMI_DDP_LAUNCH_POLICY", "shared"))
+        chosen = (args.ddp_backend, os.environ.get("CTMI_DDP_LAUNCH_POLICY", "flow"))
         if not args.no_comm_probe:
             comm_candidates = []
             # (round 5) the library's own RCCL communicator is only probed on request (--probe-rccl): it has never run at world > 1, and a
             # candidate that HANGS takes the whole measurement with it; torch.distributed's RCCL backend x the two launch policies is the default
             for backend in (("torch", "rccl") if args.probe_rccl else ("torch",)):
-                for policy in ("shared", "reserve", "persistent"):
+                for policy in ("flow", "shared", "reserve", "persistent"):
                     rec = {"ddp_backend": backend, "launch_policy": policy}
                     # phase 1: wrap.  Every rank reports whether ITS wrapper exists before any rank enters the wrapper's collectives — a
                     # candidate that cannot be built on one rank (no librccl there, a communicator error) is skipped by all (round-4 advisor)
@@ -422,6 +422,28 @@ def main(argv=None):
     mean_ms = dt / args.steps * 1e3
     tokens_per_s = world * B * S / (med_ms * 1e-3)                       # median of the timed steps (max over ranks)
 
+    # ---- world > 1: what the collectives cost that backward could not hide.  The same wrapped model under the same launch policy runs
+    # `steps` more steps with every gradient collective SKIPPED (DistributedDataParallel.stub_collectives: bucket copies, pre-division, the
+    # chunked tied-table gradient and its row scatter still run): exposed_ms = step with collectives - step without.  After the timed
+    # region and after the loss check — those steps train on unaveraged gradients.
+    comm_exposed = None
+    if world > 1 and isinstance(holder["net"], DDP):
+        holder["net"].stub_collectives = True
+        try:
+            for _ in range(2):
+                step()
+            _, st_ms, _, _ = timed_steps(max(5, args.steps))
+        finally:
+            holder["net"].stub_collectives = False
+        sm = sorted(st_ms)[len(st_ms) // 2]
+        ts_ = torch.tensor([sm], dtype=torch.float64, device=device)
+        dist.all_reduce(ts_, op=dist.ReduceOp.MAX)
+        sm = float(ts_[0])
+        comm_exposed = {"exposed_ms": round(med_ms - sm, 3), "compute_only_ms_per_step": round(sm, 3), "steps": len(st_ms),
+                        "ranks": world, "backend": dist.get_backend(),
+                        "note": "compute_only = the same wrapped model and launch policy with every gradient collective skipped "
+                                "(median, max over ranks); exposed = ms_per_step - compute_only"}
+
     # ---- per-class device time of one step (HIP-event brackets inside the library; side stream off so that brackets do not overlap)
     breakdown = None
     if not args.no_breakdown:
@@ -474,8 +496,10 @@ def main(argv=None):
                        "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}",
                        "comm_dtype": args.comm_dtype if world > 1 else None,
                        "comm": None if world == 1 else {"nccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS"),
-                                                        "launch_policy": os.environ.get("CTMI_DDP_LAUNCH_POLICY", "shared"),
+                                                        "launch_policy": os.environ.get("CTMI_DDP_LAUNCH_POLICY", "flow"),
                                                         "ddp_backend": args.ddp_backend, "candidates": comm_candidates,
+                                                        "ranks": world, "exposed_ms": None if comm_exposed is None else comm_exposed["exposed_ms"],
+                                                        "exposed": comm_exposed,
                                                         "tied_chunk_mb": os.environ.get("CTMI_DDP_TIED_CHUNK_MB", "64")},
                        "padded_sample": padded},
             "timing": {"value_from": "median of the per-step HIP-event times of the timed steps (max over ranks)",

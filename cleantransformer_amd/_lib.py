@@ -16,6 +16,7 @@ from ._build import LIB_PATH as _DEFAULT_LIB_PATH
 LIB_PATH = os.environ.get("CTMI_LIB_PATH") or _DEFAULT_LIB_PATH
 
 F32, BF16, F16 = 0, 1, 2
+OPT_LEGACY_GRID = 4                   # OR-ed into mutate_grad of ctmi_adamw_step: the (stride loop, tensor) grid of ABI <= 14
 OPT_SHADOW_F16 = 2                    # OR-ed into the mutate_grad / first_step argument of the fused optimizers: the shadows are IEEE half
 EPI_NONE, EPI_GELU, EPI_DGELU, EPI_RELU, EPI_DRELU, EPI_GELUG, EPI_MUL = 0, 1, 2, 3, 4, 5, 6
 MT_MAX = 24

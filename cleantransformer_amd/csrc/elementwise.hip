@@ -1365,6 +1365,9 @@ struct MTPack {
 struct AdamHyper { float lr, b1, b2, eps, wd, bc1, bc2, sqrt_bc2, gscale; int decoupled, mutate_grad, shadow_f16; };
 
 __device__ __forceinline__ void adam_one(float& p, float& g, float& m, float& v, const AdamHyper& h) {
+    // no FMA contraction: every launch form, and the vector and scalar paths of one launch, round every product and sum the same way — the
+    // update of an element does not depend on which kernel (or which lane of it) happened to process it
+#pragma clang fp contract(off)
     g *= h.gscale;
     if (h.decoupled) { p *= (1.0f - h.lr * h.wd); } else { g += h.wd * p; }
     m = h.b1 * m + (1.0f - h.b1) * g;
@@ -1401,6 +1404,79 @@ __global__ __launch_bounds__(256) void adamw_mt_k(MTPack pk, AdamHyper h) {
     }
 }
 
+// Chunk-balanced form (round 6): up to CTMI_MT_FLAT tensors per launch, a 1-D grid of one 16 Ki-element chunk per workgroup (64 KiB of every
+// fp32 stream; 4 x 16-byte loads per stream and thread in flight).  The (x = stride loop, y = tensor) grid above gives every tensor of a pack
+// the workgroups of the LARGEST one — a pack of the 257 M-element tied table and 23 small vectors launches 24 x 2048 workgroups of which 23 x
+// ~2040 exit at once — and the 294 parameters of Bloom-560M took 13 launches; here it is 5, every workgroup with the same amount of work.
+#define CTMI_MT_FLAT 64
+constexpr int ADAM_CHUNK = 16384;                          // elements per workgroup: 256 threads x 4 float4 x 4
+struct MTFlat {
+    float* p[CTMI_MT_FLAT]; float* g[CTMI_MT_FLAT]; float* m[CTMI_MT_FLAT]; float* v[CTMI_MT_FLAT];
+    bf16_t* shadow[CTMI_MT_FLAT];
+    int64_t n[CTMI_MT_FLAT];
+    int first[CTMI_MT_FLAT + 1];                           // first chunk of tensor i in this launch's grid
+    int count;
+};
+__global__ __launch_bounds__(256) void adamw_flat_k(MTFlat pk, AdamHyper h) {
+    // tensor of this chunk: binary search over <= 64 prefix entries (scalar registers: blockIdx is uniform)
+    int lo = 0, hi = pk.count;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)blockIdx.x >= pk.first[mid]) lo = mid; else hi = mid; }
+    const int ti = lo;
+    const int64_t n = pk.n[ti];
+    float* __restrict__ p = pk.p[ti]; float* __restrict__ g = pk.g[ti];
+    float* __restrict__ m = pk.m[ti]; float* __restrict__ v = pk.v[ti];
+    bf16_t* __restrict__ sh = pk.shadow[ti];
+    const int64_t e0 = (int64_t)((int)blockIdx.x - pk.first[ti]) * ADAM_CHUNK;
+    const int64_t e1 = e0 + ADAM_CHUNK < n ? e0 + ADAM_CHUNK : n;
+    const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0) && (sh == nullptr || (((uintptr_t)sh) & 7) == 0);
+    if (vec && e1 - e0 == ADAM_CHUNK) {
+        // full chunk: four passes of 4 float4 per stream and thread, the sixteen loads of a pass issued before its first use
+#pragma unroll 1
+        for (int pass = 0; pass < ADAM_CHUNK / 4096; ++pass) {
+        const int64_t i0 = e0 / 4 + pass * 1024 + threadIdx.x;
+        float4 P[4], G[4], M[4], V[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { P[u] = ldg_stream(p + 4 * (i0 + 256 * u)); G[u] = ldg_stream(g + 4 * (i0 + 256 * u)); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { M[u] = ldg_stream(m + 4 * (i0 + 256 * u)); V[u] = ldg_stream(v + 4 * (i0 + 256 * u)); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = i0 + 256 * u;
+            adam_one(P[u].x, G[u].x, M[u].x, V[u].x, h); adam_one(P[u].y, G[u].y, M[u].y, V[u].y, h);
+            adam_one(P[u].z, G[u].z, M[u].z, V[u].z, h); adam_one(P[u].w, G[u].w, M[u].w, V[u].w, h);
+            stg_stream(p + 4 * i, P[u]); stg_stream(m + 4 * i, M[u]); stg_stream(v + 4 * i, V[u]);
+            if (h.mutate_grad) stg_stream(g + 4 * i, G[u]);
+            if (sh) reinterpret_cast<uint2*>(sh)[i] = h.shadow_f16 ? make_uint2(pack_h2(P[u].x, P[u].y), pack_h2(P[u].z, P[u].w))
+                                                                   : make_uint2(pack_bf2(P[u].x, P[u].y), pack_bf2(P[u].z, P[u].w));
+        }
+        }
+        return;
+    }
+    // last chunk of a tensor / unaligned tensor: the vector part of what is left, then the scalar tail
+    const int64_t nv = vec ? (e1 - e0) / 4 : 0;
+    for (int64_t k = threadIdx.x; k < nv; k += 256) {
+        const int64_t i = e0 / 4 + k;
+        float4 P = ldg_stream(p + 4 * i), G = ldg_stream(g + 4 * i), M = ldg_stream(m + 4 * i), V = ldg_stream(v + 4 * i);
+        adam_one(P.x, G.x, M.x, V.x, h); adam_one(P.y, G.y, M.y, V.y, h);
+        adam_one(P.z, G.z, M.z, V.z, h); adam_one(P.w, G.w, M.w, V.w, h);
+        stg_stream(p + 4 * i, P); stg_stream(m + 4 * i, M); stg_stream(v + 4 * i, V);
+        if (h.mutate_grad) stg_stream(g + 4 * i, G);
+        if (sh) reinterpret_cast<uint2*>(sh)[i] = h.shadow_f16 ? make_uint2(pack_h2(P.x, P.y), pack_h2(P.z, P.w)) : make_uint2(pack_bf2(P.x, P.y), pack_bf2(P.z, P.w));
+    }
+    for (int64_t i = e0 + nv * 4 + threadIdx.x; i < e1; i += 256) {
+        float P = p[i], G = g[i], M = m[i], V = v[i];
+        adam_one(P, G, M, V, h);
+        p[i] = P; m[i] = M; v[i] = V;
+        if (h.mutate_grad) g[i] = G;
+        if (sh) sh[i] = h.shadow_f16 ? f2h(P).v : f2bf(P);
+    }
+}
+static int adamw_form() {                                   // CTMI_ADAMW_FLAT=0: the (stride loop, tensor) grid of rounds 1-5, for A/B runs
+    static int f = -1;
+    if (f < 0) { const char* e = getenv("CTMI_ADAMW_FLAT"); f = e ? atoi(e) : 1; }
+    return f;
+}
+
 static int mt_grid_x(const int64_t* n, int count) {
     int64_t mx = 1;
     for (int i = 0; i < count; ++i) mx = std::max(mx, n[i]);
@@ -1417,8 +1493,36 @@ extern "C" int ctmi_adamw_step(float* const* p, float* const* g, float* const* m
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     h.bc1 = (float)bc1; h.bc2 = (float)bc2; h.sqrt_bc2 = (float)sqrt(bc2);
     h.shadow_f16 = (mutate_grad & CTMI_OPT_SHADOW_F16) ? 1 : 0;
+    const bool legacy_grid = (mutate_grad & CTMI_OPT_LEGACY_GRID) != 0;
     mutate_grad &= 1;
     h.gscale = grad_scale; h.decoupled = decoupled; h.mutate_grad = (mutate_grad && !decoupled && weight_decay != 0.f) || (mutate_grad && grad_scale != 1.0f);
+    if (adamw_form() != 0 && !legacy_grid) {
+        for (int base = 0; base < count; ) {
+            MTFlat pk;
+            int c = 0;
+            int64_t chunks = 0;
+            while (base + c < count && c < CTMI_MT_FLAT) {
+                const int i = base + c;
+                CTMI_REQUIRE(p[i] && g[i] && m[i] && v[i] && n[i] >= 0, "adamw_step: null tensor %d", i);
+                const int64_t ch = cdiv64(n[i], ADAM_CHUNK);
+                if (chunks + ch > (int64_t)0x7fffffff) break;                       // (a launch's grid; never reached below 3.5e13 elements)
+                pk.p[c] = p[i]; pk.g[c] = g[i]; pk.m[c] = m[i]; pk.v[c] = v[i];
+                pk.shadow[c] = shadow ? (bf16_t*)shadow[i] : nullptr; pk.n[c] = n[i];
+                pk.first[c] = (int)chunks;
+                chunks += ch;
+                ++c;
+            }
+            CTMI_REQUIRE(c > 0, "adamw_step: tensor %d is too large for one launch", base);
+            pk.first[c] = (int)chunks; pk.count = c;
+            for (int i = c; i < CTMI_MT_FLAT; ++i) { pk.p[i] = pk.g[i] = pk.m[i] = pk.v[i] = nullptr; pk.shadow[i] = nullptr; pk.n[i] = 0; pk.first[i + 1] = (int)chunks; }
+            if (chunks > 0) {
+                hipLaunchKernelGGL(adamw_flat_k, dim3((unsigned)chunks), dim3(256), 0, as_stream(stream), pk, h);
+                CTMI_CHECK_LAUNCH("adamw_step");
+            }
+            base += c;
+        }
+        return CTMI_OK;
+    }
     for (int base = 0; base < count; base += CTMI_MT_MAX) {
         const int c = std::min(CTMI_MT_MAX, count - base);
         MTPack pk;

@@ -1262,6 +1262,7 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ s
 }
 
 static bool shared_mode();
+static bool shared_tiles();
 static int reserved_cus();
 
 template <typename TE, typename TO, bool AK, bool BKM, int EPI, int WM, int WGN, bool PP = false, bool RES = false, bool XLANE = false>
@@ -1324,11 +1325,17 @@ std::atomic<int> g_ctmi_policy_shared{-1}, g_ctmi_policy_reserve{-1};    // ONE 
 #else
 extern std::atomic<int> g_ctmi_policy_shared, g_ctmi_policy_reserve;
 #endif
-static bool shared_mode() {
+// launch policy: 0 = persistent launches (single GPU), 1 = "shared": one workgroup per tile AND the co-resident free-running tiles of rounds 1-2
+// for the layer GEMMs, 2 = "flow" (round 6): one workgroup per tile, but the SAME tile choice as the persistent policy (the ping-pong tiles) —
+// the dispatcher flows the workgroups over whatever CUs the collectives' workgroups leave free, a tile that cannot start on a CU held by an
+// RCCL channel starts on the next free one
+static int shared_level() {
     int v = g_ctmi_policy_shared.load(std::memory_order_relaxed);
-    if (v < 0) { const char* e = getenv("CTMI_GEMM_SHARED"); v = (e && e[0] != '0') ? 1 : 0; g_ctmi_policy_shared.store(v, std::memory_order_relaxed); }
-    return v == 1;
+    if (v < 0) { const char* e = getenv("CTMI_GEMM_SHARED"); v = e ? std::max(0, std::min(2, atoi(e))) : 0; g_ctmi_policy_shared.store(v, std::memory_order_relaxed); }
+    return v;
 }
+static bool shared_mode() { return shared_level() >= 1; }
+static bool shared_tiles() { return shared_level() == 1; }
 static int reserved_cus() {
     int v = g_ctmi_policy_reserve.load(std::memory_order_relaxed);
     if (v < 0) { const char* e = getenv("CTMI_GEMM_RESERVE_CUS"); v = e ? std::max(0, std::min(128, atoi(e))) : 0; g_ctmi_policy_reserve.store(v, std::memory_order_relaxed); }
@@ -1337,12 +1344,12 @@ static int reserved_cus() {
 #if CTMI_GEMM_HAS(0)
 extern "C" int ctmi_set_launch_policy(int shared, int reserve_cus) {
     CTMI_REQUIRE(reserve_cus >= 0 && reserve_cus <= 128, "set_launch_policy: reserve_cus must be in [0, 128]");
-    g_ctmi_policy_shared.store(shared ? 1 : 0, std::memory_order_relaxed);
+    g_ctmi_policy_shared.store(shared < 0 ? 0 : (shared > 2 ? 2 : shared), std::memory_order_relaxed);
     g_ctmi_policy_reserve.store(reserve_cus, std::memory_order_relaxed);
     return CTMI_OK;
 }
 extern "C" int ctmi_get_launch_policy(int* shared, int* reserve_cus) {
-    if (shared) *shared = shared_mode() ? 1 : 0;
+    if (shared) *shared = shared_level();
     if (reserve_cus) *reserve_cus = reserved_cus();
     return CTMI_OK;
 }
@@ -1378,7 +1385,7 @@ static void pick_tile(int64_t M, int64_t N, int64_t K, bool wgrad, bool bkm, int
     const int64_t t0 = cdiv64(M, 128) * cdiv64(N, 128), t1 = cdiv64(M, 256) * cdiv64(N, 128), t2 = cdiv64(M, 256) * cdiv64(N, 256);
     const int64_t t4 = cdiv64(M, 128) * cdiv64(N, 256);
     tile = 0; splits = 1;
-    if (shared_mode()) {
+    if (shared_tiles()) {
         if (wgrad) {
             if (t1 >= 1024) tile = t2 >= 2048 ? 3 : 1;
             else {

@@ -830,7 +830,7 @@ def set_launch_policy(shared: bool, reserve_cus: Optional[int] = None) -> None:
         r = C.c_int(0)
         lib.ctmi_get_launch_policy(None, C.byref(r))
         reserve_cus = r.value
-    check(lib.ctmi_set_launch_policy(int(bool(shared)), int(reserve_cus)), "set_launch_policy")
+    check(lib.ctmi_set_launch_policy(int(shared), int(reserve_cus)), "set_launch_policy")                    # (True == 1: the round-2 "shared")
 
 
 def profile_begin() -> None:
@@ -917,10 +917,11 @@ class DirectComm:
             pass
 
 
-def get_launch_policy() -> Tuple[bool, int]:
+def get_launch_policy() -> Tuple[int, int]:
+    """(shared level 0 | 1 | 2, reserved CUs) — 0 persistent, 1 shared (co-resident tiles), 2 flow (one workgroup per tile, single-GPU tiles)"""
     sh, r = C.c_int(0), C.c_int(0)
     _lib.load().ctmi_get_launch_policy(C.byref(sh), C.byref(r))
-    return bool(sh.value), r.value
+    return int(sh.value), r.value
 
 
 def invalidate_compute_copies(p: Tensor) -> None:
@@ -998,7 +999,7 @@ def _shadow_flag(shadows) -> int:
 
 
 def adamw_step(params, grads, exp_avg, exp_avg_sq, shadows, *, lr, beta1, beta2, eps, weight_decay, step, decoupled,
-               mutate_grad=False, grad_scale=1.0) -> None:
+               mutate_grad=False, grad_scale=1.0, legacy_grid=False) -> None:
     n = len(params)
     if n == 0:
         return
@@ -1006,7 +1007,8 @@ def adamw_step(params, grads, exp_avg, exp_avg_sq, shadows, *, lr, beta1, beta2,
     sh = _ptr_array(shadows) if shadows is not None else None
     check(_lib.load().ctmi_adamw_step(_ptr_array(params), _ptr_array(grads), _ptr_array(exp_avg), _ptr_array(exp_avg_sq), sh,
                                       sizes, n, float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
-                                      int(decoupled), int(bool(mutate_grad)) | _shadow_flag(shadows), float(grad_scale), _stream()), "adamw_step")
+                                      int(decoupled), int(bool(mutate_grad)) | _shadow_flag(shadows) | (_lib.OPT_LEGACY_GRID if legacy_grid else 0),
+                                      float(grad_scale), _stream()), "adamw_step")
 
 
 def amp_unscale(grads, state: Tensor) -> None:

@@ -81,13 +81,13 @@ class AdamW():
         for i, st in sd["state"].items():
             p = self.params[int(i)]
             self.steps[int(i)] = int(st["step"])
-            self.momentum_buffer[int(i)] = st["exp_avg"].to(device=p.device, dtype=torch.float32).clone()
-            self.rmsp_buffer[int(i)] = st["exp_avg_sq"].to(device=p.device, dtype=torch.float32).clone()
+            self.momentum_buffer[int(i)] = _staggered(p, 1, st["exp_avg"])
+            self.rmsp_buffer[int(i)] = _staggered(p, 2, st["exp_avg_sq"])
 
     def _lazy_state(self, i, p):
         if not torch.is_tensor(self.momentum_buffer[i]):
-            self.momentum_buffer[i] = torch.zeros_like(p, dtype=torch.float32)
-            self.rmsp_buffer[i] = torch.zeros_like(p, dtype=torch.float32)
+            self.momentum_buffer[i] = _staggered(p, 1)
+            self.rmsp_buffer[i] = _staggered(p, 2)
 
     @torch.no_grad()
     def step(self):
@@ -113,6 +113,28 @@ class AdamW():
                 self.steps[i] += 1
                 if hasattr(self.params[i], "_ct_wt"):
                     self.params[i]._ct_wt_stale = True         # transposed compute copy (GPT-2 Conv1D) must be rebuilt
+
+
+_STAGGER_MIN = 1 << 18          # elements: from 1 MiB of fp32 on, a tensor gets its own allocator block(s), aligned to 2 MiB
+
+
+def _staggered(p, slot: int, init=None):
+    """An fp32 state buffer shaped like ``p`` that starts ``slot`` x 4 KiB into its allocation.  torch's caching allocator aligns every large
+    block to 2 MiB, so element i of the parameter, its gradient and both moment buffers would sit at the same offset of four blocks — the same
+    HBM channel and bank, four different rows — and the fused update, which streams the four arrays in lockstep, loses ~10 % of its rate to
+    that (profiles/r06_adamw_placement.txt: 4.9 -> 5.5 TB/s on the 257 M-element tied table; any 2-8 KiB stagger does it)."""
+    n = p.numel()
+    if not p.is_cuda or n < _STAGGER_MIN:
+        t = torch.zeros_like(p, dtype=torch.float32) if init is None else init.to(device=p.device, dtype=torch.float32).clone()
+        return t
+    lead = slot * 1024
+    buf = torch.empty(n + lead, dtype=torch.float32, device=p.device)
+    t = buf[lead:].view(p.shape)
+    if init is None:
+        t.zero_()
+    else:
+        t.copy_(init.to(device=p.device, dtype=torch.float32).view(p.shape))
+    return t
 
 
 class SGD():

@@ -48,6 +48,13 @@ class _DirectWork:
         self.comm.wait()                                            # current stream waits for everything issued on the communicator so far
 
 
+class _NullWork:
+    """stands for a collective that was NOT issued (DistributedDataParallel.stub_collectives: the compute path of a rank timed alone)"""
+
+    def wait(self):
+        return None
+
+
 class _Bucket:
     __slots__ = ("params", "offsets", "numel", "flat", "comm", "pending", "work", "index")
 
@@ -111,7 +118,7 @@ class _TiedGradSync:
         o = self.owner
         self._tmax = None
         self._announced = True
-        if self._single_rank():
+        if self._single_rank() or o.stub_collectives:
             self._tmax = int(n_tokens)                               # single rank: nothing to agree on, no collective
             return
         on_rccl = dist.get_backend(o.process_group) == "nccl" and torch.device(device).type == "cuda"
@@ -195,7 +202,9 @@ class _TiedGradSync:
         collective is enqueued as soon as its GEMM is — communication starts after 1/16 of the weight-gradient work instead
         of after all of it, and no single collective is larger than 64 MiB)."""
         o = self.owner
-        if o._direct is not None and dw.is_cuda:
+        if o.stub_collectives:
+            self.works.append(_NullWork())
+        elif o._direct is not None and dw.is_cuda:
             o._direct.all_reduce(dw)
             self.works.append(_DirectWork(o._direct))
         else:
@@ -225,7 +234,11 @@ class _TiedGradSync:
         drows = drows.view(cap, Hc)
         all_ids = torch.empty((W, cap), dtype=ids.dtype, device=ids.device)
         all_rows = torch.empty((W, cap, Hc), dtype=drows.dtype, device=drows.device)
-        if ids.is_cuda and dist.get_backend(o.process_group) == "gloo":
+        if o.stub_collectives:
+            # timing only: every rank's slot holds the LOCAL rows (the copies and the scatter below cost what they cost with real data)
+            all_ids.copy_(ids.unsqueeze(0).expand(W, cap))
+            all_rows.copy_(drows.unsqueeze(0).expand(W, cap, Hc))
+        elif ids.is_cuda and dist.get_backend(o.process_group) == "gloo":
             # gloo has no device all_gather (several ranks sharing one GPU): stage through the host; RCCL takes the direct path
             hi, hr = ids.cpu(), drows.float().cpu()
             li, lr = [torch.empty_like(hi) for _ in range(W)], [torch.empty_like(hr) for _ in range(W)]
@@ -283,6 +296,11 @@ class DistributedDataParallel(torch.nn.Module):
         if comm_dtype not in (None, torch.float32, torch.bfloat16):
             raise ValueError("comm_dtype must be None / torch.float32 / torch.bfloat16")
         self.comm_dtype = None if comm_dtype == torch.float32 else comm_dtype
+        # Measurement switch (bench.py `comm.exposed_ms`): True = every gradient collective of the step is SKIPPED — bucket copies, pre-division,
+        # wire casts, the tied table's chunked weight gradient and row scatter all still run, under the same launch policy — so that
+        # step(collectives) - step(stubbed) is the communication this rank could not hide.  The gradients are then NOT averaged: never
+        # set while training.
+        self.stub_collectives = False
         if not dist.is_available() or not dist.is_initialized():
             raise RuntimeError("DistributedDataParallel needs torch.distributed.init_process_group(...) first "
                                "(examples/ft_bloom_DDP.py:183 does init_process_group('nccl'), i.e. RCCL on ROCm)")
@@ -344,7 +362,7 @@ class DistributedDataParallel(torch.nn.Module):
         src = dist.get_global_rank(self.process_group, 0) if hasattr(dist, "get_global_rank") else 0
         dist.broadcast_object_list(box, src=src, group=self.process_group)
         cap = int(os.environ.get("CTMI_DDP_MAX_CHANNELS", "0"))
-        if cap <= 0 and os.environ.get("CTMI_DDP_LAUNCH_POLICY", "shared").lower() == "reserve":
+        if cap <= 0 and os.environ.get("CTMI_DDP_LAUNCH_POLICY", "flow").lower() == "reserve":
             cap = max(1, min(128, int(os.environ.get("CTMI_DDP_COMM_CUS", "16"))))
         return ops.DirectComm(box[0], rank, self.world_size, cap)
 
@@ -352,24 +370,29 @@ class DistributedDataParallel(torch.nn.Module):
         """world > 1: the all-reduce kernels will hold CUs under backward — switch the GEMM launcher to a policy that tolerates it
         (ctmi_set_launch_policy; csrc/gemm.hip).  An explicit library call, re-made at every training forward, so it also takes
         effect for a model that already ran GEMMs before it was wrapped.
-          CTMI_DDP_LAUNCH_POLICY = "shared" (default, also "1"): no persistent launches — one workgroup per tile, the hardware
+          CTMI_DDP_LAUNCH_POLICY = "flow" is the default since round 6 (below);
+          "shared" (also "1"; the default of rounds 2-5): no persistent launches — one workgroup per tile, the hardware
               dispatcher flows them over whatever CUs the collectives leave free;
           "reserve": persistent launches on 256 - R CUs, R = CTMI_DDP_COMM_CUS (default 16) — meant to be paired with
               NCCL_MAX_NCHANNELS = R (RCCL runs one workgroup per channel; bench.py exports both before init_process_group, the
               communicator reads the variable when it is created), so the R channels always find a free CU and the GEMMs never wait
               for one they cannot get;
+          "flow" (round 6): one workgroup per tile like "shared", but the ping-pong tiles of the single-GPU policy instead of the co-resident
+              128x128 / 256x128 family — at world 1 it costs a fraction of what "shared" does (profiles/r06_ddp_policy_world1.json);
           "persistent": the single-GPU policy unchanged (persistent launches on all 256 CUs): the fastest when the collectives' workgroups
               co-reside with the GEMMs' or are short — nobody could measure that without a multi-GPU node, so bench.py --gpus N times it too;
           "0": leave the launcher alone."""
-        mode = os.environ.get("CTMI_DDP_LAUNCH_POLICY", "shared").lower()
+        mode = os.environ.get("CTMI_DDP_LAUNCH_POLICY", "flow").lower()
         if self.world_size > 1 and mode != "0" and any(p.is_cuda for p in self.module.parameters()):
             from .. import ops
             if mode == "reserve":
-                want = (False, max(0, min(128, int(os.environ.get("CTMI_DDP_COMM_CUS", "16")))))
+                want = (0, max(0, min(128, int(os.environ.get("CTMI_DDP_COMM_CUS", "16")))))
             elif mode == "persistent":
-                want = (False, 0)                                        # the single-GPU policy (bench.py times it as a third candidate on the node it runs on)
+                want = (0, 0)                                            # the single-GPU policy (bench.py times it as a third candidate on the node it runs on)
+            elif mode == "flow":
+                want = (2, ops.get_launch_policy()[1])                   # one workgroup per tile, the single-GPU tile choice (round 6)
             else:
-                want = (True, ops.get_launch_policy()[1])
+                want = (1, ops.get_launch_policy()[1])
             if ops.get_launch_policy() != want:
                 ops.set_launch_policy(*want)
 
@@ -442,7 +465,9 @@ class DistributedDataParallel(torch.nn.Module):
                 b.comm = torch.empty(b.numel, dtype=self.comm_dtype, device=b.flat.device)
             _cast(b.flat, b.comm)                                   # one pass per bucket; the collective is enqueued behind it
             wire = b.comm
-        if self._direct is not None and wire.is_cuda:
+        if self.stub_collectives:
+            b.work = _NullWork()
+        elif self._direct is not None and wire.is_cuda:
             self._direct.all_reduce(wire)
             b.work = _DirectWork(self._direct)
         else:

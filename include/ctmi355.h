@@ -99,7 +99,9 @@ int ctmi_wgrad_grouped(const ctmi_wgrad_problem* problems /* host */, int count,
 /* GEMM launch policy (process-wide).  shared = 0: the GPU is ours — persistent launches sized to the 256 CUs, one-workgroup-
  * per-CU ping-pong tiles.  shared = 1: another long-running kernel holds CUs under our GEMMs (the RCCL all-reduce of a
  * data-parallel job, trainer DDP at examples/ft_bloom_DDP.py:99): no persistent launches, 2-3 workgroups per CU for the
- * layer GEMMs.  reserve_cus: CUs left out of persistent launches.  Initial values: CTMI_GEMM_SHARED / CTMI_GEMM_RESERVE_CUS. */
+ * layer GEMMs.  shared = 2 ("flow", ABI v15): one workgroup per tile like 1, but the tile choice of shared = 0 (the ping-pong tiles) — the
+ * dispatcher flows the workgroups over the CUs the collectives leave free; costs +0.x ms per step at world 1 where shared = 1 costs +2.8
+ * (profiles/r06_ddp_policy_world1.json).  reserve_cus: CUs left out of persistent launches.  Initial values: CTMI_GEMM_SHARED / CTMI_GEMM_RESERVE_CUS. */
 int ctmi_set_launch_policy(int shared, int reserve_cus);
 int ctmi_get_launch_policy(int* shared /* host, may be NULL */, int* reserve_cus /* host, may be NULL */);
 
@@ -265,6 +267,10 @@ uint32_t ctmi_dropout_threshold(float p);
 #define CTMI_MT_MAX 24
 /* (ABI v14) the `shadow` copies are bf16 unless CTMI_OPT_SHADOW_F16 is OR-ed into `mutate_grad` (AdamW) / `first_step` (SGD): IEEE half then */
 #define CTMI_OPT_SHADOW_F16 2
+/* (ABI v15) ctmi_adamw_step launches one workgroup per 16 Ki-element chunk, up to 64 tensors per launch (5 launches for the 294 parameters of
+ * Bloom-560M, every workgroup with equal work); CTMI_OPT_LEGACY_GRID OR-ed into `mutate_grad` takes the (stride loop, tensor) grid of ABI <= 14
+ * (24 tensors per launch) — same arithmetic, bit-identical results (no FMA contraction in either), kept for A/B measurements and the parity test */
+#define CTMI_OPT_LEGACY_GRID 4
 int ctmi_adamw_step(float* const* p /*host*/, float* const* g /*host*/, float* const* m /*host*/, float* const* v /*host*/,
                     void* const* shadow /*host, entries may be NULL*/, const int64_t* n /*host*/, int count,
                     float lr, float beta1, float beta2, float eps, float weight_decay, int step,

@@ -426,3 +426,74 @@ def test_reference_loop_order_and_one_sided_forward():
     mp.spawn(_loop_order_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
     assert ret["early"] == 3 and ret["same"], (ret["early"], ret["same"])
     assert ret["losses"][0] > ret["losses"][1] > ret["losses"][2], ret["losses"]
+
+
+def _stub_worker(rank, world, port, ret):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cpu_kernel_emulation as emu
+    from oracle import bloom_ref as R
+    from cleantransformer_amd.models.modeling_bloom import BloomConfig, BloomForCausalLM
+    from cleantransformer_amd.trainer.ddp import DistributedDataParallel as DDP
+    emu.install(_Patch())
+    V, H, L, nh, B, S = 211, 64, 2, 8, 2, 16
+    m = BloomForCausalLM(BloomConfig(vocab_size=V, hidden_size=H, n_layer=L, num_attention_heads=nh))
+    m._tie_weight()
+    sd = dict(R.det_init(R.BloomShape(V, H, L, nh)))
+    sd["lm_head.weight"] = sd["bloom.word_embeddings.weight"]
+    m.load_state_dict(sd)
+    m._tie_weight()
+    ddp = DDP(m, device_ids=None, bucket_cap_mb=0.05)
+    ids = torch.randint(0, V, (world * B, S), generator=torch.Generator().manual_seed(7))[rank * B:(rank + 1) * B]
+    am = torch.ones(B, S, dtype=torch.long)
+
+    def grads():
+        for p in m.parameters():
+            p.grad = None
+        (loss, _, _), _ = ddp(input_ids=ids, attention_mask=am, labels=ids.clone())
+        loss.backward()
+        return {n: p.grad.clone() for n, p in m.named_parameters()}
+
+    synced = grads()
+    # stubbed: not ONE collective may be issued — every entry point of torch.distributed that moves data raises while the switch is on
+    real = {k: getattr(dist, k) for k in ("all_reduce", "all_gather", "all_gather_into_tensor", "broadcast")}
+
+    def forbidden(*a, **k):
+        raise AssertionError("a collective was issued with stub_collectives = True")
+    ddp.stub_collectives = True
+    for k in real:
+        setattr(dist, k, forbidden)
+    try:
+        stubbed = grads()
+    finally:
+        for k, f in real.items():
+            setattr(dist, k, f)
+        ddp.stub_collectives = False
+    again = grads()
+    ok_same = all(torch.equal(synced[n], again[n]) for n in synced)            # the switch leaves no state behind
+    # a non-tied gradient under the stub is the LOCAL gradient / world (the pre-division rides on the bucket copy, nothing is summed)
+    with ddp.no_sync():
+        local = grads()
+    name = "bloom.blocks.0.mlp.dense_h_to_4h.weight"
+    ok_local = bool(torch.allclose(stubbed[name], local[name] / world, rtol=1e-6, atol=1e-9))
+    differs = not bool(torch.allclose(stubbed[name], synced[name], rtol=1e-3, atol=1e-9))
+    flags = torch.tensor([float(ok_same), float(ok_local), float(differs), float(all(bool(torch.isfinite(g).all()) for g in stubbed.values()))])
+    dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        ret["flags"] = flags.tolist()
+    dist.destroy_process_group()
+
+
+def test_stub_collectives_skips_every_collective_and_leaves_no_state():
+    """bench.py's `comm.exposed_ms` (round 6) = step with collectives - step with DistributedDataParallel.stub_collectives: under the switch a
+    backward issues no collective at all (buckets, the tied table's early reduction, its capacity agreement and row exchange), the bucket
+    gradients are the local ones / world, and the next normal step is bit-identical to the one before."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_stub_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert ret["flags"] == [1.0, 1.0, 1.0, 1.0], ret["flags"]

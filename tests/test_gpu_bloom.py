@@ -871,3 +871,8 @@ def test_bench_two_rank_code_path_executes():
     assert doc["metric"].startswith("PLUMBING RUN") and doc["config"]["parallelism"] == "dp2" and doc["config"]["comm_dtype"] == "bf16"
     assert doc["roofline"]["breakdown_ms_per_step"]["ms"]["gemm_fwd"] > 0 and doc["config"]["padded_sample"]["ms_per_step"] > 0
     assert math.isfinite(doc["final_loss"])
+    # round 6: the collectives' exposed time is part of the line at world > 1 (steps with every gradient collective skipped, same policy)
+    comm = doc["config"]["comm"]
+    assert comm["ranks"] == 2 and comm["exposed"]["compute_only_ms_per_step"] > 0 and comm["exposed"]["backend"] == "gloo"
+    assert abs(comm["exposed_ms"] - (doc["ms_per_step"] - comm["exposed"]["compute_only_ms_per_step"])) < 2e-3
+    assert isinstance(comm["candidates"], list) and len(comm["candidates"]) >= 3

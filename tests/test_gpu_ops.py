@@ -590,6 +590,60 @@ def test_adamw_accepts_generator_and_many_tensors():
         check(f"adamw.many[{i}]", p, ref[i], 1e-5, 1e-7)
 
 
+@pytest.mark.parametrize("decoupled", [True, False], ids=["decoupled", "l2"])
+def test_adamw_chunk_balanced_launch_is_bit_identical_to_the_per_tensor_grid(decoupled):
+    """Round 6: ctmi_adamw_step launches one workgroup per 16 Ki-element chunk, <= 64 tensors per launch (5 launches for Bloom-560M's 294
+    tensors instead of 13).  Same arithmetic as the (stride loop, tensor) grid of rounds 1-5 (CTMI_OPT_LEGACY_GRID), no FMA contraction in
+    either: parameters, both moments, the written-back gradient (L2 form) and the bf16 operand copies must agree BIT FOR BIT after three steps —
+    on 70 tensors (two launches) that mix sizes below / at / above a chunk, sizes that are not a multiple of 4, a 4-byte-aligned view (scalar
+    path) and one tensor with the 4 KiB / 8 KiB staggered state placement of optimizer._staggered."""
+    o = ops()
+    from cleantransformer_amd import optimizer as O
+    g = torch.Generator().manual_seed(17)
+    sizes = [1, 3, 4, 7, 1023, 4096, 16384, 16385, 16384 * 2 + 5, 70001, 1 << 18] + [129 + 17 * i for i in range(58)]
+    base = torch.randn(50000, generator=g).to(DEV)
+
+    def make():
+        ps = [torch.randn(n, generator=torch.Generator().manual_seed(100 + i)).to(DEV) for i, n in enumerate(sizes)]
+        ps.append(base.clone()[1:1 + 40003])                                              # 4-byte aligned, not 16: scalar path
+        ms = [torch.zeros_like(x) for x in ps]
+        vs = [torch.zeros_like(x) for x in ps]
+        big = sizes.index(1 << 18)
+        ms[big], vs[big] = O._staggered(ps[big], 1), O._staggered(ps[big], 2)
+        assert ms[big].data_ptr() % (2 << 20) != vs[big].data_ptr() % (2 << 20)
+        sh = [torch.zeros(x.numel(), dtype=torch.bfloat16, device=DEV) if i % 3 else None for i, x in enumerate(ps)]
+        return ps, ms, vs, sh
+
+    out = []
+    for legacy in (False, True):
+        ps, ms, vs, sh = make()
+        gs_all = []
+        for t in range(1, 4):
+            gs = [torch.randn(x.numel(), generator=torch.Generator().manual_seed(1000 * t + i)).to(DEV) for i, x in enumerate(ps)]
+            o.adamw_step(ps, gs, ms, vs, sh, lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, step=t, decoupled=decoupled,
+                         mutate_grad=not decoupled, grad_scale=0.5 if t == 2 else 1.0, legacy_grid=legacy)
+            gs_all.append(gs)
+        torch.cuda.synchronize()
+        out.append((ps, ms, vs, sh, gs_all))
+    a, b = out
+    for i in range(len(a[0])):
+        for k in range(3):
+            assert torch.equal(a[k][i], b[k][i]), (i, "pmv"[k], int(a[k][i].numel()))
+        if a[3][i] is not None:
+            assert torch.equal(a[3][i], b[3][i]), (i, "shadow")
+            assert torch.equal(a[3][i].float(), a[0][i].to(torch.bfloat16).float()), (i, "shadow is the rounded parameter")
+        for t in range(3):
+            assert torch.equal(a[4][t][i], b[4][t][i]), (i, "grad", t)
+    # and against the oracle's update rule (fp64-free restatement of optimizer.py:75-95 / torch.optim.AdamW) on one tensor
+    i = sizes.index(70001)
+    ref_p = torch.randn(70001, generator=torch.Generator().manual_seed(100 + i))
+    m0, v0 = torch.zeros(70001), torch.zeros(70001)
+    for t in range(1, 4):
+        gr = torch.randn(70001, generator=torch.Generator().manual_seed(1000 * t + i)) * (0.5 if t == 2 else 1.0)
+        R.adamw_update(ref_p, gr, m0, v0, t, 1e-2, weight_decay=0.01, decoupled=decoupled)
+    check("adamw.flat.vs_oracle", a[0][i], ref_p, 1e-5, 1e-6)
+
+
 @pytest.mark.parametrize("cd", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 def test_adamw_refreshes_bf16_shadow(cd):
     """the fused optimizers write the operand copy of a weight in the same pass — bf16, or IEEE half (CTMI_OPT_SHADOW_F16, round 5); a parameter
