@@ -231,6 +231,9 @@ def main(argv=None):
     ap.add_argument("--no-power-sampler", action="store_true", help="do not sample rocm-smi power / clocks beside the timed steps")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the per-class HIP-event pass after the timed region")
     ap.add_argument("--no-padded-sample", action="store_true", help="skip the secondary sample with 25 %% of every row right-padded")
+    ap.add_argument("--graph", action="store_true",
+                    help="N = 1: replay the captured step from a hipGraph (cleantransformer_amd/graph.py) instead of issuing it launch by launch; measured "
+                         "equal on the GPU-bound headline shape (profiles/r06_launch_floor.txt), so the default stays the reference's eager loop")
     args = ap.parse_args(argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -242,7 +245,7 @@ def main(argv=None):
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
     if world > 1:
-        os.environ.setdefault("CTMI_GEMM_SHARED", "1")     # RCCL kernels share the CUs under backward
+        os.environ.setdefault("CTMI_GEMM_SHARED", "2")     # RCCL kernels share the CUs under backward (DistributedDataParallel arms its policy itself)
         # RCCL runs one workgroup per channel: bound the CUs the collectives may hold (and, with CTMI_DDP_LAUNCH_POLICY=reserve, keep
         # exactly that many out of the persistent GEMM launches — trainer/ddp.py); read when the communicator is created
         os.environ.setdefault("NCCL_MAX_NCHANNELS", os.environ.get("CTMI_DDP_COMM_CUS", "16"))
@@ -274,7 +277,19 @@ def main(argv=None):
         from cleantransformer_amd.amp import GradScaler
         scaler = GradScaler()
 
+    # --graph (N = 1): the step of the reference loop, captured once and replayed as ONE hipGraph launch per step (cleantransformer_amd/graph.py: the
+    # same ~460 launches in the same order).  A replay removes the HOST side of every launch (6.7 ms of enqueue per step); on this GPU-bound shape the
+    # device-side cost of a dependent launch stays what it is and the step time does not move (profiles/r06_launch_floor.txt: 36.50 eager vs 36.55
+    # replayed, three interleaved pairs), so the default is the reference's own eager loop.  The first two warm-up steps run eagerly, the third
+    # captures; the eager step is timed as well, after the timed region (timing.eager_ms_per_step).
+    graphed = None
+    if world == 1 and scaler is None and args.graph and args.warmup >= 3:
+        from cleantransformer_amd.graph import GraphedStep
+        graphed = GraphedStep(model, opt, warmup=2)
+
     def step():
+        if graphed is not None:                                          # (enabled = False: it drops its graph and runs the eager loop itself)
+            return graphed(batch["ids"], batch["am"], batch["labels"])
         outputs, _ = holder["net"](input_ids=batch["ids"], attention_mask=batch["am"], labels=batch["labels"])
         loss = outputs[0]
         opt.zero_grad()
@@ -389,9 +404,27 @@ def main(argv=None):
     smi_before = _smi_snapshot() if rank == 0 else None
     clock_before = ops.clock_probe(device)                                 # shader clock under MFMA load, chip warm from the warm-up steps
     timer = ops.KernelTimer(["lm_head_fwd"])
-    ops.set_timer(timer)
+    if graphed is None:
+        ops.set_timer(timer)
     dt, per_step_ms, host_loop_s, loss = timed_steps(args.steps)
     ops.set_timer(None)
+    graph_info = None
+    if graphed is not None:
+        # the same step issued launch by launch, right after the timed region: the eager number beside the replayed one, and the HIP-event brackets
+        # of the LM-head forward (roofline.largest_launch) — a replay runs no host code that could record them
+        graph_info = {"enabled": graphed.graph is not None, "replays": graphed.replays, "fallback_reason": graphed.fallback_reason}
+        graphed.enabled = False
+        for _ in range(2):
+            step()
+        ops.set_timer(timer)
+        _, eager_ms, _, _ = timed_steps(max(5, args.steps // 2))
+        ops.set_timer(None)
+        graph_info["eager_ms_per_step"] = round(sorted(eager_ms)[len(eager_ms) // 2], 3)
+        graph_info["eager_steps"] = len(eager_ms)
+        graphed.enabled = graph_info["enabled"]                          # (later samples replay again: two eager warm-up steps, then a new capture)
+        if graphed.enabled:
+            for _ in range(3):
+                step()
     # package power / shader clock while stepping: sampled beside `steps` EXTRA steps right after the timed region, not inside it — ten rocm-smi
     # processes per second beside the timed steps cost 0.07 ms per step (same box, three interleaved pairs: 36.60 vs 36.54; round-4 advisor)
     sampler = _PowerSampler().start() if (rank == 0 and not args.no_power_sampler) else None
@@ -447,6 +480,8 @@ def main(argv=None):
     # ---- per-class device time of one step (HIP-event brackets inside the library; side stream off so that brackets do not overlap)
     breakdown = None
     if not args.no_breakdown:
+        if graphed is not None:
+            graphed.enabled = False                                      # the per-class brackets are recorded by host code: eager steps
         side = modeling_bloom._WGRAD_SIDE_STREAM
         modeling_bloom._WGRAD_SIDE_STREAM = False
         step()
@@ -461,6 +496,11 @@ def main(argv=None):
                              "brackets include launch gaps inside a library call; 'launches' = library calls per step",
                      "ms": {k: round(v[0] / nb, 3) for k, v in prof.items()}, "launches": {k: v[1] // nb for k, v in prof.items()}}
         breakdown["ms_total"] = round(sum(breakdown["ms"].values()), 3)
+        if graphed is not None:
+            graphed.enabled = graph_info["enabled"]
+            if graphed.enabled:
+                for _ in range(3):
+                    step()
 
     # ---- secondary sample (SURVEY §8(d) "Synthetic inputs"): 25 % of every row right-padded
     padded = None
@@ -502,7 +542,9 @@ def main(argv=None):
                                                         "exposed": comm_exposed,
                                                         "tied_chunk_mb": os.environ.get("CTMI_DDP_TIED_CHUNK_MB", "64")},
                        "padded_sample": padded},
+            "graph": graph_info if graph_info is not None else {"enabled": False, "why": "eager loop (default); --graph replays the captured step at N = 1"},
             "timing": {"value_from": "median of the per-step HIP-event times of the timed steps (max over ranks)",
+                       "eager_ms_per_step": None if graph_info is None else graph_info["eager_ms_per_step"],
                        "ms_per_step_median": round(med_ms, 3), "ms_per_step_mean_wall": round(mean_ms, 3),
                        "ms_per_step_min": round(min(per_step_ms), 3), "ms_per_step_max": round(max(per_step_ms), 3),
                        "wall_s_timed_region": round(dt, 4),

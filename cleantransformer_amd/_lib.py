@@ -110,6 +110,8 @@ PROTOTYPES = {
     "ctmi_dropout": (i32, [vp, vp, vp, i64, f32, C.c_uint32, i32, vp]),
     "ctmi_adamw_step": (i32, [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64),
                               i32, f32, f32, f32, f32, f32, i32, i32, i32, f32, vp]),
+    "ctmi_adamw_set_hyper": (i32, [vp, f32, f32, f32, f32, f32, i32, i32, i32, f32, vp]),
+    "ctmi_adamw_step_dev": (i32, [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), i32, vp, vp]),
     "ctmi_sgd_step": (i32, [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64),
                             i32, f32, f32, f32, f32, i32, vp]),
     "ctmi_cast": (i32, [vp, i32, vp, i32, i64, vp]),

@@ -1417,7 +1417,12 @@ struct MTFlat {
     int first[CTMI_MT_FLAT + 1];                           // first chunk of tensor i in this launch's grid
     int count;
 };
-__global__ __launch_bounds__(256) void adamw_flat_k(MTFlat pk, AdamHyper h) {
+// DEV: the hyper-parameters (with this step's bias corrections) are read from device memory — the form a captured hipGraph replays: the launch's
+// arguments are frozen at capture, the record behind `hd` is rewritten before every replay (ctmi_adamw_set_hyper)
+template <bool DEV>
+__global__ __launch_bounds__(256) void adamw_flat_k(MTFlat pk, AdamHyper hv, const AdamHyper* __restrict__ hd) {
+    AdamHyper h;
+    if constexpr (DEV) h = *hd; else h = hv;
     // tensor of this chunk: binary search over <= 64 prefix entries (scalar registers: blockIdx is uniform)
     int lo = 0, hi = pk.count;
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)blockIdx.x >= pk.first[mid]) lo = mid; else hi = mid; }
@@ -1483,20 +1488,21 @@ static int mt_grid_x(const int64_t* n, int count) {
     return (int)std::min<int64_t>(cdiv64(mx, 256 * 4 * 4), 2048);
 }
 
-extern "C" int ctmi_adamw_step(float* const* p, float* const* g, float* const* m, float* const* v, void* const* shadow,
-                               const int64_t* n, int count, float lr, float beta1, float beta2, float eps,
-                               float weight_decay, int step, int decoupled, int mutate_grad, float grad_scale, void* stream) {
-    ProfScope prof__(CTMI_PROF_OPTIMIZER, as_stream(stream));
-    CTMI_REQUIRE(p && g && m && v && n && count >= 0 && step >= 1, "adamw_step: bad args (step must be >= 1)");
+static AdamHyper adam_hyper(float lr, float beta1, float beta2, float eps, float weight_decay, int step, int decoupled, int mutate_grad, float grad_scale) {
     AdamHyper h;
     h.lr = lr; h.b1 = beta1; h.b2 = beta2; h.eps = eps; h.wd = weight_decay;
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     h.bc1 = (float)bc1; h.bc2 = (float)bc2; h.sqrt_bc2 = (float)sqrt(bc2);
     h.shadow_f16 = (mutate_grad & CTMI_OPT_SHADOW_F16) ? 1 : 0;
-    const bool legacy_grid = (mutate_grad & CTMI_OPT_LEGACY_GRID) != 0;
     mutate_grad &= 1;
     h.gscale = grad_scale; h.decoupled = decoupled; h.mutate_grad = (mutate_grad && !decoupled && weight_decay != 0.f) || (mutate_grad && grad_scale != 1.0f);
-    if (adamw_form() != 0 && !legacy_grid) {
+    return h;
+}
+__global__ void adam_set_hyper_k(AdamHyper h, AdamHyper* dst) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = h; }
+
+// one launch per <= CTMI_MT_FLAT tensors; hd != nullptr: the hyper-parameters come from the device record
+static int adamw_flat_launch(float* const* p, float* const* g, float* const* m, float* const* v, void* const* shadow, const int64_t* n, int count,
+                             const AdamHyper& h, const AdamHyper* hd, hipStream_t st) {
         for (int base = 0; base < count; ) {
             MTFlat pk;
             int c = 0;
@@ -1516,13 +1522,39 @@ extern "C" int ctmi_adamw_step(float* const* p, float* const* g, float* const* m
             pk.first[c] = (int)chunks; pk.count = c;
             for (int i = c; i < CTMI_MT_FLAT; ++i) { pk.p[i] = pk.g[i] = pk.m[i] = pk.v[i] = nullptr; pk.shadow[i] = nullptr; pk.n[i] = 0; pk.first[i + 1] = (int)chunks; }
             if (chunks > 0) {
-                hipLaunchKernelGGL(adamw_flat_k, dim3((unsigned)chunks), dim3(256), 0, as_stream(stream), pk, h);
+                if (hd != nullptr) hipLaunchKernelGGL(adamw_flat_k<true>, dim3((unsigned)chunks), dim3(256), 0, st, pk, h, hd);
+                else hipLaunchKernelGGL(adamw_flat_k<false>, dim3((unsigned)chunks), dim3(256), 0, st, pk, h, hd);
                 CTMI_CHECK_LAUNCH("adamw_step");
             }
             base += c;
         }
         return CTMI_OK;
-    }
+}
+
+extern "C" int ctmi_adamw_set_hyper(void* hyper_dev, float lr, float beta1, float beta2, float eps, float weight_decay, int step, int decoupled,
+                                    int mutate_grad, float grad_scale, void* stream) {
+    CTMI_REQUIRE(hyper_dev != nullptr && step >= 1 && (((uintptr_t)hyper_dev) & 3) == 0, "adamw_set_hyper: bad args (step must be >= 1)");
+    const AdamHyper h = adam_hyper(lr, beta1, beta2, eps, weight_decay, step, decoupled, mutate_grad, grad_scale);
+    hipLaunchKernelGGL(adam_set_hyper_k, dim3(1), dim3(64), 0, as_stream(stream), h, reinterpret_cast<AdamHyper*>(hyper_dev));
+    CTMI_CHECK_LAUNCH("adamw_set_hyper");
+    return CTMI_OK;
+}
+extern "C" int ctmi_adamw_step_dev(float* const* p, float* const* g, float* const* m, float* const* v, void* const* shadow,
+                                   const int64_t* n, int count, const void* hyper_dev, void* stream) {
+    ProfScope prof__(CTMI_PROF_OPTIMIZER, as_stream(stream));
+    CTMI_REQUIRE(p && g && m && v && n && count >= 0 && hyper_dev != nullptr, "adamw_step_dev: bad args");
+    const AdamHyper unused = {};
+    return adamw_flat_launch(p, g, m, v, shadow, n, count, unused, reinterpret_cast<const AdamHyper*>(hyper_dev), as_stream(stream));
+}
+
+extern "C" int ctmi_adamw_step(float* const* p, float* const* g, float* const* m, float* const* v, void* const* shadow,
+                               const int64_t* n, int count, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, int step, int decoupled, int mutate_grad, float grad_scale, void* stream) {
+    ProfScope prof__(CTMI_PROF_OPTIMIZER, as_stream(stream));
+    CTMI_REQUIRE(p && g && m && v && n && count >= 0 && step >= 1, "adamw_step: bad args (step must be >= 1)");
+    const bool legacy_grid = (mutate_grad & CTMI_OPT_LEGACY_GRID) != 0;
+    const AdamHyper h = adam_hyper(lr, beta1, beta2, eps, weight_decay, step, decoupled, mutate_grad, grad_scale);
+    if (adamw_form() != 0 && !legacy_grid) return adamw_flat_launch(p, g, m, v, shadow, n, count, h, nullptr, as_stream(stream));
     for (int base = 0; base < count; base += CTMI_MT_MAX) {
         const int c = std::min(CTMI_MT_MAX, count - base);
         MTPack pk;

@@ -687,6 +687,10 @@ def bloom_block_bwd(acts: BlockActs, x2: Tensor, params, mask: Optional[MaskInfo
     dev = x2.device
     if use_side_stream is None:
         use_side_stream = (_WGRAD_STREAM_ENV != "0") if _WGRAD_STREAM_ENV in ("0", "1") else not block_wgrad_grouped(B, S, H, x2.dtype, acts.flags)
+    if torch.cuda.is_current_stream_capturing():
+        # a captured step (graph.py) is one stream: events recorded by earlier EAGER steps on the side stream must not become dependencies of the
+        # capture, and a deferred join is a callback of this backward pass, not of the replays.  Same launches, issued in order.
+        use_side_stream = defer_join = False
     d = _lib.BloomBlock()
     _fill_block_desc(d, x2, params, mask, slopes, eps, post_ln_res, B, S, H, nh, acts.slab, acts.flags, acts.attn_scale, acts.future_fill)
     g = _lib.BloomBlockGrads()
@@ -709,7 +713,7 @@ def bloom_block_bwd(acts: BlockActs, x2: Tensor, params, mask: Optional[MaskInfo
         prev = st[1].get(slot)
         if prev is not None:
             main.wait_event(prev)                                   # the side-stream work of the call that last used this scratch (two blocks ago)
-    elif dev in _DEFER and _DEFER[dev][1]:
+    elif dev in _DEFER and _DEFER[dev][1] and not torch.cuda.is_current_stream_capturing():        # (GraphedStep synchronises before it captures)
         for ev in _DEFER[dev][1].values():                          # a joined call after deferred ones shares slot 0: let their side work finish first
             main.wait_event(ev)
         _DEFER[dev][1].clear()
@@ -1009,6 +1013,27 @@ def adamw_step(params, grads, exp_avg, exp_avg_sq, shadows, *, lr, beta1, beta2,
                                       sizes, n, float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
                                       int(decoupled), int(bool(mutate_grad)) | _shadow_flag(shadows) | (_lib.OPT_LEGACY_GRID if legacy_grid else 0),
                                       float(grad_scale), _stream()), "adamw_step")
+
+
+def adamw_set_hyper(hyper_dev: Tensor, *, lr, beta1, beta2, eps, weight_decay, step, decoupled, mutate_grad=False, grad_scale=1.0,
+                    shadow_f16=False) -> None:
+    """Write the hyper-parameter record of AdamW step `step` into `hyper_dev` (12 x 4 bytes on the device; include/ctmi355.h ctmi_adamw_set_hyper)."""
+    if hyper_dev.numel() * hyper_dev.element_size() < 48 or not hyper_dev.is_cuda:
+        raise _lib.CtmiError("adamw_set_hyper: a device buffer of >= 48 bytes is needed")
+    check(_lib.load().ctmi_adamw_set_hyper(_p(hyper_dev), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
+                                           int(decoupled), int(bool(mutate_grad)) | (_lib.OPT_SHADOW_F16 if shadow_f16 else 0),
+                                           float(grad_scale), _stream()), "adamw_set_hyper")
+
+
+def adamw_step_dev(params, grads, exp_avg, exp_avg_sq, shadows, hyper_dev: Tensor) -> None:
+    """ctmi_adamw_step with the hyper-parameters read from `hyper_dev` (capturable in a hipGraph)."""
+    n = len(params)
+    if n == 0:
+        return
+    sizes = (C.c_int64 * n)(*[p.numel() for p in params])
+    sh = _ptr_array(shadows) if shadows is not None else None
+    check(_lib.load().ctmi_adamw_step_dev(_ptr_array(params), _ptr_array(grads), _ptr_array(exp_avg), _ptr_array(exp_avg_sq), sh, sizes, n,
+                                          _p(hyper_dev), _stream()), "adamw_step_dev")
 
 
 def amp_unscale(grads, state: Tensor) -> None:

@@ -78,6 +78,7 @@ class AdamW():
             raise ValueError("loaded state dict has a different number of parameters")
         self.lr, (self.beta1, self.beta2), self.eps = g["lr"], g["betas"], g["eps"]
         self.weight_decay, self.decoupled = g["weight_decay"], g.get("decoupled", self.decoupled)
+        self._state_epoch = getattr(self, "_state_epoch", 0) + 1            # (graph.py: a captured step addresses the old moment buffers)
         for i, st in sd["state"].items():
             p = self.params[int(i)]
             self.steps[int(i)] = int(st["step"])
@@ -89,8 +90,55 @@ class AdamW():
             self.momentum_buffer[i] = _staggered(p, 1)
             self.rmsp_buffer[i] = _staggered(p, 2)
 
+    # ------------------------------------------------------------------------------------------------ hipGraph replay (graph.py)
+    # A captured graph replays LAUNCHES: their arguments are frozen, and no Python runs.  In graph mode the numbers that change from step to step
+    # (bias corrections 1 - beta^t, a scheduler's lr, grad_scale) therefore live in a 48-byte device record that `prepare_graph_step()` rewrites —
+    # eagerly, before the capture and before every replay — and `step()` only issues the update launches that read it (ops.adamw_step_dev).
+    def enable_graph_mode(self, device) -> None:
+        self._hyper_dev = torch.zeros(12, dtype=torch.float32, device=device)
+        self._graph_mode = True
+
+    def disable_graph_mode(self) -> None:
+        self._graph_mode = False
+
+    def _graph_params(self):
+        idx = [i for i, p in enumerate(self.params) if p.requires_grad]
+        ts = {self.steps[i] for i in idx}
+        if len(ts) != 1:
+            raise RuntimeError(f"graph mode needs every parameter at the same step count, got {sorted(ts)}")
+        return idx, ts.pop()
+
+    def prepare_graph_step(self) -> None:
+        """Host side of one optimizer step in graph mode: write this step's hyper-parameter record, advance the step counts."""
+        idx, t = self._graph_params()
+        ps = [self.params[i] for i in idx]
+        shadows = [getattr(p, "_ct_shadow", None) for p in ps]
+        f16 = any(sh is not None and sh.dtype == torch.float16 for sh in shadows)
+        ops.adamw_set_hyper(self._hyper_dev, lr=self.lr, beta1=self.beta1, beta2=self.beta2, eps=self.eps, weight_decay=self.weight_decay or 0.0,
+                            step=t, decoupled=self.decoupled, mutate_grad=not self.decoupled, grad_scale=self.grad_scale, shadow_f16=f16)
+        for i in idx:
+            self.steps[i] += 1
+            if hasattr(self.params[i], "_ct_wt"):
+                self.params[i]._ct_wt_stale = True
+
+    @torch.no_grad()
+    def _graph_step(self):
+        idx = [i for i, p in enumerate(self.params) if p.grad is not None]
+        want, _ = self._graph_params()
+        if idx != want:
+            raise RuntimeError("graph mode: every trainable parameter must have a gradient in the captured step")
+        ps = [self.params[i] for i in idx]
+        for i, p in zip(idx, ps):
+            if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
+                raise TypeError("ctmi355 AdamW keeps contiguous fp32 master parameters and gradients")
+            self._lazy_state(i, p)
+        ops.adamw_step_dev(ps, [p.grad for p in ps], [self.momentum_buffer[i] for i in idx], [self.rmsp_buffer[i] for i in idx],
+                           _shadows_of(ps), self._hyper_dev)
+
     @torch.no_grad()
     def step(self):
+        if getattr(self, "_graph_mode", False):
+            return self._graph_step()
         by_step = {}
         for i, p in enumerate(self.params):
             if p.grad is None:

@@ -275,6 +275,16 @@ int ctmi_adamw_step(float* const* p /*host*/, float* const* g /*host*/, float* c
                     void* const* shadow /*host, entries may be NULL*/, const int64_t* n /*host*/, int count,
                     float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                     int decoupled, int mutate_grad, float grad_scale, void* stream);
+/* (ABI v15) The same update with its hyper-parameters in DEVICE memory — the form a captured hipGraph replays (cleantransformer_amd/graph.py: the whole
+ * SFT step, forward + backward + optimizer, as one graph launch; a launch's arguments are frozen at capture, so the per-step numbers — bias corrections
+ * 1 - beta^t, a scheduler's lr — cannot ride in them).  ctmi_adamw_set_hyper writes the 48-byte record of step `step` (computed exactly like
+ * ctmi_adamw_step does on the host: results are bit-identical) with one single-thread launch carrying the values in ITS arguments — it is issued eagerly
+ * before every replay; ctmi_adamw_step_dev is ctmi_adamw_step reading that record (chunk-balanced launches; `mutate_grad` flags ride in the record). */
+int ctmi_adamw_set_hyper(void* hyper_dev /* device, 48 bytes, 4-byte aligned */, float lr, float beta1, float beta2, float eps, float weight_decay,
+                         int step, int decoupled, int mutate_grad, float grad_scale, void* stream);
+int ctmi_adamw_step_dev(float* const* p /*host*/, float* const* g /*host*/, float* const* m /*host*/, float* const* v /*host*/,
+                        void* const* shadow /*host, entries may be NULL*/, const int64_t* n /*host*/, int count,
+                        const void* hyper_dev /* device: written by ctmi_adamw_set_hyper */, void* stream);
 int ctmi_sgd_step(float* const* p, float* const* g, float* const* buf /* momentum buffers or NULL */,
                   void* const* shadow, const int64_t* n, int count, float lr, float momentum, float dampening,
                   float weight_decay, int first_step, void* stream);
