@@ -36,14 +36,19 @@ def autocast(device_type=None, dtype=None, enabled=True, cache_enabled=None):
         statistics in fp32 (a superset of the fp16 -> fp32 score upcast at modeling_bloom.py:106-107), fp32 master weights and gradients, on fp16
         twins of the bf16 kernel families; a ``GradScaler`` is needed here, as in the reference;
       * ``autocast(dtype=torch.bfloat16)`` — the measured path (same as ``config.compute_dtype = "bf16"``);
+      * ``autocast(enabled=False)`` / ``autocast(dtype=torch.float32)`` — no override inside (also when nested in an enabled context): the model's own dtype;
       * ``autocast()`` with no dtype (what ft_bloom_DDP.py literally writes) keeps the model's own ``config.compute_dtype`` and says so once: this
         package's default mixed precision is bf16, not fp16 (no loss scaling needed for range) — pass
         ``dtype=torch.float16`` (``examples.ft_bloom_DDP.train(amp_dtype=torch.float16)``) to reproduce the reference's precision."""
     global _warned_default
     if isinstance(device_type, bool):        # torch.cuda.amp.autocast's first positional argument is `enabled` (torch.autocast's is device_type):
         enabled, device_type = device_type, None     # autocast(False) must mean "off", not device_type=False (round-3 advisor)
-    old = ops._AUTOCAST_DTYPE
-    if enabled:
+    old = ops.get_autocast_dtype()
+    if not enabled:
+        # torch semantics: a disabled region nested in an enabled one runs WITHOUT autocast — the forwards inside compute in the model's own
+        # config.compute_dtype again (round-5 advisor; rounds 3-5 left the outer override in force)
+        ops.set_autocast_dtype(None)
+    else:
         if dtype not in (None, torch.float16, torch.bfloat16, torch.float32):
             raise NotImplementedError(f"autocast(dtype={dtype}) is not supported: compute dtypes are fp16, bf16 and fp32")
         if dtype is None and not _warned_default:
@@ -52,12 +57,16 @@ def autocast(device_type=None, dtype=None, enabled=True, cache_enabled=None):
             warnings.warn("cleantransformer_amd.amp.autocast(): no dtype given — the forward runs in the model's config.compute_dtype (bf16 or fp32; "
                           "fp32 statistics and master weights).  torch's default autocast dtype on a GPU is fp16: pass dtype=torch.float16 for it",
                           stacklevel=3)
-        if dtype is not None:
-            ops._AUTOCAST_DTYPE = dtype
+        if dtype == torch.float32:
+            # torch.autocast(dtype=torch.float32) on a GPU warns and DISABLES autocast; here too: no override, not a forced fp32 forward of a
+            # bf16 / fp16 model (which is what rounds 3-5 did, silently)
+            ops.set_autocast_dtype(None)
+        elif dtype is not None:
+            ops.set_autocast_dtype(dtype)
     try:
         yield
     finally:
-        ops._AUTOCAST_DTYPE = old
+        ops.set_autocast_dtype(old)
 
 
 class GradScaler():

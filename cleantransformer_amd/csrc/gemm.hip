@@ -772,9 +772,10 @@ __device__ __forceinline__ void glds_body(const GA g) {   // (by value: through 
             // The runtime-uniform switches (residual / beta / non-temporal) are lifted OUT of the unrolled body into
             // compile-time variants: as branches inside it they cut every 8-row step into its own basic block, so hipcc
             // could not batch the LDS reads and each step exposed an LDS round trip plus a 64-bit multiply for its address.
-            auto shuffle = [&](auto plain_c, auto nt_flag) {
+            auto shuffle = [&](auto plain_c, auto nt_flag, auto unit_c) {
+                constexpr bool UNIT = decltype(unit_c)::value;              // alpha == 1 and no bias (the logits): the accumulators go to the patch as they are
                 f32x4 bias4[4];
-                if (g.bias != nullptr) load_bias4(bias4);
+                if constexpr (!UNIT) { if (g.bias != nullptr) load_bias4(bias4); }
                 uint4 pre[2][PRE ? 4 : 1];
                 auto prefetch = [&](int p, int slot) {
                     if constexpr (PRE) {
@@ -789,8 +790,11 @@ __device__ __forceinline__ void glds_body(const GA g) {   // (by value: through 
                     for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            f32x4 v = acc[p * 2 + ii][j] * g.alpha;
-                            if (g.bias != nullptr) v += bias4[j];
+                            f32x4 v = acc[p * 2 + ii][j];
+                            if constexpr (!UNIT) {
+                                v *= g.alpha;
+                                if (g.bias != nullptr) v += bias4[j];
+                            }
                             const int row = ii * 16 + (lane & 15), c = j * 4 + (lane >> 4);
                             *reinterpret_cast<f32x4*>(scr + row * 256 + ((c ^ (row & 15)) << 4)) = v;
                         }
@@ -869,8 +873,9 @@ __device__ __forceinline__ void glds_body(const GA g) {   // (by value: through 
                 if (g.bias != nullptr) direct(std::true_type{}, std::integral_constant<bool, CAN_NT>{}, std::true_type{});
                 else direct(std::true_type{}, std::integral_constant<bool, CAN_NT>{}, std::false_type{});
             } else {
-                if (plain) shuffle(std::true_type{}, std::integral_constant<bool, CAN_NT>{});
-                else shuffle(std::false_type{}, std::false_type{});
+                if (plain && CAN_NT && g.alpha == 1.0f && g.bias == nullptr) shuffle(std::true_type{}, std::integral_constant<bool, CAN_NT>{}, std::true_type{});
+                else if (plain) shuffle(std::true_type{}, std::integral_constant<bool, CAN_NT>{}, std::false_type{});
+                else shuffle(std::false_type{}, std::false_type{}, std::false_type{});
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // patch reads retired before the other row group may write it
             }
             return;
@@ -1510,9 +1515,14 @@ static int gemm_launch(GemmArgs& g, bool fast, hipStream_t st) {
     return CTMI_OK;
 }
 
-// This file is compiled as FOUR translation units (-DCTMI_GEMM_PART=0..3, see _build.py) so the bf16 kernel instantiations
-// — three operand layouts x epilogues x five tile shapes — build in parallel: part 0 = C entry point + fp32 (parity mode),
-// parts 1/2/3 = bf16 forward (NT) / data-gradient (NN) / weight-gradient (TN) families.  Undefined = everything in one unit.
+// This file is compiled as SEVEN translation units (-DCTMI_GEMM_PART=0..6, see _build.py) so the kernel instantiations — three operand
+// layouts x epilogues x five tile shapes x two 16-bit operand types — build in parallel:
+//   part 0 = the C entry point (ctmi_gemm), the launch-policy state and fp32 (parity mode);
+//   parts 1 / 2 / 3 = bf16 forward (NT) / data-gradient (NN) / weight-gradient (TN) families; part 3 ALSO owns the grouped weight-gradient
+//     launch — ctmi_wgrad_grouped, its work-list cache, gemm_wgrad_grouped_kernel AND gemm_wgrad_grouped_kernel_f16, wgrad_partials_reduce_k
+//     (everything under CTMI_GEMM_HAS(3), including the fp16 kernel: the grouped launch is one entry point for both operand types);
+//   parts 4 / 5 / 6 = the fp16 (IEEE half) twins of parts 1 / 2 / 3's single-problem families (round 5).
+// Undefined = everything in one unit.  (parts 8 / 9 exist only for tools/: one grouped kernel / one instantiation, for ISA inspection.)
 int ctmi_gemm_bf16_nt(GemmArgs& g, int epi, bool fast, hipStream_t st);
 int ctmi_gemm_bf16_nn(GemmArgs& g, int epi, bool fast, hipStream_t st);
 int ctmi_gemm_bf16_tn(GemmArgs& g, int epi, bool fast, hipStream_t st);
@@ -1659,11 +1669,19 @@ extern "C" int ctmi_wgrad_grouped(const ctmi_wgrad_problem* pr, int n, int64_t T
     sh.n = n; sh.ksteps = T / 32; sh.slots = slots;
     const int mode = ctmi_wgrad_group_mode();
     sh.split = mode == 3 ? 0 : (mode == 2 ? 2 : 1);
-    // the K-halves need 2 x (M N + M) floats per cut problem: without that much workspace nothing is cut
+    // the K-halves need 2 x (M N + M) floats per problem (the slabs are carved for every problem of the call, cut or not: the carve below must not
+    // depend on which tiles the work list cuts): without that much workspace nothing is cut — the result is the same, the last partial round then
+    // leaves half the CUs idle; said ONCE, because it changes the speed silently (round-5 advisor)
     {
         int64_t need = 0;
         for (int i = 0; i < n; ++i) { const int64_t M = pr[i].in_out ? pr[i].n_in : pr[i].n_out, N = pr[i].in_out ? pr[i].n_out : pr[i].n_in; need += 2 * (M * N + M) * 4 + 512; }
-        if (workspace == nullptr || workspace_bytes < need || (((uintptr_t)workspace) & 15)) sh.split = 0;
+        if (sh.split != 0 && (workspace == nullptr || workspace_bytes < need || (((uintptr_t)workspace) & 15))) {
+            static std::atomic<bool> said{false};
+            if (!said.exchange(true))
+                fprintf(stderr, "[ctmi355] wgrad_grouped: workspace of %lld bytes (need %lld, 16-byte aligned) — the tiles of the last partial round are NOT cut "
+                                "in K-halves (same results, lower speed)\n", (long long)workspace_bytes, (long long)need);
+            sh.split = 0;
+        }
     }
     GroupedArgs g = {};
     g.M = 128; g.N = 256; g.K = T; g.k_per_split = T; g.splits = 1; g.alpha = 1.0f;       // (the single-problem fields are not read by a grouped launch)
@@ -1683,6 +1701,13 @@ extern "C" int ctmi_wgrad_grouped(const ctmi_wgrad_problem* pr, int n, int64_t T
         auto key = std::make_pair(dev, sh);
         auto it = g_wg_tables.find(key);
         if (it == g_wg_tables.end()) {
+            if (g_wg_tables.size() >= 64) {
+                // bounded cache (round-5 advisor): a process that walks through many geometries does not keep every work list for ever.  Lists may
+                // be read by launches in flight, so the purge waits for the device first — a once-in-64-geometries event
+                (void)hipDeviceSynchronize();
+                for (auto& kv : g_wg_tables) (void)hipFree(kv.second.dev);
+                g_wg_tables.clear();
+            }
             std::vector<int4> items;
             WgTable t;
             build_items(sh, items, t.nitems, t.nsplit, t.split_mask);

@@ -41,13 +41,30 @@ def dt_code(dtype: torch.dtype) -> int:
 
 # amp.autocast(dtype=...) override of a model's config.compute_dtype for the forwards run inside the context (and their backwards: the saved
 # activations carry the dtype).  Process-wide like torch's autocast state is thread-wide; the training loop is single-threaded on the forward side.
-_AUTOCAST_DTYPE = None
+_AUTOCAST = threading.local()
 
 
 def effective_compute_dtype(model_dtype: torch.dtype) -> torch.dtype:
     """The dtype a model forward computes in: amp.autocast(dtype=torch.float16 / torch.bfloat16)'s while such a context is active (torch.autocast
     semantics: the context, not the module, picks the matmul dtype — ft_bloom_DDP.py:122), else the model's own config.compute_dtype."""
-    return _AUTOCAST_DTYPE if _AUTOCAST_DTYPE is not None else model_dtype
+    ac = get_autocast_dtype()
+    return ac if ac is not None else model_dtype
+
+
+def get_autocast_dtype():
+    return getattr(_AUTOCAST, "dtype", None)
+
+
+def set_autocast_dtype(dtype) -> None:
+    """Per THREAD, like torch's autocast state: a forward on another thread (a data-loader worker that runs a model, a second trainer) does not pick
+    up this thread's context (round-5 advisor)."""
+    _AUTOCAST.dtype = dtype
+
+
+def __getattr__(name):                                    # `ops._AUTOCAST_DTYPE` (read-only view of this thread's override; rounds 3-5 had a module global)
+    if name == "_AUTOCAST_DTYPE":
+        return get_autocast_dtype()
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
 
 
 def _need_cuda(*ts):
@@ -523,6 +540,14 @@ def note_block_params(mask: Optional["MaskInfo"], params) -> None:
         seen.add(k)
 
 
+def _multi_rank_job() -> bool:
+    try:
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    except Exception:                                                   # noqa: BLE001
+        return False
+
+
 def params_allow_deferred_grads(params, mask: Optional["MaskInfo"] = None) -> bool:
     """The parameter gradients of a block may complete on the side stream AFTER the autograd node has returned only if nothing touches them
     before the end of the backward pass.  Refused when: a hold is active (hold_deferred_wgrad_join: the explicit contract of wrappers that
@@ -533,6 +558,11 @@ def params_allow_deferred_grads(params, mask: Optional["MaskInfo"] = None) -> bo
     if not _DEFER_JOIN or _DEFER_HOLDS > 0 or torch.is_grad_enabled():
         return False
     if mask is not None and getattr(mask, "shared_params", False):
+        return False
+    # A process group with more than one rank means SOME wrapper reduces these gradients during backward.  This package's own wrapper holds the
+    # contract above; torch's DistributedDataParallel / FSDP / apex hook the AccumulateGrad node, which neither the contract nor the hook lists
+    # below can see — so in a multi-rank job the join is never deferred (round-5 advisor: default to the safe side)
+    if _multi_rank_job():
         return False
     for p in params:
         if p.grad is not None or getattr(p, "_post_accumulate_grad_hooks", None) or getattr(p, "_backward_hooks", None):

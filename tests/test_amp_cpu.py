@@ -104,7 +104,7 @@ def test_torch_gradscaler_drives_the_fused_optimizer(monkeypatch):
 
 def test_autocast_selects_the_compute_dtype_of_the_forwards_inside_it():
     """ft_bloom_DDP.py:122 writes `with autocast():` (fp16 on a GPU).  Round 5: the context selects the compute dtype of the model forwards run
-    inside it (ops.effective_compute_dtype) — fp16 (the reference's), bf16 or fp32; nested contexts restore; disabled contexts change nothing;
+    inside it (ops.effective_compute_dtype) — fp16 (the reference's), bf16 or fp32; nested contexts restore; a disabled context (or dtype=float32) means no override inside; the override is per thread;
     the default form keeps the model's own dtype and says so once; other dtypes are refused."""
     import warnings
     from cleantransformer_amd import amp, ops
@@ -115,8 +115,18 @@ def test_autocast_selects_the_compute_dtype_of_the_forwards_inside_it():
             assert ops.effective_compute_dtype(torch.float32) is torch.bfloat16
         assert ops.effective_compute_dtype(torch.float32) is torch.float16
         with amp.autocast(False, dtype=torch.float32):        # torch.cuda.amp.autocast(enabled, ...): the first positional argument is `enabled`
-            assert ops.effective_compute_dtype(torch.float32) is torch.float16
+            assert ops.effective_compute_dtype(torch.bfloat16) is torch.bfloat16      # a disabled region nested in an enabled one: no override inside (torch semantics, round-5 advisor)
+        assert ops.effective_compute_dtype(torch.float32) is torch.float16            # ... and the outer context is back afterwards
+        with amp.autocast(dtype=torch.float32):                                       # torch disables autocast for float32: the model's own dtype, not a forced fp32 forward
+            assert ops.effective_compute_dtype(torch.bfloat16) is torch.bfloat16
     assert ops.effective_compute_dtype(torch.float32) is torch.float32
+    # the override is per thread
+    import threading
+    seen = []
+    with amp.autocast(dtype=torch.float16):
+        th = threading.Thread(target=lambda: seen.append(ops.effective_compute_dtype(torch.bfloat16)))
+        th.start(); th.join()
+    assert seen == [torch.bfloat16]
     with pytest.raises(NotImplementedError):
         with amp.autocast("cuda", torch.float64):
             pass

@@ -5,7 +5,7 @@ set -u
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/evidence; rm -rf $OUT; mkdir -p $OUT
-R=${ROUND:-r05}
+R=${ROUND:-r06}
 timeout 600 python bench.py --cpu-baseline ${CPU_BASELINE:-full} > $OUT/${R}_bench_default.json 2> $OUT/bench_default.err
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -- python bench.py --no-cpu-baseline --no-breakdown --no-padded-sample --steps 10 --warmup 3 > $OUT/${R}_bench_under_rocprof.json 2> $OUT/prof_bench.err
 # (round 5: the default runs the whole step on ONE stream — grouped weight gradients; the second trace is the round-4 form: four products per block on a side stream)
