@@ -192,7 +192,7 @@ __device__ __forceinline__ void store_tile32(const f32x16 (&acc)[HD / 32], float
     for (int it = 0; it < 32 * CPR / 64; ++it) {
         const int slot = it * 64 + lane, row = slot / CPR, ch = slot % CPR;
         const uint4 v = *reinterpret_cast<const uint4*>(scr + row * PITCH + ch * 16);
-        *reinterpret_cast<uint4*>(g0 + (int64_t)row * rs + ch * 8) = v;
+        st_wt16(g0 + (int64_t)row * rs + ch * 8, v);                        // (write-through: common.h)
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }

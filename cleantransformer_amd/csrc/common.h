@@ -91,6 +91,46 @@ template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float 
 template <> __device__ __forceinline__ uint32_t pack2<bf16_t>(float lo, float hi) { return pack_bf2(lo, hi); }
 template <> __device__ __forceinline__ uint32_t pack2<f16_t>(float lo, float hi) { return pack_h2(lo, hi); }
 
+// ---------------------------------------------------------------- write-through stores of large outputs
+// The eight XCD L2s are write-back and not coherent with each other, so a kernel's dirty lines are flushed at its END — on the critical path of the
+// dependent launch behind it.  tools/probes/boundary_dirty.hip (profiles/r06_boundary_dirty.txt): a writer that leaves 16 - 64 MiB behind costs
+// the boundary 4.0 - 4.2 us with plain stores and 1.2 - 2.2 us with `sc1` (write-through: the bytes go out to the memory side while the kernel still
+// computes, the line is dropped from the XCD's L2 — the consumers of a [T, *] activation run on all eight XCDs and read it from the Infinity Cache
+// either way).  Kernels whose outputs are streamed once and read by the NEXT kernels (GEMM epilogues, LayerNorm, attention) store through these.
+// The asm ends in `s_nop 1`: hipcc's hazard recognizer does not see into asm, and a 16-byte store needs a wait state before its data registers may
+// be overwritten (cdna_hip_programming.md 5.7 item 1).  -DCTMI_ST_WT=0 restores plain stores (A/B builds).
+#ifndef CTMI_ST_WT
+#define CTMI_ST_WT 1
+#endif
+typedef uint32_t ctmi_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t ctmi_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st_wt16(void* p, const uint4& v) {
+#if CTMI_ST_WT
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(ctmi_u32x4{v.x, v.y, v.z, v.w}) : "memory");
+#else
+    *reinterpret_cast<uint4*>(p) = v;
+#endif
+}
+// fp32 outputs (weight gradients: 32-byte row pieces per lane, two store instructions per 128-byte line) stay write-back: written through, every
+// half-filled line went out twice — the grouped weight-gradient launch 213 -> 232 us (profiles/r06_boundary_dirty.txt)
+#ifndef CTMI_ST_WT_F32
+#define CTMI_ST_WT_F32 0
+#endif
+__device__ __forceinline__ void st_wt16(void* p, const f32x4& v) {
+#if CTMI_ST_WT && CTMI_ST_WT_F32
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+#else
+    *reinterpret_cast<f32x4*>(p) = v;
+#endif
+}
+__device__ __forceinline__ void st_wt8(void* p, const uint2& v) {
+#if CTMI_ST_WT
+    asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 0" :: "v"(p), "v"(ctmi_u32x2{v.x, v.y}) : "memory");
+#else
+    *reinterpret_cast<uint2*>(p) = v;
+#endif
+}
+
 // ---------------------------------------------------------------- wave / block reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void ln_fwd_vec(const T* __restrict__ x, const
                 float o[VEC];
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) o[j] = w[c + j] * ((vals[i][j] - mean) * rstd) + b[c + j];
-                *reinterpret_cast<uint4*>(yr + c) = pack16<T>(o);
+                st_wt16(yr + c, pack16<T>(o));                           // (write-through: common.h)
             }
         }
     }
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(64 * lnb_waves(MAXV)) void ln_bwd_vec(const T* __re
                     for (int j = 0; j < VEC; ++j) { if (!valid) r[j] = 0.f; o[j] += r[j]; if (NS == 4) ar[NS == 4 ? i : 0][j] += r[j]; }
                 }
                 const uint4 pk = pack16<T>(o);
-                if (valid) *reinterpret_cast<uint4*>(dxr + c) = pk;
+                if (valid) st_wt16(dxr + c, pk);
                 if (NS == 4) {                                           // column sums of dx as STORED (what the weight-gradient GEMM reads)
                     float orr[VEC];
                     unpack16<T>(pk, orr);

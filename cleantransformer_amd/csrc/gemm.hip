@@ -22,6 +22,9 @@
 #ifndef CTMI_GEMM_PART
 #define CTMI_GEMM_PART (-1)
 #endif
+#ifndef CTMI_GELU_AUX_WT
+#define CTMI_GELU_AUX_WT 0
+#endif
 #define CTMI_GEMM_HAS(p) (CTMI_GEMM_PART == -1 || CTMI_GEMM_PART == (p))
 
 // LDS-DMA ring depth and epilogue re-layout of the bf16 fast path (gemm_glds_kernel below).
@@ -608,8 +611,8 @@ __device__ __forceinline__ void glds_body(const GA g) {   // (by value: through 
                              "v_permlane16_swap_b32 %3, %7"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
                 float* d = Cl + (int64_t)arow(i) * ldc + 32 * jp;
-                *reinterpret_cast<f32x4*>(d) = f32x4{a0, a1, a2, a3};
-                *reinterpret_cast<f32x4*>(d + 4) = f32x4{b0, b1, b2, b3};
+                st_wt16(d, f32x4{a0, a1, a2, a3});
+                st_wt16(d + 4, f32x4{b0, b1, b2, b3});
             }
         if (gs.cs_on) {
             // gs.accs: D'[n][m] = sum_k 1 * A[k][m] in every n for the wave's block arow(0): lanes 0-15 hold its 16 rows in element 0
@@ -689,7 +692,8 @@ __device__ __forceinline__ void glds_body(const GA g) {   // (by value: through 
                     // the pre-activation is kept for the BACKWARD only (a whole forward and half a backward away): CTMI_GELU_AUX_NT writes it
                     // non-temporally, so that the activation next to it — the A operand of the very next GEMM — is what stays in the caches
                     // (same box, interleaved: forward chain of 24 blocks 6.16 / 6.26 -> 6.07 / 6.05 ms, step 37.01-37.35 -> 36.83-37.08 ms)
-                    if constexpr (sizeof(T) == 2) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, tb), reinterpret_cast<u32x4*>(AUXO + off));   // (the builtin, not asm: hipcc's hazard recognizer does not see into asm, and a first asm version — no wait state between the 16-byte store and the next write of its data registers — stored garbage in a few rows; tests/test_gpu_ops.py::test_gemm_at_the_step_shapes_sampled_vs_fp64 caught it)
+                    if constexpr (sizeof(T) == 2 && CTMI_GELU_AUX_WT) st_wt16(AUXO + off, tb);                 // (round 6: written through — like nt it does not stay in the XCD's L2, and the kernel's end does not wait for 64 MB of dirty lines)
+                    else if constexpr (sizeof(T) == 2) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, tb), reinterpret_cast<u32x4*>(AUXO + off));   // (the builtin, not asm: hipcc's hazard recognizer does not see into asm, and a first asm version — no wait state between the 16-byte store and the next write of its data registers — stored garbage in a few rows; tests/test_gpu_ops.py::test_gemm_at_the_step_shapes_sampled_vs_fp64 caught it)
                     else *reinterpret_cast<uint4*>(AUXO + off) = tb;
                     unpack16<T>(tb, v);
 #pragma unroll
@@ -709,7 +713,7 @@ __device__ __forceinline__ void glds_body(const GA g) {   // (by value: through 
                         const f32x2 y = x * sg;
                         gd[r] = d[0]; gd[r + 1] = d[1]; v[r] = y[0]; v[r + 1] = y[1];
                     }
-                    *reinterpret_cast<uint4*>(AUXO + off) = pack16<T>(gd);
+                    st_wt16(AUXO + off, pack16<T>(gd));
                 } else if (EPI == CTMI_EPI_RELU) {
 #pragma unroll
                     for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
@@ -750,8 +754,8 @@ __device__ __forceinline__ void glds_body(const GA g) {   // (by value: through 
                             for (int r = 0; r < 4; ++r) { v[r] += c0v[r]; v[4 + r] += c1v[r]; }
                         }
                     }
-                    *reinterpret_cast<f32x4*>(Cf) = f32x4{v[0], v[1], v[2], v[3]};
-                    *reinterpret_cast<f32x4*>(Cf + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                    st_wt16(Cf, f32x4{v[0], v[1], v[2], v[3]});
+                    st_wt16(Cf + 4, f32x4{v[4], v[5], v[6], v[7]});
                 } else {
                     if constexpr (!PLAIN) {
                         if (g.beta) {
@@ -766,7 +770,7 @@ __device__ __forceinline__ void glds_body(const GA g) {   // (by value: through 
                     // not push the operand panels out of L2 (asm: hipcc would merge a plain and a nontemporal store
                     // to one address into one plain store)
                     if (NT && g.nt_c) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" :: "v"(C + off), "v"(__builtin_bit_cast(u32x4, pk)) : "memory");
-                    else *reinterpret_cast<uint4*>(C + off) = pk;
+                    else st_wt16(C + off, pk);                                // (write-through: common.h — the next kernel's boundary does not wait for this tile's lines)
                 }
             };
             // The runtime-uniform switches (residual / beta / non-temporal) are lifted OUT of the unrolled body into
