@@ -25,6 +25,9 @@
 #ifndef CTMI_GELU_AUX_WT
 #define CTMI_GELU_AUX_WT 0
 #endif
+#ifndef CTMI_SIDE_PRE8
+#define CTMI_SIDE_PRE8 1      // round 6: the 256-row ping-pong tile prefetches its epilogue's side input too (0: rounds 3-5 — such epilogues forced onto the 128-row tile)
+#endif
 #define CTMI_GEMM_HAS(p) (CTMI_GEMM_PART == -1 || CTMI_GEMM_PART == (p))
 
 // LDS-DMA ring depth and epilogue re-layout of the bf16 fast path (gemm_glds_kernel below).
@@ -674,7 +677,7 @@ __device__ __forceinline__ void glds_body(const GA g) {   // (by value: through 
             // RES) is fetched one pass ahead, into the registers the previous pass's accumulators just freed: loaded
             // where it is used, each of the 16 row groups of a tile would expose a full global-load latency
             // (only the 128-row tiles have the registers for it: with 128 accumulators live hipcc spills the prefetch)
-            constexpr bool PRE_AUX = (EPI == CTMI_EPI_DGELU || EPI == CTMI_EPI_DRELU || EPI == CTMI_EPI_MUL) && WM == 4;
+            constexpr bool PRE_AUX = (EPI == CTMI_EPI_DGELU || EPI == CTMI_EPI_DRELU || EPI == CTMI_EPI_MUL) && (WM == 4 || CTMI_SIDE_PRE8);
             constexpr bool PRE_RES = RES && !PRE_AUX && WM == 4;
             constexpr bool PRE = PRE_AUX || PRE_RES;
             const T* side = PRE_AUX ? AUXI : R;
@@ -780,7 +783,10 @@ __device__ __forceinline__ void glds_body(const GA g) {   // (by value: through 
                 constexpr bool UNIT = decltype(unit_c)::value;              // alpha == 1 and no bias (the logits): the accumulators go to the patch as they are
                 f32x4 bias4[4];
                 if constexpr (!UNIT) { if (g.bias != nullptr) load_bias4(bias4); }
-                uint4 pre[2][PRE ? 4 : 1];
+                // 256-row tile (round 6): ONE slot — the piece of pass p + 1 is requested into the register quad that `finish` has just consumed for
+                // pass p (a pass of lead time all the same, 16 registers instead of 32: with two slots this instantiation needed 260)
+                constexpr bool ONE_SLOT = PRE && WM == 8;
+                uint4 pre[ONE_SLOT ? 1 : 2][PRE ? 4 : 1];
                 auto prefetch = [&](int p, int slot) {
                     if constexpr (PRE) {
 #pragma unroll
@@ -803,7 +809,7 @@ __device__ __forceinline__ void glds_body(const GA g) {   // (by value: through 
                             *reinterpret_cast<f32x4*>(scr + row * 256 + ((c ^ (row & 15)) << 4)) = v;
                         }
                     __builtin_amdgcn_sched_barrier(0);                         // the next pass's inputs go into the registers these accumulators just freed
-                    if (p + 1 < WM / 2) prefetch(p + 1, (p + 1) & 1);
+                    if (!ONE_SLOT && p + 1 < WM / 2) prefetch(p + 1, (p + 1) & 1);
                     constexpr int RB = (WM == 8) ? 2 : 4;                       // 8-row steps read back together (register budget)
 #pragma unroll
                     for (int ib = 0; ib < 4; ib += RB) {
@@ -819,7 +825,8 @@ __device__ __forceinline__ void glds_body(const GA g) {   // (by value: through 
                         const int it = ib + k;
                         float v[8] = {lo[k][0], lo[k][1], lo[k][2], lo[k][3], hi[k][0], hi[k][1], hi[k][2], hi[k][3]};
                         const int64_t off = off0 + (p * 4 + it) * row8;
-                        finish(plain_c, nt_flag, v, off, pre[p & 1][PRE ? it : 0]);
+                        finish(plain_c, nt_flag, v, off, pre[ONE_SLOT ? 0 : (p & 1)][PRE ? it : 0]);
+                        if constexpr (ONE_SLOT) { if (p + 1 < WM / 2) pre[0][it] = *reinterpret_cast<const uint4*>(side + off0 + ((p + 1) * 4 + it) * row8); }
                     }
                     }
                     __builtin_amdgcn_sched_barrier(0);                         // one pass at a time: keeps the live set at acc + one pass
@@ -1446,9 +1453,10 @@ static void pick_tile(int64_t M, int64_t N, int64_t K, bool wgrad, bool bkm, int
     else if (t4 >= 256) tile = 4;                                  // (round 3: also K-major B with long K — 919 vs 861 TF/s on the QKV data gradient)
     else if (t1 >= 700) tile = 1;
     else tile = 0;
-    // epilogues that read a second [M,N] operand (activation-derivative input): only the 128-row ping-pong tile has the
-    // registers to prefetch it a pass ahead (measured 112 vs 121 us on the [T,4H] DGELU dgrad)
-    if ((epi == CTMI_EPI_DGELU || epi == CTMI_EPI_DRELU || epi == CTMI_EPI_MUL) && tile == 3) tile = 4;
+    // epilogues that read a second [M,N] operand (activation-derivative input): rounds 3-5 only the 128-row ping-pong tile had the registers to
+    // prefetch it a pass ahead (112 vs 121 us on the [T,4H] DGELU dgrad) and took these launches; round 6 the 256-row tile prefetches it through ONE
+    // register slot (244 VGPRs, no scratch) and keeps them: 77 - 81 vs 88 - 90 us (profiles/r06_dgelu_side_input.txt)
+    if (!CTMI_SIDE_PRE8 && (epi == CTMI_EPI_DGELU || epi == CTMI_EPI_DRELU || epi == CTMI_EPI_MUL) && tile == 3) tile = 4;
     if (force >= 0) tile = force;
 }
 

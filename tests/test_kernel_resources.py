@@ -64,7 +64,10 @@ def test_gemm_kernels_fit_their_occupancy(kernels):
     gemms.update(pick(kernels, "void gemm_glds_kernel_f16<"))                  # (round 5: the fp16 twins of the same schedules)
     gemms.update(pick(kernels, "gemm_wgrad_grouped_kernel"))
     for name, k in gemms.items():
-        assert k["vgpr_count"] <= 240, (name, k["vgpr_count"])                 # two waves per SIMD (eight-wave tiles: one workgroup per CU)
+        # two waves per SIMD (eight-wave tiles: one workgroup per CU).  Round 6: the 256-row ping-pong tile of the dGELU data gradient prefetches
+        # its side input through one register slot — 244, still without scratch (two slots, as on the 128-row tile, needed 260 = 256 + 4 spilled)
+        cap = 248 if ", true, 2, 8, 4, true, false, false>" in name else 240
+        assert k["vgpr_count"] <= cap, (name, k["vgpr_count"])
         assert k["agpr_count"] == 0, (name, k["agpr_count"])
         assert k["vgpr_spill_count"] == 0 and k.get("private_segment_fixed_size", 0) == 0, (name, k)
     # the 128 x 128 free-running tile: three workgroups per CU
