@@ -21,6 +21,9 @@
 //   dx   = LN1'(dln1) + dh1    [+ partial rows of dln1_w, dln1_b]
 //   join;  ONE reduce launch turns all partial rows into the 8 small gradient vectors.
 #include "common.h"
+#ifndef CTMI_BLOCK_TAIL
+#define CTMI_BLOCK_TAIL 1      // 0: the sum of the K-halves right behind the grouped launch (round 5), for A/B builds
+#endif
 #include <math.h>
 #include <stdlib.h>
 #include <mutex>
@@ -30,6 +33,10 @@ int ctmi_ln_bwd_parts_internal(const void* dy, const void* x, const float* w, co
                                int* nparts, int* ns, hipStream_t st);
 int ctmi_colsum_parts_internal(const void* x, int64_t ld, float* ws, int64_t M, int64_t N, int dtype, int* parts_out, hipStream_t st);
 bool ctmi_wgrad_grouped_ok(const ctmi_wgrad_problem* pr, int n, int64_t T, int dtype);      // csrc/gemm.hip
+int ctmi_wgrad_grouped_ex(const ctmi_wgrad_problem* pr, int n, int64_t T, int dtype, void* workspace, int64_t workspace_bytes, void* stream, bool defer_reduce);
+int ctmi_wgrad_tail(const ctmi_reduce_job* jobs, int count, hipStream_t st);      // the pending sum of K-halves + these jobs in one launch (csrc/gemm.hip)
+void ctmi_wgrad_pending_clear();
+bool ctmi_wgrad_pending();
 
 #ifndef CTMI_BLOCK_GELUG
 #define CTMI_BLOCK_GELUG 0      // 1: forward saves gelu'(u) (GELUG) and the backward multiplies (MUL); 0: save u, DGELU epilogue.
@@ -246,6 +253,7 @@ extern "C" int ctmi_bloom_block_bwd(const ctmi_bloom_block* b, const ctmi_bloom_
         return CTMI_OK;
     };
 
+    ctmi_wgrad_pending_clear();                                          // (a previous call of this thread that failed half-way)
     ctmi_reduce_job jobs[CTMI_REDUCE_MAX_JOBS];
     int nj = 0;
     auto job = [&](const float* src, int64_t stride, int nparts, float* dst, int64_t n) {
@@ -298,8 +306,12 @@ extern "C" int ctmi_bloom_block_bwd(const ctmi_bloom_block* b, const ctmi_bloom_
             RC(colsum_job(W(W_DU), 4 * H, W_CS_DU, gr->db1));
             RC(colsum_job(dqkv, 3 * H, W_CS_DQKV, gr->dbqkv));
         }
-        RC(ctmi_wgrad_grouped(wp, 4, T, dt, pws, pws_bytes, pst));
-        RC(linear_dgrad(dqkv, b->wqkv, W(W_DLN1), T, 3 * H, H, CTMI_EPI_NONE, nullptr, post ? W(W_DH1) : nullptr, dt, gr->splitk_ws, gr->splitk_ws_bytes, main_st, w_io));
+        // one stream (the default of the grouped path): the sum of the K-halves waits for the block's last launch and shares it with the
+        // partial-row reductions (ctmi_wgrad_tail below) — the data gradient in between then gets no split-K workspace: the slabs of the halves live there
+        const bool tail = !two && CTMI_BLOCK_TAIL;
+        RC(ctmi_wgrad_grouped_ex(wp, 4, T, dt, pws, pws_bytes, pst, tail));
+        const bool pend = ctmi_wgrad_pending();
+        RC(linear_dgrad(dqkv, b->wqkv, W(W_DLN1), T, 3 * H, H, CTMI_EPI_NONE, nullptr, post ? W(W_DH1) : nullptr, dt, pend ? nullptr : gr->splitk_ws, pend ? 0 : gr->splitk_ws_bytes, main_st, w_io));
         int np1 = 0, ns1 = 2;
         RC(ctmi_ln_bwd_parts_internal(W(W_DLN1), b->x, b->ln1_w, s.at<float>(CTMI_BLK_MEAN1), s.at<float>(CTMI_BLK_RSTD1),
                                       post ? nullptr : W(W_DH1), gr->dx, WF(W_LNP1), T, H, dt, 0, &np1, &ns1, main_st));
@@ -364,7 +376,7 @@ extern "C" int ctmi_bloom_block_bwd(const ctmi_bloom_block* b, const ctmi_bloom_
         const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(main_st, ev, 0) : e1;
         if (e2 != hipSuccess && rc_launch == CTMI_OK) { ctmi_set_error("bloom_block_bwd: joining the side stream: %s", hipGetErrorString(e2)); return CTMI_ERR_LAUNCH; }
     }
-    RC(rc_launch);
-    RC(ctmi_reduce_jobs(jobs, nj, main_st));
+    if (rc_launch != CTMI_OK) { ctmi_wgrad_pending_clear(); return rc_launch; }
+    RC(ctmi_wgrad_tail(jobs, nj, main_st));
     return CTMI_OK;
 }

@@ -2,6 +2,7 @@
 // gfx950: one wave (64 lanes) per row for LayerNorm, one 256-thread block per vocabulary row for CE,
 // 16-byte loads everywhere, fp32 statistics, wavefront shuffles for the reductions.
 #include "common.h"
+#include "reduce_jobs.h"
 #include "prof.h"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
@@ -728,26 +729,9 @@ extern "C" int ctmi_dropout(const void* x, const void* residual, void* y, int64_
 // rows of its two LayerNorm backward passes and its bias column sums in workspaces and reduces them all here, instead of one
 // small "final" launch per vector (what used to be 96 colsum_final + 50 ln_bwd_reduce launches per Bloom-560M step).
 // ------------------------------------------------------------------------------------------------
-struct ReduceJobs { ctmi_reduce_job j[CTMI_REDUCE_MAX_JOBS]; int chunk0[CTMI_REDUCE_MAX_JOBS + 1]; int count; };
 __global__ __launch_bounds__(256) void reduce_jobs_k(ReduceJobs R) {
-    // block -> (job, 64-column chunk); 64 columns x 4 part-slices per block, LDS combine
     __shared__ float sm[4][64];
-    int job = 0;
-    while (job + 1 < R.count && (int)blockIdx.x >= R.chunk0[job + 1]) ++job;
-    const ctmi_reduce_job& J = R.j[job];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int64_t c = (int64_t)((int)blockIdx.x - R.chunk0[job]) * 64 + tx;
-    float t = 0.f;
-    if (c < J.n) {
-#pragma unroll 8
-        for (int p = ty; p < J.nparts; p += 4) t += J.src[(int64_t)p * J.part_stride + c];
-    }
-    sm[ty][tx] = t;
-    __syncthreads();
-    if (ty == 0 && c < J.n) {
-        const float r = J.alpha * (sm[0][tx] + sm[1][tx] + sm[2][tx] + sm[3][tx]);
-        J.dst[c] = J.accumulate ? J.dst[c] + r : r;
-    }
+    reduce_jobs_block(R, (int)blockIdx.x, sm);                            // (csrc/reduce_jobs.h: shared with gemm.hip's wgrad_tail_k)
 }
 
 extern "C" int ctmi_reduce_jobs(const ctmi_reduce_job* jobs, int count, void* stream) {
@@ -756,16 +740,8 @@ extern "C" int ctmi_reduce_jobs(const ctmi_reduce_job* jobs, int count, void* st
     hipStream_t st = as_stream(stream);
     for (int base = 0; base < count; base += CTMI_REDUCE_MAX_JOBS) {
         ReduceJobs R;
-        R.count = std::min(CTMI_REDUCE_MAX_JOBS, count - base);
-        int chunks = 0;
-        for (int i = 0; i < R.count; ++i) {
-            const ctmi_reduce_job& J = jobs[base + i];
-            CTMI_REQUIRE(J.src && J.dst && J.n > 0 && J.nparts > 0, "reduce_jobs: job %d is malformed", base + i);
-            R.j[i] = J;
-            R.chunk0[i] = chunks;
-            chunks += (int)cdiv64(J.n, 64);
-        }
-        R.chunk0[R.count] = chunks;
+        const int chunks = reduce_jobs_pack(jobs + base, std::min(CTMI_REDUCE_MAX_JOBS, count - base), R);
+        if (chunks < 0) return CTMI_ERR_ARG;
         hipLaunchKernelGGL(reduce_jobs_k, dim3((unsigned)chunks), dim3(256), 0, st, R);
         CTMI_CHECK_LAUNCH("reduce_jobs");
     }

@@ -14,6 +14,7 @@
 // handles any shape/alignment element-wise.  Small-tile-count problems (weight gradients) are split along K into
 // fp32 slabs in a caller-provided workspace and reduced deterministically by a second kernel.
 #include "common.h"
+#include "reduce_jobs.h"
 #include <type_traits>
 #include "mma.h"
 #include "prof.h"
@@ -1246,10 +1247,13 @@ __global__ __launch_bounds__(512, 2) void gemm_wgrad_grouped_kernel_f16(GroupedA
 }
 // second launch of a grouped call that cut tiles in two along K: C = partial 0 + partial 1 (and the column sums), one 32-row slice of a tile per workgroup
 struct WgReduceArgs { GroupProb p[WG_MAXP]; const int4* tiles; int ntiles; };           // tiles: x = problem | WG_COLSUM, y = first row, z = first column
-__global__ __launch_bounds__(256) void wgrad_partials_reduce_k(WgReduceArgs z) {
-    const int4 it = z.tiles[blockIdx.x >> 2];
+__global__ __launch_bounds__(256) void wgrad_partials_reduce_k(WgReduceArgs z);
+// (round 6) the same sum and the block's partial-row reductions (LayerNorm affine gradients, bias column sums: csrc/reduce_jobs.h) in ONE launch:
+// blocks [0, 4 * ntiles) are wgrad_partials_reduce_k's, the rest are reduce_jobs_k's — one dependent launch per block backward less
+__device__ __forceinline__ void wgrad_partials_block(const WgReduceArgs& z, int block) {
+    const int4 it = z.tiles[block >> 2];
     const GroupProb& P = z.p[it.x & (WG_MAXP - 1)];
-    const int qr = blockIdx.x & 3, tid = threadIdx.x;
+    const int qr = block & 3, tid = threadIdx.x;
     const int64_t half = P.M * P.N;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -1259,6 +1263,13 @@ __global__ __launch_bounds__(256) void wgrad_partials_reduce_k(WgReduceArgs z) {
         *reinterpret_cast<float4*>(P.C + off) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
     }
     if ((it.x & WG_COLSUM) && qr == 0 && tid < 128) P.cs[it.y + tid] = P.cspart[it.y + tid] + P.cspart[P.M + it.y + tid];
+}
+__global__ __launch_bounds__(256) void wgrad_partials_reduce_k(WgReduceArgs z) { wgrad_partials_block(z, (int)blockIdx.x); }
+__global__ __launch_bounds__(256) void wgrad_tail_k(WgReduceArgs z, ReduceJobs R) {
+    __shared__ float sm[4][64];
+    const int nb = 4 * z.ntiles;
+    if ((int)blockIdx.x < nb) wgrad_partials_block(z, (int)blockIdx.x);
+    else reduce_jobs_block(R, (int)blockIdx.x - nb, sm);
 }
 #endif
 
@@ -1666,7 +1677,33 @@ bool ctmi_wgrad_grouped_ok(const ctmi_wgrad_problem* pr, int n, int64_t T, int d
     return true;
 }
 
+// A grouped call made with defer_reduce leaves the sum of its K-halves PENDING (per host thread): ctmi_wgrad_tail() then launches it together with
+// the caller's partial-row reductions (block.hip: one launch at the end of a block's backward instead of two).  The partial slabs live in the
+// caller's workspace: nothing may overwrite it in between.
+static thread_local struct { bool valid = false; WgReduceArgs z; hipStream_t st = nullptr; } g_wg_pending;
+void ctmi_wgrad_pending_clear() { g_wg_pending.valid = false; }
+bool ctmi_wgrad_pending() { return g_wg_pending.valid; }
+int ctmi_wgrad_tail(const ctmi_reduce_job* jobs, int count, hipStream_t st) {
+    if (!g_wg_pending.valid) return ctmi_reduce_jobs(jobs, count, st);
+    g_wg_pending.valid = false;
+    if (st != g_wg_pending.st || count > CTMI_REDUCE_MAX_JOBS || count <= 0) {           // not combinable: the two launches of rounds 5
+        hipLaunchKernelGGL(wgrad_partials_reduce_k, dim3(4 * g_wg_pending.z.ntiles), dim3(256), 0, g_wg_pending.st, g_wg_pending.z);
+        CTMI_CHECK_LAUNCH("wgrad_grouped_reduce");
+        return ctmi_reduce_jobs(jobs, count, st);
+    }
+    ProfScope prof__(CTMI_PROF_REDUCE, st);
+    ReduceJobs R;
+    const int chunks = reduce_jobs_pack(jobs, count, R);
+    if (chunks < 0) return CTMI_ERR_ARG;
+    hipLaunchKernelGGL(wgrad_tail_k, dim3((unsigned)(4 * g_wg_pending.z.ntiles + chunks)), dim3(256), 0, st, g_wg_pending.z, R);
+    CTMI_CHECK_LAUNCH("wgrad_tail");
+    return CTMI_OK;
+}
+int ctmi_wgrad_grouped_ex(const ctmi_wgrad_problem* pr, int n, int64_t T, int dtype, void* workspace, int64_t workspace_bytes, void* stream, bool defer_reduce);
 extern "C" int ctmi_wgrad_grouped(const ctmi_wgrad_problem* pr, int n, int64_t T, int dtype, void* workspace, int64_t workspace_bytes, void* stream) {
+    return ctmi_wgrad_grouped_ex(pr, n, T, dtype, workspace, workspace_bytes, stream, false);
+}
+int ctmi_wgrad_grouped_ex(const ctmi_wgrad_problem* pr, int n, int64_t T, int dtype, void* workspace, int64_t workspace_bytes, void* stream, bool defer_reduce) {
     CTMI_REQUIRE(pr != nullptr, "wgrad_grouped: null problem list");
     if (!ctmi_wgrad_grouped_ok(pr, n, T, dtype)) {
         ctmi_set_error("wgrad_grouped: unsupported problem set (bf16 / fp16, <= %d problems, rows a multiple of 128 and columns of 256 of every gradient, T %% 32 == 0, "
@@ -1748,6 +1785,7 @@ extern "C" int ctmi_wgrad_grouped(const ctmi_wgrad_problem* pr, int n, int64_t T
         WgReduceArgs z = {};
         for (int i = 0; i < n; ++i) z.p[i] = g.p[i];
         z.tiles = tab.dev + tab.nitems; z.ntiles = tab.nsplit;
+        if (defer_reduce) { g_wg_pending.valid = true; g_wg_pending.z = z; g_wg_pending.st = st; return CTMI_OK; }
         hipLaunchKernelGGL(wgrad_partials_reduce_k, dim3(4 * tab.nsplit), dim3(256), 0, st, z);
         CTMI_CHECK_LAUNCH("wgrad_grouped_reduce");
     }
