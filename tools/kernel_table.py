@@ -35,20 +35,21 @@ WORK = [
      L * ((3 * H + H + 4 * H + 3 * H) * T * 2 + 8 * H * H * 2), "qkv dgrad"),
     (r"gemm_glds_kernel<unsigned short, false, false, 0, 4, 4, true, true, false>", "dense / 4h->h forward + residual (128x256 tile)", "TF", L * (GF(H, H) + GF(H, 4 * H)),
      L * ((H + 4 * H + 4 * H) * T * 2 + 5 * H * H * 2), "4hh fwd"),
-    (r"gemm_glds_kernel<unsigned short, false, true, 2, 4, 4, true", "4h->h data gradient x gelu'(u) (dGELU epilogue)", "TF", L * GF(4 * H, H), L * ((H + 4 * H + 4 * H) * T * 2 + 4 * H * H * 2), "4hh dgrad"),
+    (r"gemm_glds_kernel<unsigned short, false, true, 2, [48], 4, true", "4h->h data gradient x gelu'(u) (dGELU epilogue; 256x256 tile since round 6)", "TF", L * GF(4 * H, H), L * ((H + 4 * H + 4 * H) * T * 2 + 4 * H * H * 2), "4hh dgrad"),
     (r"gemm_glds_kernel<unsigned short, false, false, 1, 8, 4, true, false, true>", "h->4h forward + GELU (256x256 tile, cross-lane epilogue)", "TF", L * GF(4 * H, H),
      L * ((H + 4 * H + 4 * H) * T * 2 + 4 * H * H * 2), "h4h fwd"),
     (r"gemm_glds_kernel<unsigned short, false, false, 0, 8, 4, true, false, true>", "QKV forward (256x256 tile, cross-lane epilogue)", "TF", L * GF(3 * H, H), L * ((H + 3 * H) * T * 2 + 3 * H * H * 2), "qkv fwd"),
     (r"attn32_fwd_kernel", "attention forward (hd = 64, causal)", "TF", L * ATT, L * 4 * T * H * 2, "attention fwd"),
     (r"attn32_dq_kernel", "attention backward: dQ", "TF", L * ATT * 2.5 * 3 / 7, L * 5 * T * H * 2, None),
     (r"attn32_dkdv_kernel", "attention backward: dK, dV", "TF", L * ATT * 2.5 * 4 / 7, L * 6 * T * H * 2, "attention bwd"),
-    (r"adamw_mt_k", "AdamW, fused (fp32 state + bf16 shadow)", "TB", P * 30.0, P * 30.0, "AdamW (140 M params)"),
+    (r"adamw_(mt|flat)_k", "AdamW, fused (fp32 state + bf16 shadow)", "TB", P * 30.0, P * 30.0, "AdamW (140 M params)"),
     (r"ce_fused_k", "shifted cross entropy: loss + dlogits in one pass", "TB", T * V * 2 * 2.0, T * V * 2 * 2.0, None),
     (r"ln_fwd_vec", "LayerNorm forward", "TB", (2 * L + 2) * T * H * 2 * 2.0, (2 * L + 2) * T * H * 2 * 2.0, None),
     (r"ln_bwd_vec", "LayerNorm backward (+ residual-gradient add, bias column sums)", "TB", (2 * L + 2) * T * H * 2 * 4.0, (2 * L + 2) * T * H * 2 * 4.0, "LayerNorm bwd [8192,1024]"),
     (r"splitk_reduce", "split-K reduce", "TB", None, None, None),
     (r"colsum_part", "bias column sums (separate pass)", "TB", None, None, None),
     (r"reduce_jobs_k", "partial-row reductions of a block (LayerNorm affine, bias gradients)", "TB", None, None, None),
+    (r"wgrad_tail_k", "block tail (round 6): sum of the K-halves of the cut tiles + the partial-row reductions in one launch", "TB", L * 128 * 128 * 256 * 4 * 3, L * 128 * 128 * 256 * 4 * 3, None),
 ]
 PEAK = {"TF": 2500e12, "TB": 8e12}
 
