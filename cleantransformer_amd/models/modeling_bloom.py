@@ -436,6 +436,10 @@ class ShiftedCrossEntropyFn(torch.autograd.Function):
             ctx.used = True
             d = ops.scale_if_(ctx.dl, g, *ctx.applied)                    # no-op on the device when gout is what the forward was told to expect
             ctx.dl = None
+            if d.stride(0) != V and d._base is not None:
+                # padded row pitch (odd vocabulary): the pad columns were zeroed with the buffer — tell the LM-head backward, as the two-pass form does below
+                ops.ZERO_PADDED.clear()                                   # at most one live entry (it pins its buffer)
+                ops.ZERO_PADDED[d.data_ptr()] = (d.stride(0), d._base)
             return d.view(B, S, V), None
         l2, lab, row_lse, loss_out = ctx.saved_tensors
         out = None

@@ -438,7 +438,16 @@ def ce_fwd_bwd(logits2d: Tensor, labels: Tensor, seq: int, shift: int, ignore_in
     row_lse = torch.empty(N, dtype=torch.float32, device=dev)
     row_loss = torch.empty(N, dtype=torch.float32, device=dev)
     loss_out = torch.empty(2, dtype=torch.float32, device=dev)
-    dl = torch.empty((N, Cn), dtype=logits2d.dtype, device=dev)
+    if logits2d.stride(0) != Cn:
+        # a padded row pitch (odd vocabulary — GPT-2's 50257 in rows of 50272): dlogits gets the same pitch with zeroed pad columns (dl._base is the
+        # padded buffer).  The loss node's BACKWARD registers it in ZERO_PADDED — that table is per thread, and the backward pass runs on autograd's
+        # worker thread, not on the one that ran this forward
+        Vp = logits2d.stride(0)
+        buf = torch.empty((N, Vp), dtype=logits2d.dtype, device=dev)
+        buf[:, Cn:].zero_()
+        dl = buf[:, :Cn]
+    else:
+        dl = torch.empty((N, Cn), dtype=logits2d.dtype, device=dev)
     check(_lib.load().ctmi_ce_fwd_bwd(_p(logits2d), logits2d.stride(0), _p(labels), _p(row_lse), _p(row_loss), _p(loss_out), _p(dl),
                                       dl.stride(0), N, Cn, seq, shift, ignore_index, denom_mode, denom_rows, float(grad_factor),
                                       _p(grad_factor_dev), dt_code(logits2d.dtype), _stream()), "ce_fwd_bwd")
@@ -446,10 +455,13 @@ def ce_fwd_bwd(logits2d: Tensor, labels: Tensor, seq: int, shift: int, ignore_in
 
 
 def ce_fused_ok(logits2d: Tensor) -> bool:
-    """Rows 16-byte aligned and densely packed: the single-pass loss+gradient kernel applies."""
+    """Rows 16-byte aligned — densely packed, or (round 6) at the padded pitch ops.pad_rows gives an odd vocabulary: the single-pass
+    loss+gradient kernel applies (it takes the row pitch and finishes a row's last C % 8 classes one by one)."""
     vec = 16 // logits2d.element_size()
-    return logits2d.is_cuda and logits2d.stride(1) == 1 and logits2d.stride(0) == logits2d.shape[1] and logits2d.shape[1] % vec == 0 \
-        and logits2d.data_ptr() % 16 == 0
+    C = logits2d.shape[1]
+    dense = logits2d.stride(0) == C and C % vec == 0
+    padded = logits2d.stride(0) != C and logits2d.stride(0) == pad_rows(C)
+    return logits2d.is_cuda and logits2d.stride(1) == 1 and (dense or padded) and logits2d.stride(0) % vec == 0 and logits2d.data_ptr() % 16 == 0
 
 
 def scale_if_(x2d: Tensor, s_dev: Tensor, applied: float = 1.0, applied_dev: Optional[Tensor] = None) -> Tensor:
@@ -1116,6 +1128,9 @@ class _ZeroPadded(threading.local):
 
     def pop(self, k, default=None):
         return self.d.pop(k, default)
+
+    def get(self, k, default=None):
+        return self.d.get(k, default)
 
 
 ZERO_PADDED = _ZeroPadded()

@@ -117,6 +117,40 @@ def test_ce_fwd_bwd_equals_two_pass_and_oracle(dtype, rtol, N, Cn, seq):
     assert torch.equal(dl.float(), keep.float() * 0.25)                         # a power of two: exact in both dtypes
 
 
+@pytest.mark.parametrize("dtype,rtol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+def test_fused_loss_at_a_padded_row_pitch_and_the_lm_head_backward_finds_its_buffer(dtype, rtol):
+    """Round 6: an odd class count (GPT-2: 50257) keeps its logits in rows of ops.pad_rows(V); the single-pass loss takes that pitch (it did not
+    until round 6: such steps ran the two-pass form), gives dlogits the same pitch with zero pad columns, equals the two-pass form — and the loss
+    node's BACKWARD (autograd's worker thread, where the per-thread ZERO_PADDED table is read) registers the padded buffer, so that the LM-head
+    backward runs over the padded extent instead of re-packing 0.8 GB: a forward-thread registration cost GPT-2-medium 10 ms per step."""
+    from cleantransformer_amd.models.modeling_bloom import ShiftedCrossEntropyFn
+    o = ops()
+    B, S, V = 2, 16, 1001
+    Vp = o.pad_rows(V)
+    buf = rnd(B * S, Vp, seed=5, scale=2.0).to(DEV).to(dtype)
+    l2 = buf[:, :V]
+    lab = torch.randint(0, V, (B, S), generator=torch.Generator().manual_seed(6)).to(DEV)
+    assert o.ce_fused_ok(l2) and l2.stride(0) == Vp != V
+    lo, lse, dl = o.ce_fwd_bwd(l2, lab, seq=S, shift=1)
+    lo2, lse2 = o.ce_fwd(l2, lab, seq=S, shift=1)
+    dl2 = o.ce_bwd(l2, lab, lse2, lo2, None, seq=S, shift=1)
+    assert dl.stride(0) == Vp and dl._base is not None and float(dl._base[:, V:].float().abs().sum()) == 0.0
+    assert abs(float(lo[0]) - float(lo2[0])) <= 1e-6 * abs(float(lo2[0])) and relerr(lse, lse2) < 1e-6
+    assert relerr(dl, dl2) < (1e-6 if dtype == torch.float32 else 4e-3)
+    ref = l2.detach().float().cpu().double().reshape(B, S, V)
+    l_ref = torch.nn.functional.cross_entropy(ref[:, :-1].reshape(-1, V), lab.cpu()[:, 1:].reshape(-1))
+    assert abs(float(lo[0]) - float(l_ref)) <= (2e-5 if dtype == torch.float32 else 2e-3) * abs(float(l_ref))
+    # through the autograd node: the gradient arrives as a VIEW of the padded buffer and is registered on the backward thread
+    x = l2.reshape(B, S, V).detach().requires_grad_(True)                    # (reshape of the padded view keeps the pitch: no copy)
+    assert x.stride(1) == Vp
+    seen = {}
+    x.register_hook(lambda g: seen.setdefault("entry", o.ZERO_PADDED.get(g.reshape(B * S, V).data_ptr())) and None)
+    loss = ShiftedCrossEntropyFn.apply(x, lab)
+    loss.backward()
+    assert seen["entry"] is not None and seen["entry"][0] == Vp, "the loss node's backward did not register its padded dlogits"
+    assert relerr(x.grad, dl.reshape(B, S, V)) < rtol
+
+
 def test_fused_loss_node_autograd_scaling_and_double_backward_guard():
     from cleantransformer_amd.models.modeling_bloom import ShiftedCrossEntropyFn
     B, S, V = 2, 8, 512
