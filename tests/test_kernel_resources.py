@@ -85,3 +85,53 @@ def test_streaming_kernels_do_not_spill(kernels):
                    "reduce_jobs_k", "void colsum_part<unsigned short>", "void embed_bwd_k<unsigned short>"):
         for name, k in pick(kernels, prefix).items():
             assert k["vgpr_spill_count"] == 0 and k.get("private_segment_fixed_size", 0) == 0, (name, k)
+
+
+def _disassemble(lib_path, wanted):
+    """{demangled name: disassembly text} of the kernels whose demangled name starts with one of `wanted` (llvm-objdump on the gfx950 code objects)"""
+    import shutil
+    import subprocess
+    import tempfile
+    llvm = KR.LLVM
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        local = os.path.join(tmp, "lib.so")
+        shutil.copy(lib_path, local)
+        subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", local], cwd=tmp, check=True, capture_output=True)
+        for f in sorted(os.listdir(tmp)):
+            if "gfx950" not in f:
+                continue
+            syms = subprocess.run([os.path.join(llvm, "llvm-readelf"), "-s", "-W", os.path.join(tmp, f)], capture_output=True, text=True).stdout.split("\n")
+            mangled = [ln.split()[-1] for ln in syms if " FUNC " in ln]
+            if not mangled:
+                continue
+            dem = subprocess.run(["c++filt"], input="\n".join(mangled), capture_output=True, text=True).stdout.split("\n")
+            for m, d in zip(mangled, dem):
+                if any(d.startswith(w) for w in wanted):
+                    r = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", f"--disassemble-symbols={m}", os.path.join(tmp, f)],
+                                       capture_output=True, text=True)
+                    out[d] = r.stdout
+    return out
+
+
+def test_streamed_bf16_outputs_are_written_through_and_fp32_gradients_are_not():
+    """Round 6 (csrc/common.h st_wt16; profiles/r06_boundary_dirty.txt): the 16-byte stores of LayerNorm, of the 128-row attention kernels and of the
+    bf16 GEMM epilogues carry `sc1` (the dependent launch does not wait for the producer's dirty L2 lines); the fp32 weight gradients of the grouped
+    launch are plain stores (written through they were 9 % slower), the GELU pre-activation and the logits non-temporal.  A build flag or a refactor
+    that silently drops the policy shows up here on the CPU box."""
+    from cleantransformer_amd import _lib
+    if not KR.have_tools() or not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("tools / library not available")
+    wanted = ["void ln_fwd_vec<unsigned short, 2>", "void ln_bwd_vec<unsigned short, 2, 4, true, 1>", "void (anonymous namespace)::attn32_fwd_kernel<64, 4, false, false>",
+              "void gemm_glds_kernel<unsigned short, false, false, 0, 8, 4, true, false, true>", "void gemm_glds_kernel<unsigned short, false, false, 1, 8, 4, true, false, true>",
+              "gemm_wgrad_grouped_kernel(GroupedArgs)"]
+    dis = _disassemble(_lib.LIB_PATH, wanted)
+    assert len(dis) == len(wanted), sorted(dis)
+
+    def stores(name, flag):
+        txt = next(v for k, v in dis.items() if k.startswith(name))
+        return sum(1 for ln in txt.split("\n") if "global_store_dwordx4" in ln and (flag in ln.split("//")[0].split()))
+    for name in wanted[:5]:
+        assert stores(name, "sc1") > 0, name
+    assert stores("gemm_wgrad_grouped_kernel", "sc1") == 0
+    assert stores("void gemm_glds_kernel<unsigned short, false, false, 1, 8, 4", "nt") > 0                  # the GELU pre-activation stays non-temporal
