@@ -274,9 +274,9 @@ extern "C" int ctmi_bloom_block_bwd(const ctmi_bloom_block* b, const ctmi_bloom_
     // Bloom-560M — are the ones cut in two along T)
     ctmi_wgrad_problem wp[4] = {
         {dout, s.at(CTMI_BLK_G), gr->dw2, nullptr, H, 4 * H, wio ? 1 : 0, 0},
-        {W(W_DU), s.at(CTMI_BLK_LN2), gr->dw1, wio ? nullptr : gr->db1, 4 * H, H, wio ? 1 : 0, 0},
+        {W(W_DU), s.at(CTMI_BLK_LN2), gr->dw1, gr->db1, 4 * H, H, wio ? 1 : 0, 0},        // (round 6: the column sums of du / dqkv ride in the grouped launch for [in,out] weights too — there as sums of its B operand)
         {W(W_DH1), s.at(CTMI_BLK_ATT), gr->dwd, nullptr, H, H, wio ? 1 : 0, 0},
-        {W(W_DQKV), s.at(CTMI_BLK_LN1), gr->dwqkv, wio ? nullptr : gr->dbqkv, 3 * H, H, wio ? 1 : 0, 0},
+        {W(W_DQKV), s.at(CTMI_BLK_LN1), gr->dwqkv, gr->dbqkv, 3 * H, H, wio ? 1 : 0, 0},
     };
     const bool grouped = !(blk_dbg & 1) && ctmi_wgrad_grouped_ok(wp, 4, T, dt);
     // The launches run inside a lambda so that a failure half-way still reaches the join below: the side stream may already hold
@@ -302,10 +302,6 @@ extern "C" int ctmi_bloom_block_bwd(const ctmi_bloom_block* b, const ctmi_bloom_
         else RC(colsum_job(dout, H, W_CS_DOUT, gr->db2));
         if (ns2 == 4) job(WF(W_LNP2) + 3 * H, ns2 * H, np2, gr->dbd, H);
         else RC(colsum_job(W(W_DH1), H, W_CS_DH1, gr->dbd));
-        if (wio) {                                                        // [in,out] weight gradients: dy is the B operand there, its column sums stay a pass of their own
-            RC(colsum_job(W(W_DU), 4 * H, W_CS_DU, gr->db1));
-            RC(colsum_job(dqkv, 3 * H, W_CS_DQKV, gr->dbqkv));
-        }
         // one stream (the default of the grouped path): the sum of the K-halves waits for the block's last launch and shares it with the
         // partial-row reductions (ctmi_wgrad_tail below) — the data gradient in between then gets no split-K workspace: the slabs of the halves live there
         const bool tail = !two && CTMI_BLOCK_TAIL;

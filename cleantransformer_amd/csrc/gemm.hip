@@ -191,13 +191,14 @@ struct GemmArgs {
 // a problem: ONE extra MFMA per wave and ring stage against a fragment of ones — each of the four waves of a row group starts its A fragments at
 // a different 16-row block (i -> (i + wc) & 3), so wave wc's fragment 0 is block wc and the four waves cover the 64 rows between them.
 constexpr int WG_MAXP = 4;
-struct GroupProb { const void* A; const void* B; float* C; float* cs; float* part; float* cspart; int64_t lda, ldb, ldc, M, N; };
+struct GroupProb { const void* A; const void* B; float* C; float* cs; float* part; float* cspart; int64_t lda, ldb, ldc, M, N, csn; };   // csn: length of cs (M: sums of the A operand; N: of the B operand, [in,out] weights)
     // C[M,N] = A^T B, A = [K][M], B = [K][N]; cs[M] = column sums of A (or null); part = [2][M][N] / cspart = [2][M] partial results of the K-halves
 struct GroupedArgs : GemmArgs { GroupProb p[WG_MAXP]; const int4* items; int nitems; };
 // work item (int4): x = problem | WG_PART | WG_HALF1 | WG_COLSUM, y = first row, z = first column of the tile, w = first K-step | K-steps << 16
-constexpr int WG_PART = 16, WG_COLSUM = 32, WG_HALF1 = 64;
-template <bool GRP, int WM> struct GrpRegs { };
-template <int WM> struct GrpRegs<true, WM> { f32x4 accs; bool cs_on; };             // column-sum accumulator of this wave's 16-row block, and whether the tile has one
+constexpr int WG_PART = 16, WG_COLSUM = 32, WG_HALF1 = 64, WG_COLSUMB = 128;      // WG_COLSUMB (round 6): the column sums of the B operand (dy of an [in,out] weight), tiles of the first tile ROW
+template <bool GRP, int WM, bool BSUM = false> struct GrpRegs { };
+template <int WM> struct GrpRegs<true, WM, false> { f32x4 accs; bool cs_on; };      // column-sum accumulator of this wave's 16-row block, and whether the tile has one
+template <int WM> struct GrpRegs<true, WM, true> { f32x4 accs; bool cs_on; f32x4 accb[4]; bool csb_on; };   // + the sums of the wave's four 16-column blocks of the B operand
 #define WG_ONES8 (std::is_same<T, f16_t>::value ? short8{0x3C00, 0x3C00, 0x3C00, 0x3C00, 0x3C00, 0x3C00, 0x3C00, 0x3C00} \
                                                 : short8{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80})   /* eight 1.0 in the operand type (half: 0x3C00, bf16: 0x3F80) */
 
@@ -455,7 +456,7 @@ struct GTile {
     }
 };
 
-template <typename TO, bool AK, bool BKM, int EPI, int WM, int WGN, bool PP, bool RES, bool XLANE, bool GRP, typename GA, typename TE = bf16_t>
+template <typename TO, bool AK, bool BKM, int EPI, int WM, int WGN, bool PP, bool RES, bool XLANE, bool GRP, typename GA, typename TE = bf16_t, bool BSUM = false>
 __device__ __forceinline__ void glds_body(const GA g) {   // (by value: through a reference hipcc kept a 16-byte piece of the kernel arguments in scratch memory, reloaded in every epilogue)
     using T = TE;                                                           // bf16_t (the measured path) or f16_t (round 5: same schedules, v_mfma_f32_16x16x32_f16)
     static_assert(!GRP || (PP && WM == 4 && WGN == 4 && AK && BKM && EPI == CTMI_EPI_NONE && sizeof(TO) == 4), "grouped launches: weight gradients on the 128x256 ping-pong tile");
@@ -579,8 +580,14 @@ __device__ __forceinline__ void glds_body(const GA g) {   // (by value: through 
 
     // grouped weight gradients: column sums of the A operand (the bias gradient) of this tile, accumulated by MFMAs against a fragment of ones
     // (state of the grouped instantiation only: the other kernels do not even declare it)
-    GrpRegs<GRP, WM> gs;
+    static_assert(!BSUM || GRP, "B-operand column sums: grouped launches only");
+    GrpRegs<GRP, WM, BSUM> gs;
     if constexpr (GRP) { gs.accs = f32x4{0.f, 0.f, 0.f, 0.f}; gs.cs_on = false; }
+    if constexpr (BSUM) {
+        gs.csb_on = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gs.accb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     // first row (inside the wave's WM*16 rows) of A fragment i: grouped launches rotate the blocks by the wave's column index
     auto arow = [&](int i) { return GRP ? ((i + wc) & (WM - 1)) * 16 : i * 16; };
 
@@ -621,8 +628,16 @@ __device__ __forceinline__ void glds_body(const GA g) {   // (by value: through 
         if (gs.cs_on) {
             // gs.accs: D'[n][m] = sum_k 1 * A[k][m] in every n for the wave's block arow(0): lanes 0-15 hold its 16 rows in element 0
             if ((lane >> 4) == 0) {
-                float* d = (part ? P.cspart + (half1 ? P.M : 0) : P.cs) + mw + arow(0) + lane;
+                float* d = (part ? P.cspart + (half1 ? P.csn : 0) : P.cs) + mw + arow(0) + lane;
                 *d = gs.accs[0];
+            }
+        }
+        if constexpr (BSUM) {
+            // gs.accb[j]: D[m][n] = sum_k 1 * B[k][n] in every m: the lanes of accumulator row 0 hold columns 4 (lane >> 4) .. + 3 of block j
+            if (gs.csb_on && (lane & 15) == 0) {
+                float* d = (part ? P.cspart + (half1 ? P.csn : 0) : P.cs) + nw + (lane >> 4) * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(d + j * 16) = gs.accb[j];
             }
         }
         return;
@@ -1022,6 +1037,7 @@ __device__ __forceinline__ void glds_body(const GA g) {   // (by value: through 
                 const int4 it = g.items[cw];
                 m0 = it.y; n0 = it.z; split = it.x; ntc = it.w >> 16;
                 gs.cs_on = (it.x & WG_COLSUM) != 0;
+                if constexpr (BSUM) gs.csb_on = (it.x & WG_COLSUMB) != 0 && wr == 0;      // (both row groups hold the same B columns: one of them sums)
             } else {
                 decode(cw, m0, n0, split);
                 ntc = (int)((min(g.K, (int64_t)(split + 1) * g.k_per_split) - (int64_t)split * g.k_per_split) / BK);
@@ -1074,6 +1090,14 @@ __device__ __forceinline__ void glds_body(const GA g) {   // (by value: through 
                                 gs.accs = Mma<T>::mma(WG_ONES8, af0[0], gs.accs);
                                 gs.accs = Mma<T>::mma(WG_ONES8, af1[0], gs.accs);
                             }
+                            if constexpr (BSUM) {
+                                if (gs.csb_on) {
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) gs.accb[j] = Mma<T>::mma(bf0[j], WG_ONES8, gs.accb[j]);
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) gs.accb[j] = Mma<T>::mma(bf1[j], WG_ONES8, gs.accb[j]);
+                                }
+                            }
                         }
                         __builtin_amdgcn_sched_barrier(0);
                         __builtin_amdgcn_s_barrier();
@@ -1108,6 +1132,12 @@ __device__ __forceinline__ void glds_body(const GA g) {   // (by value: through 
                         for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(bf[j], af[i], acc[i][j]);
                     if constexpr (GRP) {
                         if (gs.cs_on) gs.accs = Mma<T>::mma(WG_ONES8, af[0], gs.accs);
+                        if constexpr (BSUM) {
+                            if (gs.csb_on) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) gs.accb[j] = Mma<T>::mma(bf[j], WG_ONES8, gs.accb[j]);
+                            }
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_barrier();
@@ -1145,6 +1175,12 @@ __device__ __forceinline__ void glds_body(const GA g) {   // (by value: through 
                 for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(bf[j], af[i], acc[i][j]);
             if constexpr (GRP) {
                 if (gs.cs_on) gs.accs = Mma<T>::mma(WG_ONES8, af[0], gs.accs);
+                if constexpr (BSUM) {
+                    if (gs.csb_on) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) gs.accb[j] = Mma<T>::mma(bf[j], WG_ONES8, gs.accb[j]);
+                    }
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -1163,6 +1199,10 @@ __device__ __forceinline__ void glds_body(const GA g) {   // (by value: through 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             if constexpr (GRP) gs.accs = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (BSUM) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gs.accb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
         if (wr == 0) __builtin_amdgcn_s_barrier();
         return;
@@ -1245,6 +1285,14 @@ __global__ __launch_bounds__(512, 2) void gemm_wgrad_grouped_kernel(GroupedArgs 
 __global__ __launch_bounds__(512, 2) void gemm_wgrad_grouped_kernel_f16(GroupedArgs g) {             // IEEE-half operands (the column sums then multiply by a fragment of half ones)
     glds_body<float, true, true, CTMI_EPI_NONE, 4, 4, true, false, false, true, GroupedArgs, f16_t>(g);
 }
+// (round 6) the same launch with the column sums of the B operand too: bias gradients of [in,out] (Conv1D) weights, whose dy is the B operand.  Its own
+// instantiation: the kernels above — the measured Bloom path — keep their code
+__global__ __launch_bounds__(512, 2) void gemm_wgrad_grouped_bsum_kernel(GroupedArgs g) {
+    glds_body<float, true, true, CTMI_EPI_NONE, 4, 4, true, false, false, true, GroupedArgs, bf16_t, true>(g);
+}
+__global__ __launch_bounds__(512, 2) void gemm_wgrad_grouped_bsum_kernel_f16(GroupedArgs g) {
+    glds_body<float, true, true, CTMI_EPI_NONE, 4, 4, true, false, false, true, GroupedArgs, f16_t, true>(g);
+}
 // second launch of a grouped call that cut tiles in two along K: C = partial 0 + partial 1 (and the column sums), one 32-row slice of a tile per workgroup
 struct WgReduceArgs { GroupProb p[WG_MAXP]; const int4* tiles; int ntiles; };           // tiles: x = problem | WG_COLSUM, y = first row, z = first column
 __global__ __launch_bounds__(256) void wgrad_partials_reduce_k(WgReduceArgs z);
@@ -1262,7 +1310,8 @@ __device__ __forceinline__ void wgrad_partials_block(const WgReduceArgs& z, int 
         const float4 a = *reinterpret_cast<const float4*>(P.part + off), b = *reinterpret_cast<const float4*>(P.part + half + off);
         *reinterpret_cast<float4*>(P.C + off) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
     }
-    if ((it.x & WG_COLSUM) && qr == 0 && tid < 128) P.cs[it.y + tid] = P.cspart[it.y + tid] + P.cspart[P.M + it.y + tid];
+    if ((it.x & WG_COLSUM) && qr == 0 && tid < 128) P.cs[it.y + tid] = P.cspart[it.y + tid] + P.cspart[P.csn + it.y + tid];
+    if ((it.x & WG_COLSUMB) && qr == 0) P.cs[it.z + tid] = P.cspart[it.z + tid] + P.cspart[P.csn + it.z + tid];      // 256 columns of the tile, one per thread
 }
 __global__ __launch_bounds__(256) void wgrad_partials_reduce_k(WgReduceArgs z) { wgrad_partials_block(z, (int)blockIdx.x); }
 __global__ __launch_bounds__(256) void wgrad_tail_k(WgReduceArgs z, ReduceJobs R) {
@@ -1588,7 +1637,7 @@ int ctmi_gemm_bf16_tn(GemmArgs& g, int epi, bool fast, hipStream_t st) {
 #include <mutex>
 #include <vector>
 namespace {
-struct WgShape { int64_t M[WG_MAXP], N[WG_MAXP]; int cs[WG_MAXP]; int n; int64_t ksteps; int slots; int split;
+struct WgShape { int64_t M[WG_MAXP], N[WG_MAXP]; int cs[WG_MAXP]; int n; int64_t ksteps; int slots; int split;      // cs: 0 none, 1 sums of the A operand, 2 of the B operand ([in,out] weight)
     bool operator<(const WgShape& o) const {
         if (n != o.n) return n < o.n;
         if (ksteps != o.ksteps) return ksteps < o.ksteps;
@@ -1629,8 +1678,9 @@ void build_items(const WgShape& sh, std::vector<int4>& out, int& nitems, int& ns
     if (sh.split == 2 && ks >= 2) whole = 0;
     else if (sh.split == 1 && ks >= 2) { const int R = nt % slots; if (R > 0 && 2 * R <= slots) whole = nt - R; }
     split_mask = 0;
+    auto csflag = [&](const Tile& t) { return sh.cs[t.p] == 1 ? (t.n0 == 0 ? WG_COLSUM : 0) : (sh.cs[t.p] == 2 ? (t.m0 == 0 ? WG_COLSUMB : 0) : 0); };
     auto item = [&](const Tile& t, int kb, int n, bool part) {
-        const int cs = (sh.cs[t.p] && t.n0 == 0) ? WG_COLSUM : 0;
+        const int cs = csflag(t);
         if (part) split_mask |= 1u << t.p;
         return make_int4(t.p | (part ? WG_PART : 0) | ((part && kb) ? WG_HALF1 : 0) | cs, t.m0, t.n0, kb | (n << 16));
     };
@@ -1650,7 +1700,7 @@ void build_items(const WgShape& sh, std::vector<int4>& out, int& nitems, int& ns
         for (int b = 0; b < L; ++b) out[r0 + b] = lin[r0 + xcd_pos(b, L)];
     }
     nitems = total; nsplit = nt - whole;
-    for (int t = whole; t < nt; ++t) out.push_back(make_int4(tiles[t].p | ((sh.cs[tiles[t].p] && tiles[t].n0 == 0) ? WG_COLSUM : 0), tiles[t].m0, tiles[t].n0, 0));
+    for (int t = whole; t < nt; ++t) out.push_back(make_int4(tiles[t].p | csflag(tiles[t]), tiles[t].m0, tiles[t].n0, 0));
 }
 }  // namespace
 
@@ -1672,7 +1722,7 @@ bool ctmi_wgrad_grouped_ok(const ctmi_wgrad_problem* pr, int n, int64_t T, int d
         if (M * N >= (32LL << 20)) return false;
         if (!pr[i].dy || !pr[i].x || !pr[i].dw) return false;
         if ((((uintptr_t)pr[i].dy) | ((uintptr_t)pr[i].x) | ((uintptr_t)pr[i].dw)) & 15) return false;
-        if (pr[i].db && (pr[i].in_out || (((uintptr_t)pr[i].db) & 3))) return false;       // the column sums ride on the A operand: dy must be it
+        if (pr[i].db && (((uintptr_t)pr[i].db) & 15)) return false;                        // (round 6: also with an [in,out] weight, where dy is the B operand)
     }
     return true;
 }
@@ -1707,7 +1757,7 @@ int ctmi_wgrad_grouped_ex(const ctmi_wgrad_problem* pr, int n, int64_t T, int dt
     CTMI_REQUIRE(pr != nullptr, "wgrad_grouped: null problem list");
     if (!ctmi_wgrad_grouped_ok(pr, n, T, dtype)) {
         ctmi_set_error("wgrad_grouped: unsupported problem set (bf16 / fp16, <= %d problems, rows a multiple of 128 and columns of 256 of every gradient, T %% 32 == 0, "
-                       "16-byte aligned operands, no bias gradient with an [in,out] weight; CTMI_WGRAD_GROUP != 0)", WG_MAXP);
+                       "16-byte aligned operands and bias gradients; CTMI_WGRAD_GROUP != 0)", WG_MAXP);
         return CTMI_ERR_UNSUPPORTED;
     }
     hipStream_t st = as_stream(stream);
@@ -1723,7 +1773,7 @@ int ctmi_wgrad_grouped_ex(const ctmi_wgrad_problem* pr, int n, int64_t T, int dt
     // leaves half the CUs idle; said ONCE, because it changes the speed silently (round-5 advisor)
     {
         int64_t need = 0;
-        for (int i = 0; i < n; ++i) { const int64_t M = pr[i].in_out ? pr[i].n_in : pr[i].n_out, N = pr[i].in_out ? pr[i].n_out : pr[i].n_in; need += 2 * (M * N + M) * 4 + 512; }
+        for (int i = 0; i < n; ++i) { const int64_t M = pr[i].in_out ? pr[i].n_in : pr[i].n_out, N = pr[i].in_out ? pr[i].n_out : pr[i].n_in; need += 2 * (M * N + std::max(M, N)) * 4 + 512; }
         if (sh.split != 0 && (workspace == nullptr || workspace_bytes < need || (((uintptr_t)workspace) & 15))) {
             static std::atomic<bool> said{false};
             if (!said.exchange(true))
@@ -1733,6 +1783,7 @@ int ctmi_wgrad_grouped_ex(const ctmi_wgrad_problem* pr, int n, int64_t T, int dt
         }
     }
     GroupedArgs g = {};
+    bool bsum = false;                                                                      // some problem wants the column sums of its B operand
     g.M = 128; g.N = 256; g.K = T; g.k_per_split = T; g.splits = 1; g.alpha = 1.0f;       // (the single-problem fields are not read by a grouped launch)
     for (int i = 0; i < n; ++i) {
         const bool io = pr[i].in_out != 0;
@@ -1740,7 +1791,9 @@ int ctmi_wgrad_grouped_ex(const ctmi_wgrad_problem* pr, int n, int64_t T, int dt
         P.A = io ? pr[i].x : pr[i].dy; P.B = io ? pr[i].dy : pr[i].x; P.C = pr[i].dw; P.cs = pr[i].db;
         P.M = io ? pr[i].n_in : pr[i].n_out; P.N = io ? pr[i].n_out : pr[i].n_in;
         P.lda = P.M; P.ldb = P.N; P.ldc = P.N;
-        sh.M[i] = P.M; sh.N[i] = P.N; sh.cs[i] = P.cs != nullptr;
+        P.csn = io ? P.N : P.M;
+        sh.M[i] = P.M; sh.N[i] = P.N; sh.cs[i] = P.cs == nullptr ? 0 : (io ? 2 : 1);
+        bsum = bsum || (io && P.cs != nullptr);
     }
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -1772,12 +1825,13 @@ int ctmi_wgrad_grouped_ex(const ctmi_wgrad_problem* pr, int n, int64_t T, int dt
         char* w = reinterpret_cast<char*>(workspace);
         for (int i = 0; i < n; ++i) {
             g.p[i].part = reinterpret_cast<float*>(w); w += 2 * g.p[i].M * g.p[i].N * 4;
-            g.p[i].cspart = reinterpret_cast<float*>(w); w += (2 * g.p[i].M * 4 + 255) / 256 * 256;
+            g.p[i].cspart = reinterpret_cast<float*>(w); w += (2 * g.p[i].csn * 4 + 255) / 256 * 256;
         }
     }
     constexpr size_t lds = 6 * (size_t)(GTile<true, 128>::BYTES + GTile<true, 256>::BYTES);
     const unsigned grid = (unsigned)((persist && tab.nitems > slots) ? slots : tab.nitems);
-    auto kern = dtype == CTMI_F16 ? &gemm_wgrad_grouped_kernel_f16 : &gemm_wgrad_grouped_kernel;
+    auto kern = bsum ? (dtype == CTMI_F16 ? &gemm_wgrad_grouped_bsum_kernel_f16 : &gemm_wgrad_grouped_bsum_kernel)
+                     : (dtype == CTMI_F16 ? &gemm_wgrad_grouped_kernel_f16 : &gemm_wgrad_grouped_kernel);
     ctmi_dyn_lds(reinterpret_cast<const void*>(kern), lds);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, g);
     CTMI_CHECK_LAUNCH("wgrad_grouped");

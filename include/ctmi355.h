@@ -80,10 +80,11 @@ int ctmi_gemm(const void* A, int64_t lda, int a_kmajor, const void* B, int64_t l
  * modeling_bloom.py:79 (query_key_value), :121 (dense), :256 (dense_h_to_4h), :267 (dense_4h_to_h) — in ONE persistent launch:
  *   dw[n_out, n_in] (fp32, overwritten) = dy[T, n_out]^T x[T, n_in]        dy, x: row-major, dense, bf16 (or fp16)
  *   db[n_out]       (fp32, overwritten, optional) = column sums of dy      (the bias gradient; computed by the matrix cores against a vector of ones)
- *   in_out = 1: dw is written [n_in, n_out] (a Conv1D weight's own layout, modeling_gpt.py:32-46); db must be NULL then.
+ *   in_out = 1: dw is written [n_in, n_out] (a Conv1D weight's own layout, modeling_gpt.py:32-46); db (round 6: allowed there too) is then the sum of the
+ *               launch's B operand, taken by the tiles of the first tile row.  db must be 16-byte aligned.
  * Output tiles are 128 x 256; whole rounds of the 256 CUs accumulate over all T rows, the tiles of the last partial round are cut in two along T:
  * each half stores its partial tile into `workspace` and a small second launch adds the two in a fixed order (deterministic; without enough
- * workspace — 2 x (rows x columns + rows) floats per gradient — nothing is cut).  No split-K slabs of whole gradients, no separate column-sum pass.
+ * workspace — 2 x (rows x columns + max(rows, columns)) floats per gradient — nothing is cut).  No split-K slabs of whole gradients, no separate column-sum pass.
  * Needs dtype = CTMI_BF16 or CTMI_F16, n <= 4, T % 32 == 0, every gradient's rows a multiple of 128 and columns of 256, 16-byte aligned pointers: anything
  * else returns CTMI_ERR_UNSUPPORTED (callers then use ctmi_gemm(a_kmajor = b_kmajor = 1) per product).
  * CTMI_WGRAD_GROUP = 0 in the environment disables it (ctmi_bloom_block_bwd then launches the four products separately, as in ABI <= 12). */

@@ -25,6 +25,11 @@ def lib():
     return _lib
 
 
+def relerr(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max()) / (float(b.abs().max()) + 1e-30)
+
+
 def _problems(T, shapes, seed, scale=0.5, dtype=torch.bfloat16):
     g = torch.Generator(device=DEV).manual_seed(seed)
     bfr = lambda *sh: (torch.randn(*sh, generator=g, device=DEV) * scale).to(dtype)   # noqa: E731
@@ -99,18 +104,37 @@ def test_grouped_weight_gradients_on_half_operands():
             assert float((dw.double() - single.double()).norm() / (single.double().norm() + 1e-30)) < 2e-6, i
 
 
-def test_grouped_weight_gradients_in_out_layout():
-    """[in,out] gradients (Conv1D weights, modeling_gpt.py:32-46): dy is the B operand; a bias gradient is refused there"""
+GPT2 = [(1024, 4096, False), (4096, 1024, True), (1024, 1024, False), (3072, 1024, True)]        # the same four products through Conv1D ([in,out]) weights
+
+
+@pytest.mark.parametrize("T,shapes", [
+    (256, [(256, 512, False), (768, 256, False)]),                    # no bias gradients (the round-5 case)
+    (256, [(256, 512, True), (768, 256, True)]),                      # bias gradients = column sums of the launch's B operand (round 6)
+    (8192, GPT2),                                                     # GPT-2-medium's block: one whole round + 128 tiles cut in two (the sums of the cut tiles take the K-halves path)
+    (96, GPT2), (160, GPT2),                                          # 3 / 5 K-steps: single steps and odd halves
+    (512, [(256, 128, True)]),                                        # one tile [128 in, 256 out], cut in two
+    (1024, [(2048, 4096, True), (4096, 2048, True)]),                 # whole rounds only, several tile rows (only the first sums)
+], ids=lambda v: str(v) if isinstance(v, int) else f"{len(v)}p{sum(1 for t in v if t[2])}b")
+def test_grouped_weight_gradients_in_out_layout(T, shapes):
+    """[in,out] gradients (Conv1D weights, modeling_gpt.py:32-46): dy is the B operand of the launch; round 6: its column sums (the bias gradient)
+    come from the tiles of the first tile row — MFMAs of the B fragments against a fragment of ones (its own kernel instantiation: the Bloom
+    launch keeps its code).  Until then such steps ran a separate column-sum pass per bias."""
     o = ops()
-    T = 256
-    probs = _problems(T, [(256, 512, False), (768, 256, False)], seed=5)
+    probs = _problems(T, shapes, seed=5)
     outs = o.wgrad_grouped(probs, in_out=True)
     torch.cuda.synchronize()
-    for (dy, x, _), (dw, db) in zip(probs, outs):
-        assert dw.shape == (x.shape[1], dy.shape[1]) and db is None
-        _check_fp64("in_out", dy, x, dw, None, in_out=True)
-    with pytest.raises(lib().CtmiError):
-        o.wgrad_grouped(_problems(T, [(256, 512, True)], seed=6), in_out=True)
+    for (dy, x, want), (dw, db) in zip(probs, outs):
+        assert dw.shape == (x.shape[1], dy.shape[1]) and (db is not None) == want
+        _check_fp64("in_out", dy, x, dw, db, in_out=True)
+    # bias gradients of the two launch forms agree to the last bit of the MFMA's fp32 accumulation order per K-half: compare with [out,in] sums loosely
+    if any(x.shape[1] % 256 or dy.shape[1] % 128 for dy, x, _ in probs):
+        return                                                        # (the [out,in] launch tiles the transposed gradient: not every shape fits both)
+    outs2 = o.wgrad_grouped(probs, in_out=False)
+    torch.cuda.synchronize()
+    for (dw, db), (dw2, db2) in zip(outs, outs2):
+        assert relerr(dw.t(), dw2) < 1e-5
+        if db is not None:
+            assert relerr(db, db2) < 1e-5
 
 
 def test_grouped_weight_gradients_refuse_what_the_tiling_cannot_take():
