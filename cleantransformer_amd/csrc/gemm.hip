@@ -1508,7 +1508,9 @@ static void pick_tile(int64_t M, int64_t N, int64_t K, bool wgrad, bool bkm, int
             while (splits < max_splits && tiles * splits < items && K / (splits * 2) >= 1024) splits *= 2;
         }
     } else if (K >= 32768 && max_splits >= 2 && t2 * 2 >= 192) { tile = 3; splits = 2; }
-    else if (t2 >= tile3_min()) tile = 3;                                         // (also where 256x256 tiles fill their last round badly — QKV forward: 384
+    else if (t2 >= tile3_min() || (t2 == 256 && K >= 2048)) tile = 3;             // (round 6: exactly ONE full round of 256x256 tiles with a long K — the [T,H] outputs of the Bloom-7B1 geometry, T = H = 4096:
+                                                                                  // 204.2 -> 197.3 ms per step against two rounds of the 128-row tile, profiles/r06_bloom7b1_1gpu_bench.txt)
+                                                                                  // (also where 256x256 tiles fill their last round badly — QKV forward: 384
                                                                                   // tiles = 1.5 rounds; onto 768 tiles of 128x256 it is +4 % alone and 0.1 ms WORSE in the step, round 4)
     else if (t4 >= 256) tile = 4;                                  // (round 3: also K-major B with long K — 919 vs 861 TF/s on the QKV data gradient)
     else if (t1 >= 700) tile = 1;
