@@ -24,7 +24,7 @@
 #define CTMI_GEMM_PART (-1)
 #endif
 #ifndef CTMI_GELU_AUX_WT
-#define CTMI_GELU_AUX_WT 0
+#define CTMI_GELU_AUX_WT 0      // 1: the GELU pre-activation written through (sc1) instead of non-temporally — measured slower in the step, kept for A/B builds
 #endif
 #ifndef CTMI_SIDE_PRE8
 #define CTMI_SIDE_PRE8 1      // round 6: the 256-row ping-pong tile prefetches its epilogue's side input too (0: rounds 3-5 — such epilogues forced onto the 128-row tile)
@@ -711,7 +711,7 @@ __device__ __forceinline__ void glds_body(const GA g) {   // (by value: through 
                     // the pre-activation is kept for the BACKWARD only (a whole forward and half a backward away): CTMI_GELU_AUX_NT writes it
                     // non-temporally, so that the activation next to it — the A operand of the very next GEMM — is what stays in the caches
                     // (same box, interleaved: forward chain of 24 blocks 6.16 / 6.26 -> 6.07 / 6.05 ms, step 37.01-37.35 -> 36.83-37.08 ms)
-                    if constexpr (sizeof(T) == 2 && CTMI_GELU_AUX_WT) st_wt16(AUXO + off, tb);                 // (round 6: written through — like nt it does not stay in the XCD's L2, and the kernel's end does not wait for 64 MB of dirty lines)
+                    if constexpr (sizeof(T) == 2 && CTMI_GELU_AUX_WT) st_wt16(AUXO + off, tb);                 // (-DCTMI_GELU_AUX_WT=1, A/B builds only: written through like the tile itself — measured +0.2 ms per step against the non-temporal store below, profiles/r06_boundary_dirty.txt)
                     else if constexpr (sizeof(T) == 2) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, tb), reinterpret_cast<u32x4*>(AUXO + off));   // (the builtin, not asm: hipcc's hazard recognizer does not see into asm, and a first asm version — no wait state between the 16-byte store and the next write of its data registers — stored garbage in a few rows; tests/test_gpu_ops.py::test_gemm_at_the_step_shapes_sampled_vs_fp64 caught it)
                     else *reinterpret_cast<uint4*>(AUXO + off) = tb;
                     unpack16<T>(tb, v);
