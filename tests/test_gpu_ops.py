@@ -744,7 +744,12 @@ STEP_GEMMS = [  # name, kind, rows T, out features, in features, epilogue       
     ("h4h", "dgrad", 8192, 4096, 1024, None), ("4hh", "dgrad", 8192, 1024, 4096, "dgelu"), ("4hh", "dgrad", 8192, 1024, 4096, "mul"),
     ("qkv", "wgrad", 8192, 3072, 1024, None), ("dense", "wgrad", 8192, 1024, 1024, None), ("h4h", "wgrad", 8192, 4096, 1024, None),
     ("4hh", "wgrad", 8192, 1024, 4096, None), ("lm_head", "fwd", 8192, 250880, 1024, None), ("lm_head", "dgrad", 8192, 250880, 1024, None),
-    ("lm_head", "wgrad", 8192, 250880, 1024, None)]
+    ("lm_head", "wgrad", 8192, 250880, 1024, None),
+    # Bloom-7B1 geometry on one GPU (BASELINE configs[4]: T = 2 x 2048, H = 4096): the [T,H] outputs — exactly ONE full round of 256x256 tiles with
+    # K = 4096 / 12288 / 16384 — take the 256-row ping-pong tile since round 6 (pick_tile: t2 == 256 && K >= 2048), the residual forwards on its
+    # non-prefetching epilogue variant
+    ("7b1-dense", "fwd", 4096, 4096, 4096, "bias+res"), ("7b1-4hh", "fwd", 4096, 4096, 16384, "bias+res"), ("7b1-qkv", "dgrad", 4096, 12288, 4096, None),
+    ("7b1-dense", "dgrad", 4096, 4096, 4096, None), ("7b1-h4h", "dgrad", 4096, 16384, 4096, None)]
 
 
 @pytest.mark.parametrize("name,kind,T,Nout,Kin,epi", STEP_GEMMS, ids=lambda v: str(v))
